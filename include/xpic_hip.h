@@ -1,0 +1,165 @@
+/*
+ * xpic_hip.h -- C ABI of the MI355X (gfx950) implementation of xpic's per-timestep hot path.
+ *
+ * The reference (vakurshakov/xpic) has no FFI: its hot path is reached through the C++ virtual
+ * `interfaces::Simulation::timestep_implementation()` (src/interfaces/simulation.h:71-72) and the
+ * public members of `interfaces::Simulation` / `interfaces::Particles`.  This header is the boundary a
+ * `impls/` backend binds UNDERNEATH those classes: every entry point names the reference function it
+ * replaces (file:line relative to the reference checkout).  INTEGRATION.md shows the subclass a
+ * maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error (slots into `PetscCall`); the message
+ *     of the last error of the calling thread is returned by xpic_last_error().
+ *   - field vectors cross the boundary in the reference's DMDA layout: double[nz][ny][nx][3]
+ *     (x fastest, 3 components interleaved; src/utils/vector3.h:233, src/utils/world.h:35-43).
+ *   - particles cross the boundary as `struct Point` records: double[6] = {x,y,z,px,py,pz}
+ *     (src/interfaces/point.h:7-35).  Inside, both are re-laid out.
+ *   - pointers are HOST pointers unless the parameter is called `dptr` (device pointer).
+ *   - all boundaries are periodic (every BASELINE config); anything else is rejected at create.
+ */
+#ifndef XPIC_HIP_H
+#define XPIC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct xpic_ctx xpic_ctx;
+
+/* Geometry: globals dx,dy,dz,dt,geom_n* (src/constants.h:10-28) + World (src/utils/world.h:11-61). */
+typedef struct xpic_geometry {
+  int32_t n[3];     /* global cells geom_nx, geom_ny, geom_nz */
+  double d[3];      /* dx, dy, dz */
+  double dt;
+  int32_t periodic[3]; /* must be {1,1,1}: DM_BOUNDARY_PERIODIC */
+  int32_t rank;     /* z-slab index of this context (DMDA da_processors_z) */
+  int32_t nranks;   /* number of z-slabs */
+  int32_t device;   /* HIP device ordinal */
+} xpic_geometry;
+
+/* SortParameters (src/interfaces/sort_parameters.h:7-19) */
+typedef struct xpic_sort_params {
+  int32_t Np;
+  double n, q, m;
+} xpic_sort_params;
+
+/* named global vectors of interfaces::Simulation / ecsim::Simulation / ecsimcorr::Simulation
+ * (src/interfaces/simulation.h:33-48, src/impls/ecsim/simulation.h:27-28, ecsimcorr/simulation.h:17-18) */
+enum xpic_field {
+  XPIC_E = 0, XPIC_B = 1, XPIC_B0 = 2, XPIC_J = 3, XPIC_EP = 4, XPIC_EC = 5, XPIC_CURRI = 6,
+  XPIC_CURRJE = 7, XPIC_W0 = 8, XPIC_W1 = 9, XPIC_W2 = 10, XPIC_NFIELDS = 11
+};
+
+enum xpic_scheme { XPIC_BASIC = 0, XPIC_ECSIM = 1, XPIC_ECSIMCORR = 2 };
+
+/* operator / method selector of xpic_solve */
+enum xpic_solve_op {
+  XPIC_OP_MATA_GMRES = 0, /* (matL + matM) x = b, GMRES(30): KSP "predict" (ecsim/simulation.cpp:197-201,266) */
+  XPIC_OP_MATM_GMRES = 1, /* matM x = b, GMRES(30): KSP "correct" (ecsimcorr/simulation.cpp:133) */
+  XPIC_OP_MATM_CG = 2     /* matM x = b, CG (matM is SPD on periodic boundaries) */
+};
+
+#define XPIC_LSTENCIL 123 /* couplings per matL row: 27 same-component + 48 + 48 */
+
+const char* xpic_last_error(void);
+int xpic_version(void);
+
+/* World::initialize + Simulation::initialize_implementation (world.cpp:11-48; ecsim/simulation.cpp:122-143,
+ * 517-567; basic/simulation.cpp:8-28): allocates E,B,B0,J,(Ep,Ec,currI,currJe), operators and solver state. */
+int xpic_create(const xpic_geometry* geom, int scheme, xpic_ctx** out);
+int xpic_destroy(xpic_ctx* ctx); /* Simulation::finalize (ecsim/simulation.cpp:569-590) */
+int xpic_synchronize(xpic_ctx* ctx);
+
+/* init_particles -> PartSpec(sim, SortParameters) (src/interfaces/simulation.tpp:43); capacity in particles */
+int xpic_add_sort(xpic_ctx* ctx, const xpic_sort_params* p, int64_t capacity, int* sort_out);
+/* Particles::add_particle (src/interfaces/particles.cpp:47-67) for n Points: binned by FLOOR_STEP, points
+ * outside the local box are dropped; *added = number kept. Appends to what the sort already holds. */
+int xpic_sort_add_particles(xpic_ctx* ctx, int sort, int64_t n, const double* points6, int64_t* added);
+int xpic_sort_count(xpic_ctx* ctx, int sort, int64_t* count);
+/* storage read-back in cell order: points6[count][6], cell_of[count] = local cell index g (world.s_g) */
+int xpic_sort_get_particles(xpic_ctx* ctx, int sort, double* points6, int32_t* cell_of);
+int xpic_sort_clear(xpic_ctx* ctx, int sort);
+/* synthetic plasma generated on the device (bench/smoke only; no reference counterpart): ppc particles per
+ * cell, uniform in the cell, Maxwellian velocities of thermal spread vth (then v /= sqrt(1+v^2), "tov") */
+int xpic_sort_fill_synthetic(xpic_ctx* ctx, int sort, int ppc, double vth, uint64_t seed);
+
+/* Vec access (DMDAVecGetArray / VecGetArray): copies in/out in the [z][y][x][3] layout, local slab */
+int xpic_field_set(xpic_ctx* ctx, int field, const double* v);
+int xpic_field_get(xpic_ctx* ctx, int field, double* v);
+int xpic_sort_current_get(xpic_ctx* ctx, int sort, int which /* XPIC_J | XPIC_CURRI | XPIC_CURRJE */, double* v);
+
+/* ---- BLAS-1 on named vectors (VecSet/VecAXPY/VecAXPBY/VecDot/VecNorm; K14) */
+int xpic_vec_set(xpic_ctx* ctx, int y, double alpha);
+int xpic_vec_axpy(xpic_ctx* ctx, int y, double alpha, int x);                 /* y += alpha x */
+int xpic_vec_axpby(xpic_ctx* ctx, int y, double alpha, double beta, int x);  /* y = alpha x + beta y */
+int xpic_vec_dot(xpic_ctx* ctx, int x, int y, double* out);
+int xpic_vec_norm2(xpic_ctx* ctx, int x, double* out);
+
+/* ---- operators (K11-K13) on named vectors; `add` != 0 gives MatMultAdd (y += ...) */
+/* Rotor (src/utils/operators.cpp:155-215): y (+)= alpha * rot(sign) x; sign +1 = rotE, -1 = rotB */
+int xpic_rot_apply(xpic_ctx* ctx, int sign, double alpha, int x, int y, int add);
+/* matM = 2 I + 0.5 dt^2 rotB rotE (src/impls/ecsim/simulation.cpp:544-551) */
+int xpic_matM_apply(xpic_ctx* ctx, int x, int y, int add);
+/* matL as filled by xpic_ecsim_fill_current (MatMultAdd(matL,...) ecsimcorr/simulation.cpp:78) */
+int xpic_matL_apply(xpic_ctx* ctx, int x, int y, int add);
+/* matA = matL + matM (ecsim/simulation.cpp:197-198) */
+int xpic_matA_apply(xpic_ctx* ctx, int x, int y);
+/* matL read-back as double[3N][XPIC_LSTENCIL], row = ((z*ny+y)*nx+x)*3+c, k as xpic_lstencil_decode */
+int xpic_matL_get(xpic_ctx* ctx, double* out);
+void xpic_lstencil_decode(int c1, int k, int* c2, int* d3);
+
+/* ---- per-phase entry points */
+/* ecsim::Particles::first_push (src/impls/ecsim/particles.cpp:21-31): r += dt*p */
+int xpic_ecsim_first_push(xpic_ctx* ctx, int sort);
+/* Particles::update_cells_seq / correct_coordinates (src/interfaces/particles.cpp:79-116,329-339):
+ * periodic wrap, re-bin by FLOOR_STEP, drop what falls outside; *count = particles left */
+int xpic_update_cells(xpic_ctx* ctx, int sort, int64_t* count);
+/* ecsim::Simulation::fill_ecsim_current + Particles::fill_ecsim_current/decompose_ecsim_current
+ * (src/impls/ecsim/simulation.cpp:336-368,471-484; particles.cpp:33-173): zeroes then fills currI
+ * (per sort and total) and matL from all sorts, gathering B */
+int xpic_ecsim_fill_current(xpic_ctx* ctx);
+/* ecsim::Particles::second_push (src/impls/ecsim/particles.cpp:175-192): CIC gather of Ep and B, update_vEB(dt) */
+int xpic_ecsim_second_push(xpic_ctx* ctx, int sort);
+/* basic::Particles::push (src/impls/basic/particles.cpp:17-53): half move, 2nd-order gather, Boris, half move,
+ * Esirkepov into the sort's J and the simulation's J */
+int xpic_basic_push(xpic_ctx* ctx, int sort);
+/* ecsimcorr::Particles::{first_push, second_push, final_update, calculate_energy}
+ * (src/impls/ecsimcorr/particles.cpp:27-50, 52-91, 93-126, 134-150) */
+int xpic_ecsimcorr_first_push(xpic_ctx* ctx, int sort);
+int xpic_ecsimcorr_second_push(xpic_ctx* ctx, int sort);
+int xpic_ecsimcorr_final_update(xpic_ctx* ctx, int sort);
+int xpic_calculate_energy(xpic_ctx* ctx, int sort, double* energy);
+/* pred_w, corr_w, lambda_dK, pred_dK, corr_dK, energy (ecsimcorr/particles.h:44-49) */
+int xpic_ecsimcorr_scalars(xpic_ctx* ctx, int sort, double* out6);
+
+/* KSPSolve (src/impls/ecsim/simulation.cpp:266): x0 = 0, no preconditioner, converged when
+ * ||r|| <= max(rtol ||b||, atol). *iterations >= 0; *reason > 0 converged, < 0 diverged (maxit).
+ * A non-converged solve RETURNS NON-ZERO, like KSPSetErrorIfNotConverged (:562). */
+int xpic_solve(xpic_ctx* ctx, int op, int rhs, int x, double rtol, double atol, int maxit, int* iterations,
+  int* reason, double* rnorm);
+/* KSPSetTolerances used by the step drivers (src/impls/ecsim/simulation.h:15-18: 1e-7,1e-7,100) */
+int xpic_set_tolerances(xpic_ctx* ctx, double rtol, double atol, int maxit);
+
+/* timestep_implementation of the context's scheme (basic/simulation.cpp:30-43, ecsim/simulation.cpp:145-155,
+ * ecsimcorr/simulation.cpp:21-32); *ksp_iterations = Krylov iterations spent in this step */
+int xpic_step(xpic_ctx* ctx, int* ksp_iterations);
+
+/* Energy::calculate_field/calculate_kinetic (src/diagnostics/energy.cpp:43-108):
+ * out = {wE, wB, sE, sB, wK_0, sK_0, wK_1, sK_1, ...} */
+int xpic_energy(xpic_ctx* ctx, double* out);
+
+/* ---- measurement: HIP-event timers around kernel families, on the context's own stream */
+int xpic_profile_enable(xpic_ctx* ctx, int on);
+int xpic_profile_reset(xpic_ctx* ctx);
+/* name: "matA_apply","matL_apply","matM_apply","fill_current","move_bin","scatter","second_push",... */
+int xpic_profile_get(xpic_ctx* ctx, const char* name, int64_t* launches, double* total_ms);
+/* device copy bandwidth probe (bytes moved / s) measured with a float4-style copy kernel */
+int xpic_probe_copy_bandwidth(xpic_ctx* ctx, int64_t bytes, int reps, double* bytes_per_s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -32,13 +32,26 @@ def build():
 _lib = None
 
 
+def default_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("XPIC_ORACLE_THREADS", "16"))))
+
+
 def lib():
     global _lib
     if _lib is not None:
         return _lib
     if not os.path.exists(_SO):
         build()
+    # The GPU box exposes far more logical CPUs than its CPU share: an oversubscribed, spin-waiting OpenMP team
+    # makes the thousands of small parallel regions of the oracle's GMRES crawl.  Cap the team and wait passively.
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     L = C.CDLL(_SO)
+    L.orc_set_threads.argtypes = [C.c_int]
+    L.orc_set_threads(default_threads())
     L.orc_create.restype = C.c_void_p
     L.orc_create.argtypes = [C.c_int] * 4 + [C.c_double] * 4
     L.orc_destroy.argtypes = [C.c_void_p]

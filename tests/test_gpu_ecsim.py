@@ -1,0 +1,299 @@
+"""GPU parity tests of the ECSIM path: every call goes through the C ABI (xpic_amd.Context -> libxpic_hip.so)
+and is compared with the CPU oracle on the same seeded inputs, or with the reference's golden tables.
+
+Tolerances: integers (cells, counts) exact; particle r, v after a phase <= 4 ulp-ish
+(1e-14 relative: only FMA contraction differs); deposited currents / matL <= 1e-12 of the max entry
+(summation order of atomics); solver solutions <= 1e-6 relative (10 x rtol).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def canon(pts, cells):
+    """Order particles by (cell, x, y, z, vx, vy, vz): storage order inside a cell is not part of the contract."""
+    key = np.lexsort((pts[:, 5], pts[:, 4], pts[:, 3], pts[:, 2], pts[:, 1], pts[:, 0], cells))
+    return pts[key], cells[key]
+
+
+def make_pair(oracle, scheme, n, d, dt, sorts, seed=0, ppc=6, vth=0.05, B0=(0.0, 0.0, 0.0)):
+    """Builds an oracle sim and a GPU context holding identical particles and fields."""
+    import xpic_amd
+
+    rng = np.random.default_rng(seed)
+    o = oracle.OracleSim(scheme, n, d, dt)
+    g = xpic_amd.Context(scheme, n, d, dt)
+    N = n[0] * n[1] * n[2]
+    for (Np, dens, q, m) in sorts:
+        so = o.add_sort(Np, dens, q, m)
+        sg = g.add_sort(Np, dens, q, m, capacity=max(4 * ppc * N, 1024))
+        npart = ppc * N
+        L = np.array(n) * np.array(d)
+        pts = np.empty((npart, 6))
+        pts[:, :3] = rng.random((npart, 3)) * L
+        pts[:, 3:] = rng.normal(0, vth, (npart, 3))
+        assert o.add_particles(so, pts) == g.add_particles(sg, pts)
+    for name, fid in (("E", xpic_amd.E), ("B", xpic_amd.B)):
+        F = rng.normal(0, 0.05, o.fshape())
+        if name == "B":
+            F += np.array(B0)
+        o.set_field(name, F)
+        g.set_field(fid, F)
+    b0 = np.zeros(o.fshape()) + np.array(B0)
+    o.set_field("B0", b0)
+    g.set_field(xpic_amd.B0, b0)
+    return o, g
+
+
+GRID = ((12, 10, 8), (0.5, 0.4, 0.25), 0.7)
+
+
+def test_operators_match_oracle(oracle):
+    import xpic_amd as X
+
+    n, d, dt = GRID
+    o, g = make_pair(oracle, "ecsim", n, d, dt, [])
+    F = o.get_field("E")
+    for sign in (+1, -1):
+        g.rot_apply(sign, 0.37, X.E, X.W2)
+        ref = o.rot(sign, 0.37, F)
+        assert np.abs(g.get_field(X.W2) - ref).max() <= 1e-14 * np.abs(ref).max()
+    g.matM_apply(X.E, X.W2)
+    ref = o.matM(F)
+    assert np.abs(g.get_field(X.W2) - ref).max() <= 1e-13 * np.abs(ref).max()
+    # BLAS-1
+    assert np.isclose(g.vec_dot(X.E, X.B), float((F * o.get_field("B")).sum()), rtol=1e-12)
+    assert np.isclose(g.vec_norm2(X.E), np.sqrt((F * F).sum()), rtol=1e-13)
+    g.vec_axpby(X.W2, 2.0, -1.0, X.E)  # W2 = 2 E - W2
+    assert np.abs(g.get_field(X.W2) - (2 * F - ref)).max() <= 1e-13 * np.abs(ref).max()
+
+
+def test_add_particles_bins_like_add_particle(oracle):
+    """add_particle (particles.cpp:47-67): exact cell of every kept particle, outside points dropped."""
+    import xpic_amd as X
+
+    n, d, dt = GRID
+    o = oracle.OracleSim("ecsim", n, d, dt)
+    g = X.Context("ecsim", n, d, dt)
+    so = o.add_sort(1, 1.0, -1.0, 1.0)
+    sg = g.add_sort(1, 1.0, -1.0, 1.0, capacity=10000)
+    rng = np.random.default_rng(5)
+    L = np.array(n) * np.array(d)
+    pts = np.zeros((5000, 6))
+    pts[:, :3] = rng.random((5000, 3)) * L * 1.2 - 0.1 * L  # ~40 % outside
+    pts[:, 3:] = rng.normal(0, 1, (5000, 3))
+    # exact cell boundaries and box edges
+    pts[0, :3] = 0.0
+    pts[1, :3] = L  # == Geom: outside
+    pts[2, :3] = np.array(d) * 3
+    pts[3, :3] = L - 1e-15
+    ko, kg = o.add_particles(so, pts), g.add_particles(sg, pts)
+    assert ko == kg == g.count(sg) and 0 < kg < 5000
+    po, co = canon(*o.particles(so))
+    pg, cg = canon(*g.particles(sg))
+    assert np.array_equal(co, cg)
+    assert np.array_equal(po, pg)
+    # empty append is fine
+    assert g.add_particles(sg, np.zeros((0, 6))) == 0
+
+
+def test_first_push_and_update_cells_exact(oracle):
+    """a9 + a14: r += dt v, periodic wrap (one fold, s == L kept), FLOOR_STEP re-binning, drop outside."""
+    import xpic_amd as X
+
+    n, d, dt = GRID
+    o, g = make_pair(oracle, "ecsim", n, d, 4.0, [(4, 1.0, -1.0, 1.0)], vth=0.6, ppc=5)
+    lib = oracle.lib()
+    lib.orc_ecsim_first_push(o.h, 0)
+    g.ecsim_first_push(0)
+    po, _ = o.particles(0)
+    pg, _ = g.particles(0)
+    # same storage order before re-binning only up to the initial sort: compare as sets
+    assert np.array_equal(po[np.lexsort(po.T[::-1])], pg[np.lexsort(pg.T[::-1])])
+    lib.orc_update_cells(o.h, 0)
+    left = g.update_cells(0)
+    assert left == o.count(0) == g.count(0)
+    assert left < 5 * 12 * 10 * 8  # with v*dt of several cells some particles fold twice -> dropped
+    po, co = canon(*o.particles(0))
+    pg, cg = canon(*g.particles(0))
+    assert np.array_equal(co, cg)
+    assert np.array_equal(po, pg)  # bit-exact positions: same single-fold arithmetic
+    assert np.all(np.diff(g.particles(0)[1]) >= 0)  # storage is cell-sorted
+
+
+@pytest.mark.parametrize("B0", [(0.0, 0.0, 0.0), (0.3, -0.2, 0.9)])
+def test_fill_current_and_matL(oracle, B0):
+    """a10 + a11 + a18: currI and the 123-coefficient rows of matL, two species."""
+    import xpic_amd as X
+
+    n, d, dt = GRID
+    o, g = make_pair(oracle, "ecsim", n, d, dt, [(6, 1.0, -1.0, 1.0), (6, 1.0, +1.0, 100.0)], B0=B0)
+    oracle.lib().orc_ecsim_fill_current(o.h)
+    g.ecsim_fill_current()
+    ci_o, ci_g = o.get_field("currI"), g.get_field(X.CURRI)
+    assert np.abs(ci_o - ci_g).max() <= 1e-12 * np.abs(ci_o).max()
+    for s in range(2):
+        a, b = o.sort_current(s, "currI"), g.sort_current(s, X.CURRI)
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
+    Lo, Lg = o.matL(), g.matL()
+    assert np.abs(Lo).max() > 0
+    assert np.abs(Lo - Lg).max() <= 1e-12 * np.abs(Lo).max()
+    # SpMV on the assembled operator, alone and fused with matM
+    x = o.get_field("E")
+    g.matL_apply(X.E, X.W2)
+    ref = o.matL_apply(x)
+    assert np.abs(g.get_field(X.W2) - ref).max() <= 1e-12 * np.abs(ref).max()
+    g.matA_apply(X.E, X.W2)
+    ref = ref + o.matM(x)
+    assert np.abs(g.get_field(X.W2) - ref).max() <= 1e-12 * np.abs(ref).max()
+    g.matL_apply(X.E, X.W2, add=True)
+    ref = ref + o.matL_apply(x)
+    assert np.abs(g.get_field(X.W2) - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_lstencil_layout_is_shared(oracle):
+    import xpic_amd as X
+    import ctypes as C
+
+    L = oracle.lib()
+    for c1 in range(3):
+        seen = set()
+        for k in range(123):
+            c2 = C.c_int()
+            dd = (C.c_int * 3)()
+            L.orc_lstencil_decode(c1, k, C.byref(c2), dd)
+            assert X.lstencil_decode(c1, k) == (c2.value, (dd[0], dd[1], dd[2]))
+            seen.add((c2.value, dd[0], dd[1], dd[2]))
+        assert len(seen) == 123
+
+
+@pytest.mark.parametrize("op", [0, 1, 2])
+def test_solve_matches_oracle(oracle, op):
+    """a19: GMRES(30) on matL+matM, GMRES and CG on matM; same method on both sides, 10 x rtol agreement."""
+    import xpic_amd as X
+
+    n, d, dt = GRID
+    o, g = make_pair(oracle, "ecsim", n, d, 1.5, [(8, 1.0, -1.0, 1.0)], B0=(0.0, 0.0, 0.5))
+    oracle.lib().orc_ecsim_fill_current(o.h)
+    g.ecsim_fill_current()
+    rhs = o.get_field("E")
+    xo, its_o, rn_o = o.solve(op, rhs, 1e-9, 1e-50, 300)
+    its_g, reason, rn_g = g.solve(op, X.E, X.W2, 1e-9, 1e-50, 300)
+    assert its_o > 0 and reason > 0
+    assert abs(its_o - its_g) <= 1
+    xg = g.get_field(X.W2)
+    assert np.abs(xo - xg).max() <= 1e-6 * np.abs(xo).max()
+    # true residual of the GPU solution, evaluated by the oracle's operator
+    Ax = o.matM(xg) + (o.matL_apply(xg) if op == 0 else 0)
+    assert np.linalg.norm(Ax - rhs) <= 1e-8 * np.linalg.norm(rhs)
+
+
+def test_solve_reports_non_convergence(oracle):
+    """KSPSetErrorIfNotConverged(TRUE) (ecsim/simulation.cpp:562): hitting maxit is an error."""
+    import xpic_amd as X
+
+    n, d, dt = GRID
+    o, g = make_pair(oracle, "ecsim", n, d, 1.5, [(4, 1.0, -1.0, 1.0)])
+    g.ecsim_fill_current()
+    with pytest.raises(X.XpicError, match="did not converge"):
+        g.solve(0, X.E, X.W2, 1e-14, 1e-50, 3)
+
+
+def test_second_push_matches_oracle(oracle):
+    """a8 + a3 + a12: CIC Yee gather of Ep and B, Boris update."""
+    import xpic_amd as X
+
+    n, d, dt = GRID
+    o, g = make_pair(oracle, "ecsim", n, d, dt, [(5, 1.0, -1.0, 1.0)], B0=(0.1, 0.2, -0.6), vth=0.2)
+    Ep = np.random.default_rng(3).normal(0, 0.1, o.fshape())
+    o.set_field("Ep", Ep)
+    g.set_field(X.EP, Ep)
+    oracle.lib().orc_ecsim_second_push(o.h, 0)
+    g.ecsim_second_push(0)
+    po, co = canon(*o.particles(0))
+    pg, cg = canon(*g.particles(0))
+    assert np.array_equal(co, cg)
+    assert np.array_equal(po[:, :3], pg[:, :3])
+    assert np.abs(po[:, 3:] - pg[:, 3:]).max() <= 1e-14
+
+
+def test_full_steps_match_oracle_and_conserve_energy(oracle):
+    import xpic_amd as X
+
+    n, d, dt = GRID
+    o, g = make_pair(oracle, "ecsim", n, d, 1.0, [(8, 1.0, -1.0, 1.0), (8, 1.0, 1.0, 1836.0)], B0=(0.0, 0.0, 0.2), vth=0.03)
+    for s in (o, g):
+        s.set_tolerances(1e-10, 1e-50, 300)
+    e0 = g.energy()
+    for t in range(3):
+        io, ig = o.step(), g.step()
+        assert io > 0 and abs(io - ig) <= 1
+        eo, eg = o.energy(), g.energy()
+        assert np.allclose(eo, eg, rtol=1e-7, atol=1e-14)
+        for name, fid in (("E", X.E), ("B", X.B)):
+            a, b = o.get_field(name), g.get_field(fid)
+            assert np.abs(a - b).max() <= 1e-6 * np.abs(a).max()
+        tot0 = e0[0] + e0[1] + e0[4] + e0[6]
+        tot = eg[0] + eg[1] + eg[4] + eg[6]
+        assert abs(tot - tot0) <= 1e-9 * tot0  # ECSIM conserves energy to solver tolerance
+    for s in range(2):
+        assert o.count(s) == g.count(s)
+        assert np.array_equal(canon(*o.particles(s))[1], canon(*g.particles(s))[1])
+
+
+def test_reference_golden_ecsim_ex1(oracle):
+    """The reference's own integration test (tests/ecsim/ecsim_ex1.cpp) through the HIP path: RNG-exact
+    initial particles from the oracle's loader, then rows 0 and 1 of energy.txt to every printed digit."""
+    import xpic_amd as X
+
+    oracle.lib().orc_reset_rng()
+    o = oracle.OracleSim("ecsim", (10, 10, 10), (0.5, 0.5, 0.5), 1.5)
+    so = o.add_sort(100, 1.0, -1.0, 1.0, (0.1, 0.1, 0.1))
+    o.load_maxwell_box(so, True)
+    pts, _ = o.particles(so)
+    g = X.Context("ecsim", (10, 10, 10), (0.5, 0.5, 0.5), 1.5)
+    sg = g.add_sort(100, 1.0, -1.0, 1.0, capacity=200000)
+    assert g.add_particles(sg, pts) == 100000
+    _, gold = oracle.read_table(os.path.join(GOLD, "ecsim_ex1", "energy.txt"))
+
+    def row(en):
+        return np.array([float("% .6e" % v) for v in (en[0], en[1], en[4], en[2], en[3], en[5])])
+
+    assert np.abs(row(g.energy()) - gold[0, 1:]).max() < 1e-10
+    prev = g.energy()
+    for t in range(1, 6):
+        assert g.step() > 0
+        en = g.energy()
+        if t == 1:
+            assert np.abs(row(en) - gold[1, 1:]).max() < 1e-10
+        else:
+            assert np.allclose(row(en), gold[t, 1:], rtol=1e-3)
+        d = (en[0] - prev[0]) + (en[1] - prev[1]) + (en[4] - prev[4])
+        assert abs(d) < 5e-12  # golden dE+dB+dK column: ~1e-13
+        prev = en
+
+
+def test_config2_size_properties():
+    """BASELINE config-2 size (128^3, 32 ppc = 67 M particles), size-independent properties only:
+    particle count conserved, storage stays cell-sorted, exact energy conservation, solver converges."""
+    import xpic_amd as X
+
+    n = (128, 128, 128)
+    g = X.Context("ecsim", n, (0.5, 0.5, 0.5), 1.0)
+    N = n[0] * n[1] * n[2]
+    s = g.add_sort(32, 1.0, -1.0, 1.0, capacity=int(32 * N * 1.05))
+    g.fill_synthetic(s, 32, 0.02, seed=7)
+    assert g.count(s) == 32 * N
+    e0 = g.energy()
+    for t in range(2):
+        assert 0 < g.step() <= 100
+    e1 = g.energy()
+    assert g.count(s) == 32 * N
+    tot0, tot1 = e0[0] + e0[1] + e0[4], e1[0] + e1[1] + e1[4]
+    assert abs(tot1 - tot0) <= 1e-7 * tot0
+    assert e1[0] > 0 and e1[1] > 0

@@ -1,0 +1,275 @@
+"""xpic_amd -- MI355X (gfx950) implementation of xpic's per-timestep hot path.
+
+This package is a thin ctypes view of the C ABI in include/xpic_hip.h (xpic_amd/libxpic_hip.so, built from
+xpic_amd/csrc/*.hip by `make` / `__graft_entry__.build()`).  There is NO CPU fallback: if the shared library
+or a HIP device is missing, every entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxpic_hip.so")
+
+E, B, B0, J, EP, EC, CURRI, CURRJE, W0, W1, W2 = range(11)
+BASIC, ECSIM, ECSIMCORR = 0, 1, 2
+OP_MATA_GMRES, OP_MATM_GMRES, OP_MATM_CG = 0, 1, 2
+LSTENCIL = 123
+SCHEMES = {"basic": BASIC, "ecsim": ECSIM, "ecsimcorr": ECSIMCORR}
+
+# every symbol include/xpic_hip.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "xpic_last_error", "xpic_version", "xpic_create", "xpic_destroy", "xpic_synchronize", "xpic_add_sort",
+    "xpic_sort_add_particles", "xpic_sort_count", "xpic_sort_get_particles", "xpic_sort_clear",
+    "xpic_sort_fill_synthetic", "xpic_field_set", "xpic_field_get", "xpic_sort_current_get", "xpic_vec_set",
+    "xpic_vec_axpy", "xpic_vec_axpby", "xpic_vec_dot", "xpic_vec_norm2", "xpic_rot_apply", "xpic_matM_apply",
+    "xpic_matL_apply", "xpic_matA_apply", "xpic_matL_get", "xpic_lstencil_decode", "xpic_ecsim_first_push",
+    "xpic_update_cells", "xpic_ecsim_fill_current", "xpic_ecsim_second_push", "xpic_basic_push",
+    "xpic_ecsimcorr_first_push", "xpic_ecsimcorr_second_push", "xpic_ecsimcorr_final_update",
+    "xpic_calculate_energy", "xpic_ecsimcorr_scalars", "xpic_solve", "xpic_set_tolerances", "xpic_step",
+    "xpic_energy", "xpic_profile_enable", "xpic_profile_reset", "xpic_profile_get", "xpic_probe_copy_bandwidth",
+]
+
+
+class XpicError(RuntimeError):
+    pass
+
+
+class Geometry(C.Structure):
+    _fields_ = [("n", C.c_int32 * 3), ("d", C.c_double * 3), ("dt", C.c_double), ("periodic", C.c_int32 * 3),
+                ("rank", C.c_int32), ("nranks", C.c_int32), ("device", C.c_int32)]
+
+
+class SortParams(C.Structure):
+    _fields_ = [("Np", C.c_int32), ("n", C.c_double), ("q", C.c_double), ("m", C.c_double)]
+
+
+_lib = None
+c_dp = C.POINTER(C.c_double)
+
+
+def load_library():
+    """Loads libxpic_hip.so; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise XpicError(f"{LIB_PATH} is missing: run `make` (or __graft_entry__.build()) first; "
+                        "xpic_amd has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    L.xpic_last_error.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def _dp(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_dp)
+
+
+class Context:
+    """One z-slab context = one `interfaces::Simulation` backend instance."""
+
+    def __init__(self, scheme, n, d, dt, device=0, rank=0, nranks=1):
+        self.L = load_library()
+        g = Geometry()
+        g.n[:] = [int(v) for v in n]
+        g.d[:] = [float(v) for v in d]
+        g.dt = float(dt)
+        g.periodic[:] = [1, 1, 1]
+        g.rank, g.nranks, g.device = rank, nranks, device
+        self.n = tuple(int(v) for v in n)
+        self.d = tuple(float(v) for v in d)
+        self.dt = float(dt)
+        self.scheme = scheme
+        self.h = C.c_void_p()
+        self._ck(self.L.xpic_create(C.byref(g), SCHEMES[scheme], C.byref(self.h)))
+        self.N = self.n[0] * self.n[1] * self.n[2]
+        self.nsorts = 0
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise XpicError(f"xpic error {rc}: {self.L.xpic_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.xpic_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- particles
+    def add_sort(self, Np, n, q, m, capacity):
+        p = SortParams(int(Np), float(n), float(q), float(m))
+        out = C.c_int()
+        self._ck(self.L.xpic_add_sort(self.h, C.byref(p), C.c_int64(int(capacity)), C.byref(out)))
+        self.nsorts += 1
+        return out.value
+
+    def add_particles(self, sort, pts):
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        added = C.c_int64()
+        self._ck(self.L.xpic_sort_add_particles(self.h, sort, C.c_int64(pts.shape[0]), _dp(pts), C.byref(added)))
+        return added.value
+
+    def count(self, sort):
+        n = C.c_int64()
+        self._ck(self.L.xpic_sort_count(self.h, sort, C.byref(n)))
+        return n.value
+
+    def particles(self, sort):
+        n = self.count(sort)
+        pts = np.zeros((n, 6))
+        cells = np.zeros(n, dtype=np.int32)
+        self._ck(self.L.xpic_sort_get_particles(self.h, sort, _dp(pts), cells.ctypes.data_as(C.POINTER(C.c_int32))))
+        return pts, cells
+
+    def clear(self, sort):
+        self._ck(self.L.xpic_sort_clear(self.h, sort))
+
+    def fill_synthetic(self, sort, ppc, vth, seed=1):
+        self._ck(self.L.xpic_sort_fill_synthetic(self.h, sort, int(ppc), C.c_double(vth), C.c_uint64(seed)))
+
+    # ---- fields
+    def fshape(self):
+        return (self.n[2], self.n[1], self.n[0], 3)
+
+    def set_field(self, f, v):
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(self.fshape())
+        self._ck(self.L.xpic_field_set(self.h, f, _dp(v)))
+
+    def get_field(self, f):
+        v = np.zeros(self.fshape())
+        self._ck(self.L.xpic_field_get(self.h, f, _dp(v)))
+        return v
+
+    def sort_current(self, sort, which):
+        v = np.zeros(self.fshape())
+        self._ck(self.L.xpic_sort_current_get(self.h, sort, which, _dp(v)))
+        return v
+
+    def vec_set(self, y, a):
+        self._ck(self.L.xpic_vec_set(self.h, y, C.c_double(a)))
+
+    def vec_axpy(self, y, a, x):
+        self._ck(self.L.xpic_vec_axpy(self.h, y, C.c_double(a), x))
+
+    def vec_axpby(self, y, a, b, x):
+        self._ck(self.L.xpic_vec_axpby(self.h, y, C.c_double(a), C.c_double(b), x))
+
+    def vec_dot(self, x, y):
+        o = C.c_double()
+        self._ck(self.L.xpic_vec_dot(self.h, x, y, C.byref(o)))
+        return o.value
+
+    def vec_norm2(self, x):
+        o = C.c_double()
+        self._ck(self.L.xpic_vec_norm2(self.h, x, C.byref(o)))
+        return o.value
+
+    # ---- operators
+    def rot_apply(self, sign, alpha, x, y, add=False):
+        self._ck(self.L.xpic_rot_apply(self.h, sign, C.c_double(alpha), x, y, int(add)))
+
+    def matM_apply(self, x, y, add=False):
+        self._ck(self.L.xpic_matM_apply(self.h, x, y, int(add)))
+
+    def matL_apply(self, x, y, add=False):
+        self._ck(self.L.xpic_matL_apply(self.h, x, y, int(add)))
+
+    def matA_apply(self, x, y):
+        self._ck(self.L.xpic_matA_apply(self.h, x, y))
+
+    def matL(self):
+        out = np.zeros((self.N * 3, LSTENCIL))
+        self._ck(self.L.xpic_matL_get(self.h, _dp(out)))
+        return out
+
+    # ---- phases
+    def ecsim_first_push(self, sort):
+        self._ck(self.L.xpic_ecsim_first_push(self.h, sort))
+
+    def update_cells(self, sort):
+        n = C.c_int64()
+        self._ck(self.L.xpic_update_cells(self.h, sort, C.byref(n)))
+        return n.value
+
+    def ecsim_fill_current(self):
+        self._ck(self.L.xpic_ecsim_fill_current(self.h))
+
+    def ecsim_second_push(self, sort):
+        self._ck(self.L.xpic_ecsim_second_push(self.h, sort))
+
+    def basic_push(self, sort):
+        self._ck(self.L.xpic_basic_push(self.h, sort))
+
+    def ecsimcorr_first_push(self, sort):
+        self._ck(self.L.xpic_ecsimcorr_first_push(self.h, sort))
+
+    def ecsimcorr_second_push(self, sort):
+        self._ck(self.L.xpic_ecsimcorr_second_push(self.h, sort))
+
+    def ecsimcorr_final_update(self, sort):
+        self._ck(self.L.xpic_ecsimcorr_final_update(self.h, sort))
+
+    def calculate_energy(self, sort):
+        o = C.c_double()
+        self._ck(self.L.xpic_calculate_energy(self.h, sort, C.byref(o)))
+        return o.value
+
+    def ecsimcorr_scalars(self, sort):
+        o = np.zeros(6)
+        self._ck(self.L.xpic_ecsimcorr_scalars(self.h, sort, _dp(o)))
+        return dict(pred_w=o[0], corr_w=o[1], lambda_dK=o[2], pred_dK=o[3], corr_dK=o[4], energy=o[5])
+
+    def solve(self, op, rhs, x, rtol=1e-7, atol=1e-7, maxit=100):
+        its, reason, rn = C.c_int(), C.c_int(), C.c_double()
+        self._ck(self.L.xpic_solve(self.h, op, rhs, x, C.c_double(rtol), C.c_double(atol), maxit, C.byref(its),
+                                   C.byref(reason), C.byref(rn)))
+        return its.value, reason.value, rn.value
+
+    def set_tolerances(self, rtol, atol, maxit):
+        self._ck(self.L.xpic_set_tolerances(self.h, C.c_double(rtol), C.c_double(atol), maxit))
+
+    def step(self):
+        its = C.c_int()
+        self._ck(self.L.xpic_step(self.h, C.byref(its)))
+        return its.value
+
+    def energy(self):
+        out = np.zeros(4 + 2 * self.nsorts)
+        self._ck(self.L.xpic_energy(self.h, _dp(out)))
+        return out
+
+    def synchronize(self):
+        self._ck(self.L.xpic_synchronize(self.h))
+
+    # ---- measurement
+    def profile_enable(self, on=True):
+        self._ck(self.L.xpic_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        self._ck(self.L.xpic_profile_reset(self.h))
+
+    def profile_get(self, name):
+        n, ms = C.c_int64(), C.c_double()
+        self._ck(self.L.xpic_profile_get(self.h, name.encode(), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def probe_copy_bandwidth(self, nbytes=1 << 30, reps=10):
+        o = C.c_double()
+        self._ck(self.L.xpic_probe_copy_bandwidth(self.h, C.c_int64(nbytes), reps, C.byref(o)))
+        return o.value
+
+
+def lstencil_decode(c1, k):
+    L = load_library()
+    c2 = C.c_int()
+    d = (C.c_int * 3)()
+    L.xpic_lstencil_decode(c1, k, C.byref(c2), d)
+    return c2.value, (d[0], d[1], d[2])

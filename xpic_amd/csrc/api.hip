@@ -1,0 +1,535 @@
+// api.hip -- the C ABI of include/xpic_hip.h: context life cycle, boundary copies, per-phase entry points
+// and the timestep drivers that mirror timestep_implementation() of the reference's schemes.
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+#include "lstencil.h"
+
+namespace xpic {
+
+static thread_local std::string g_error;
+void set_error(const std::string& msg) { g_error = msg; }
+
+hipEvent_t get_event(xpic_ctx* c)
+{
+  if (!c->event_pool.empty()) {
+    hipEvent_t e = c->event_pool.back();
+    c->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+Timed::Timed(xpic_ctx* ctx, const char* name) : c(ctx)
+{
+  if (!c->profiling) return;
+  e = &c->prof[name];
+  a = get_event(c);
+  b = get_event(c);
+  (void)hipEventRecord(a, c->stream);
+}
+
+Timed::~Timed()
+{
+  if (!e) return;
+  (void)hipEventRecord(b, c->stream);
+  e->pending.emplace_back(a, b);
+}
+
+static int resolve_profile(xpic_ctx* c)
+{
+  XPIC_HIP(hipStreamSynchronize(c->stream));
+  for (auto& kv : c->prof) {
+    for (auto& pr : kv.second.pending) {
+      float ms = 0;
+      XPIC_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+      kv.second.total_ms += ms;
+      kv.second.launches += 1;
+      c->event_pool.push_back(pr.first);
+      c->event_pool.push_back(pr.second);
+    }
+    kv.second.pending.clear();
+  }
+  return 0;
+}
+
+static bool valid_field(int f) { return f >= 0 && f < XPIC_NFIELDS; }
+
+#define CTX_CHECK(c) XPIC_CHECK((c) != nullptr, "null context")
+#define FIELD_CHECK(f) XPIC_CHECK(valid_field(f) && ctx->field[f], "unknown or unallocated field id")
+#define SORT_CHECK(s) XPIC_CHECK((s) >= 0 && (s) < (int)ctx->sorts.size(), "unknown sort id")
+
+// ---- scheme drivers --------------------------------------------------------------------------------
+
+// ecsim::Simulation::advance_fields(ksp, curr, out)  (src/impls/ecsim/simulation.cpp:255-279)
+static int advance_fields(xpic_ctx* c, int op, const double* curr, double* out, int* its)
+{
+  double* rhs = c->field[XPIC_W0];
+  double* Bm = c->field[XPIC_W1];
+  XPIC_CALL(vec_waxpby(c, Bm, 1.0, c->field[XPIC_B], -1.0, c->field[XPIC_B0]));   // B - B0        :260
+  XPIC_CALL(vec_waxpby(c, rhs, 2.0, c->field[XPIC_E], -c->g.dt, curr));          // 2E - dt curr  :262-263
+  XPIC_CALL(halo_fill(c, Bm));
+  XPIC_CALL(rot_apply(c, -1, +c->g.dt, Bm, rhs, true));                           // + dt rotB(B)  :264, :554
+  int reason;
+  double rn;
+  XPIC_CALL(solve(c, op, rhs, out, c->rtol, c->atol, c->maxit, its, &reason, &rn));
+  return 0;
+}
+
+// ecsim::Simulation::fill_ecsim_current (src/impls/ecsim/simulation.cpp:336-368, 471-484) incl. the
+// clear_sources of :157-172
+static int ecsim_fill_current(xpic_ctx* c)
+{
+  const GridDev& g = c->g;
+  {
+    Timed t(c, "matL_zero");
+    XPIC_HIP(hipMemsetAsync(c->matL, 0, sizeof(double) * 3 * g.nown * kLStencil, c->stream)); // MatZeroEntries :164
+  }
+  XPIC_CALL(vec_set(c, c->field[XPIC_CURRI], 0.0));
+  XPIC_CALL(halo_fill(c, c->field[XPIC_B])); // DMGlobalToLocal(B) :474
+  for (auto& s : c->sorts) {
+    XPIC_HIP(hipMemsetAsync(s.currI, 0, sizeof(double) * c->nvec, c->stream));
+    XPIC_CALL(ecsim_fill_sort(c, s, c->field[XPIC_B], s.currI, c->matL));
+    XPIC_CALL(vec_axpy(c, c->field[XPIC_CURRI], 1.0, s.currI)); // particles.cpp:57
+  }
+  return 0;
+}
+
+// ecsim::Simulation::final_update (src/impls/ecsim/simulation.cpp:241-253)
+static int ecsim_final_update(xpic_ctx* c)
+{
+  XPIC_CALL(vec_axpby(c, c->field[XPIC_E], 2.0, -1.0, c->field[XPIC_EP]));          // E = 2 Ep - E
+  XPIC_CALL(halo_fill(c, c->field[XPIC_EP]));
+  XPIC_CALL(rot_apply(c, +1, -c->g.dt, c->field[XPIC_EP], c->field[XPIC_B], true)); // B -= dt rot(+) Ep
+  return 0;
+}
+
+// ecsim::Simulation::timestep_implementation (src/impls/ecsim/simulation.cpp:145-253)
+static int step_ecsim(xpic_ctx* c, int* its)
+{
+  for (auto& s : c->sorts) XPIC_CALL(sort_rebin(c, s, c->g.dt, true)); // first_push + update_cells :174-189
+  XPIC_CALL(ecsim_fill_current(c));
+  XPIC_CALL(advance_fields(c, XPIC_OP_MATA_GMRES, c->field[XPIC_CURRI], c->field[XPIC_EP], its)); // :191-210
+  XPIC_CALL(halo_fill(c, c->field[XPIC_EP]));
+  XPIC_CALL(halo_fill(c, c->field[XPIC_B]));
+  // second_push :212-239.  Positions did not change since the re-bin of first_push and are already wrapped,
+  // so correct_coordinates() + update_cells() of :227,:233 are the identity here.
+  for (auto& s : c->sorts) XPIC_CALL(ecsim_second_push(c, s, c->field[XPIC_EP], c->field[XPIC_B]));
+  XPIC_CALL(ecsim_final_update(c));
+  return 0;
+}
+
+}  // namespace xpic
+
+using namespace xpic;
+
+extern "C" {
+
+const char* xpic_last_error(void) { return g_error.c_str(); }
+int xpic_version(void) { return 1; }
+
+int xpic_create(const xpic_geometry* geom, int scheme, xpic_ctx** out)
+{
+  XPIC_CHECK(geom && out, "null argument");
+  XPIC_CHECK(geom->periodic[0] && geom->periodic[1] && geom->periodic[2], "only DM_BOUNDARY_PERIODIC is supported");
+  XPIC_CHECK(geom->n[0] >= 4 && geom->n[1] >= 4 && geom->n[2] >= 4, "every grid extent must be >= 4 cells");
+  XPIC_CHECK(geom->nranks == 1 && geom->rank == 0, "nranks > 1 (z-slab decomposition) is not built yet");
+  XPIC_CHECK(scheme == XPIC_BASIC || scheme == XPIC_ECSIM || scheme == XPIC_ECSIMCORR, "unknown scheme");
+  int ndev = 0;
+  XPIC_HIP(hipGetDeviceCount(&ndev));
+  XPIC_CHECK(ndev > 0, "no HIP device: the xpic HIP path has no CPU fallback");
+  XPIC_HIP(hipSetDevice(geom->device));
+  xpic_ctx* c = new xpic_ctx;
+  c->geom = *geom;
+  c->scheme = scheme;
+  GridDev& g = c->g;
+  g.nx = geom->n[0]; g.ny = geom->n[1]; g.nzg = geom->n[2];
+  g.nzl = g.nzg; g.z0 = 0; g.G = 0;
+  g.nzs = g.nzl + 2 * g.G;
+  g.dx = geom->d[0]; g.dy = geom->d[1]; g.dz = geom->d[2]; g.dt = geom->dt;
+  g.Lx = g.nx * g.dx; g.Ly = g.ny * g.dy; g.Lz = g.nzg * g.dz;
+  g.plane = (long)g.nx * g.ny;
+  g.cstride = g.plane * g.nzs;
+  g.nown = g.plane * g.nzl;
+  c->nvec = 3 * g.cstride;
+  c->ncell = g.nown;
+  XPIC_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (int f = 0; f < XPIC_NFIELDS; ++f) {
+    const bool need = scheme != XPIC_BASIC || (f != XPIC_EP && f != XPIC_EC && f != XPIC_CURRI && f != XPIC_CURRJE);
+    if (!need) continue;
+    XPIC_HIP(hipMalloc(&c->field[f], sizeof(double) * c->nvec));
+    XPIC_HIP(hipMemsetAsync(c->field[f], 0, sizeof(double) * c->nvec, c->stream));
+  }
+  XPIC_HIP(hipMalloc(&c->red_partial, sizeof(double) * kMaxDots * kRedBlocks));
+  XPIC_HIP(hipMalloc(&c->red_out, sizeof(double) * 64));
+  XPIC_HIP(hipHostMalloc(&c->red_host, sizeof(double) * 64));
+  if (scheme != XPIC_BASIC) {
+    XPIC_HIP(hipMalloc(&c->matL, sizeof(double) * 3 * g.nown * kLStencil));
+    XPIC_HIP(hipMemsetAsync(c->matL, 0, sizeof(double) * 3 * g.nown * kLStencil, c->stream));
+    XPIC_HIP(hipMalloc(&c->kry_V, sizeof(double) * c->nvec * 31));
+    XPIC_HIP(hipMalloc(&c->kry_w, sizeof(double) * c->nvec));
+    XPIC_HIP(hipMemsetAsync(c->kry_V, 0, sizeof(double) * c->nvec * 31, c->stream));
+    XPIC_HIP(hipMemsetAsync(c->kry_w, 0, sizeof(double) * c->nvec, c->stream));
+    XPIC_CALL(build_ltab(c));
+  }
+  XPIC_HIP(hipStreamSynchronize(c->stream));
+  *out = c;
+  return 0;
+}
+
+int xpic_destroy(xpic_ctx* ctx)
+{
+  if (!ctx) return 0;
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& s : ctx->sorts) sort_free(s);
+  for (int f = 0; f < XPIC_NFIELDS; ++f) (void)hipFree(ctx->field[f]);
+  (void)hipFree(ctx->matL); (void)hipFree(ctx->ltab); (void)hipFree(ctx->kry_V); (void)hipFree(ctx->kry_w);
+  (void)hipFree(ctx->red_partial); (void)hipFree(ctx->red_out); (void)hipHostFree(ctx->red_host);
+  (void)hipFree(ctx->scan_tmp);
+  for (auto& kv : ctx->prof)
+    for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return 0;
+}
+
+int xpic_synchronize(xpic_ctx* ctx)
+{
+  CTX_CHECK(ctx);
+  XPIC_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int xpic_add_sort(xpic_ctx* ctx, const xpic_sort_params* p, int64_t capacity, int* sort_out)
+{
+  CTX_CHECK(ctx);
+  XPIC_CHECK(p && p->Np > 0 && p->m != 0.0, "bad sort parameters");
+  Sort s;
+  s.par = *p;
+  XPIC_CALL(sort_alloc(ctx, s, capacity));
+  double** cur = ctx->scheme == XPIC_BASIC ? &s.J : &s.currI;
+  XPIC_HIP(hipMalloc(cur, sizeof(double) * ctx->nvec));
+  XPIC_HIP(hipMemsetAsync(*cur, 0, sizeof(double) * ctx->nvec, ctx->stream));
+  if (ctx->scheme == XPIC_ECSIMCORR) {
+    XPIC_HIP(hipMalloc(&s.currJe, sizeof(double) * ctx->nvec));
+    XPIC_HIP(hipMemsetAsync(s.currJe, 0, sizeof(double) * ctx->nvec, ctx->stream));
+  }
+  ctx->sorts.push_back(s);
+  if (sort_out) *sort_out = (int)ctx->sorts.size() - 1;
+  return 0;
+}
+
+int xpic_sort_add_particles(xpic_ctx* ctx, int sort, int64_t n, const double* pts6, int64_t* added)
+{
+  CTX_CHECK(ctx); SORT_CHECK(sort);
+  return sort_append_host(ctx, ctx->sorts[sort], n, pts6, added);
+}
+
+int xpic_sort_count(xpic_ctx* ctx, int sort, int64_t* count)
+{
+  CTX_CHECK(ctx); SORT_CHECK(sort);
+  *count = ctx->sorts[sort].n;
+  return 0;
+}
+
+int xpic_sort_get_particles(xpic_ctx* ctx, int sort, double* pts6, int32_t* cell_of)
+{
+  CTX_CHECK(ctx); SORT_CHECK(sort);
+  return sort_download(ctx, ctx->sorts[sort], pts6, cell_of);
+}
+
+int xpic_sort_clear(xpic_ctx* ctx, int sort)
+{
+  CTX_CHECK(ctx); SORT_CHECK(sort);
+  Sort& s = ctx->sorts[sort];
+  s.n = 0;
+  XPIC_HIP(hipMemsetAsync(s.d.cell_count, 0, sizeof(int) * (ctx->ncell + 1), ctx->stream));
+  XPIC_HIP(hipMemsetAsync(s.d.cell_start, 0, sizeof(int) * (ctx->ncell + 1), ctx->stream));
+  return 0;
+}
+
+int xpic_sort_fill_synthetic(xpic_ctx* ctx, int sort, int ppc, double vth, uint64_t seed)
+{
+  CTX_CHECK(ctx); SORT_CHECK(sort);
+  return sort_fill_synthetic(ctx, ctx->sorts[sort], ppc, vth, seed);
+}
+
+int xpic_field_set(xpic_ctx* ctx, int field, const double* v)
+{
+  CTX_CHECK(ctx); FIELD_CHECK(field);
+  return field_import(ctx, ctx->field[field], v);
+}
+
+int xpic_field_get(xpic_ctx* ctx, int field, double* v)
+{
+  CTX_CHECK(ctx); FIELD_CHECK(field);
+  return field_export(ctx, ctx->field[field], v);
+}
+
+int xpic_sort_current_get(xpic_ctx* ctx, int sort, int which, double* v)
+{
+  CTX_CHECK(ctx); SORT_CHECK(sort);
+  Sort& s = ctx->sorts[sort];
+  const double* src = which == XPIC_J ? s.J : (which == XPIC_CURRI ? s.currI : (which == XPIC_CURRJE ? s.currJe : nullptr));
+  XPIC_CHECK(src, "this sort does not hold the requested current");
+  return field_export(ctx, src, v);
+}
+
+int xpic_vec_set(xpic_ctx* ctx, int y, double a) { CTX_CHECK(ctx); FIELD_CHECK(y); return vec_set(ctx, ctx->field[y], a); }
+int xpic_vec_axpy(xpic_ctx* ctx, int y, double a, int x)
+{
+  CTX_CHECK(ctx); FIELD_CHECK(y); FIELD_CHECK(x);
+  return vec_axpy(ctx, ctx->field[y], a, ctx->field[x]);
+}
+int xpic_vec_axpby(xpic_ctx* ctx, int y, double a, double b, int x)
+{
+  CTX_CHECK(ctx); FIELD_CHECK(y); FIELD_CHECK(x);
+  return vec_axpby(ctx, ctx->field[y], a, b, ctx->field[x]);
+}
+int xpic_vec_dot(xpic_ctx* ctx, int x, int y, double* out)
+{
+  CTX_CHECK(ctx); FIELD_CHECK(y); FIELD_CHECK(x);
+  return vec_dot_host(ctx, ctx->field[x], ctx->field[y], out);
+}
+int xpic_vec_norm2(xpic_ctx* ctx, int x, double* out)
+{
+  CTX_CHECK(ctx); FIELD_CHECK(x);
+  double d;
+  XPIC_CALL(vec_dot_host(ctx, ctx->field[x], ctx->field[x], &d));
+  *out = std::sqrt(d);
+  return 0;
+}
+
+int xpic_rot_apply(xpic_ctx* ctx, int sign, double alpha, int x, int y, int add)
+{
+  CTX_CHECK(ctx); FIELD_CHECK(y); FIELD_CHECK(x);
+  XPIC_CHECK(x != y, "rot_apply cannot work in place");
+  XPIC_CALL(halo_fill(ctx, ctx->field[x]));
+  return rot_apply(ctx, sign, alpha, ctx->field[x], ctx->field[y], add != 0);
+}
+
+int xpic_matM_apply(xpic_ctx* ctx, int x, int y, int add)
+{
+  CTX_CHECK(ctx); FIELD_CHECK(y); FIELD_CHECK(x);
+  XPIC_CHECK(x != y, "matM_apply cannot work in place");
+  XPIC_CALL(halo_fill(ctx, ctx->field[x]));
+  return matM_apply(ctx, ctx->field[x], ctx->field[y], add != 0);
+}
+
+int xpic_matL_apply(xpic_ctx* ctx, int x, int y, int add)
+{
+  CTX_CHECK(ctx); FIELD_CHECK(y); FIELD_CHECK(x);
+  XPIC_CHECK(ctx->matL, "scheme has no matL");
+  XPIC_CHECK(x != y, "matL_apply cannot work in place");
+  XPIC_CALL(halo_fill(ctx, ctx->field[x]));
+  return matL_apply(ctx, ctx->field[x], ctx->field[y], add != 0);
+}
+
+int xpic_matA_apply(xpic_ctx* ctx, int x, int y)
+{
+  CTX_CHECK(ctx); FIELD_CHECK(y); FIELD_CHECK(x);
+  XPIC_CHECK(ctx->matL, "scheme has no matL");
+  XPIC_CHECK(x != y, "matA_apply cannot work in place");
+  XPIC_CALL(halo_fill(ctx, ctx->field[x]));
+  return matA_apply(ctx, ctx->field[x], ctx->field[y]);
+}
+
+int xpic_matL_get(xpic_ctx* ctx, double* out)
+{
+  CTX_CHECK(ctx);
+  XPIC_CHECK(ctx->matL, "scheme has no matL");
+  const GridDev& g = ctx->g;
+  const size_t n = (size_t)3 * g.nown * kLStencil;
+  std::vector<double> tmp(n);
+  XPIC_HIP(hipMemcpyAsync(tmp.data(), ctx->matL, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  XPIC_HIP(hipStreamSynchronize(ctx->stream));
+  // device [c1][z][y][k][x] -> boundary [node][c1][k]
+  for (int c1 = 0; c1 < 3; ++c1)
+    for (int z = 0; z < g.nzl; ++z)
+      for (int y = 0; y < g.ny; ++y)
+        for (int k = 0; k < kLStencil; ++k)
+          for (int x = 0; x < g.nx; ++x) {
+            size_t src = ((((size_t)c1 * g.nzl + z) * g.ny + y) * kLStencil + k) * g.nx + x;
+            size_t row = (((size_t)z * g.ny + y) * g.nx + x) * 3 + c1;
+            out[row * kLStencil + k] = tmp[src];
+          }
+  return 0;
+}
+
+void xpic_lstencil_decode(int c1, int k, int* c2, int* d3)
+{
+  LEntry e = ldecode(c1, k);
+  *c2 = e.c2;
+  d3[0] = e.d[0]; d3[1] = e.d[1]; d3[2] = e.d[2];
+}
+
+int xpic_ecsim_first_push(xpic_ctx* ctx, int sort)
+{
+  // the reference's phase boundary, for callers that want it; xpic_step fuses this move into the re-bin
+  CTX_CHECK(ctx); SORT_CHECK(sort);
+  return sort_move(ctx, ctx->sorts[sort], ctx->g.dt);
+}
+
+int xpic_update_cells(xpic_ctx* ctx, int sort, int64_t* count)
+{
+  CTX_CHECK(ctx); SORT_CHECK(sort);
+  XPIC_CALL(sort_rebin(ctx, ctx->sorts[sort], 0.0, true));
+  if (count) *count = ctx->sorts[sort].n;
+  return 0;
+}
+
+int xpic_ecsim_fill_current(xpic_ctx* ctx)
+{
+  CTX_CHECK(ctx);
+  XPIC_CHECK(ctx->scheme != XPIC_BASIC, "basic scheme has no ECSIM current");
+  return ecsim_fill_current(ctx);
+}
+
+int xpic_ecsim_second_push(xpic_ctx* ctx, int sort)
+{
+  CTX_CHECK(ctx); SORT_CHECK(sort);
+  XPIC_CHECK(ctx->scheme != XPIC_BASIC, "basic scheme has no second_push");
+  XPIC_CALL(halo_fill(ctx, ctx->field[XPIC_EP]));
+  XPIC_CALL(halo_fill(ctx, ctx->field[XPIC_B]));
+  return ecsim_second_push(ctx, ctx->sorts[sort], ctx->field[XPIC_EP], ctx->field[XPIC_B]);
+}
+
+int xpic_basic_push(xpic_ctx*, int) { set_error("basic::push is not built yet"); return 5; }
+int xpic_ecsimcorr_first_push(xpic_ctx*, int) { set_error("ecsimcorr is not built yet"); return 5; }
+int xpic_ecsimcorr_second_push(xpic_ctx*, int) { set_error("ecsimcorr is not built yet"); return 5; }
+int xpic_ecsimcorr_final_update(xpic_ctx*, int) { set_error("ecsimcorr is not built yet"); return 5; }
+int xpic_ecsimcorr_scalars(xpic_ctx*, int, double*) { set_error("ecsimcorr is not built yet"); return 5; }
+
+int xpic_calculate_energy(xpic_ctx* ctx, int sort, double* energy)
+{
+  CTX_CHECK(ctx); SORT_CHECK(sort);
+  Sort& s = ctx->sorts[sort];
+  double o[5];
+  XPIC_CALL(kinetic_sums_host(ctx, s, o));
+  s.energy = 0.5 * s.par.m * (s.par.n / s.par.Np) * o[3];
+  if (energy) *energy = s.energy;
+  return 0;
+}
+
+int xpic_solve(xpic_ctx* ctx, int op, int rhs, int x, double rtol, double atol, int maxit, int* iterations,
+  int* reason, double* rnorm)
+{
+  CTX_CHECK(ctx); FIELD_CHECK(rhs); FIELD_CHECK(x);
+  XPIC_CHECK(ctx->kry_V, "scheme has no Krylov workspace");
+  XPIC_CHECK(rhs != x, "rhs and x must differ");
+  XPIC_CHECK(op >= 0 && op <= 2, "unknown solve op");
+  int its = 0, rs = 0;
+  double rn = 0;
+  int rc = solve(ctx, op, ctx->field[rhs], ctx->field[x], rtol, atol, maxit, &its, &rs, &rn);
+  if (iterations) *iterations = its;
+  if (reason) *reason = rs;
+  if (rnorm) *rnorm = rn;
+  return rc;
+}
+
+int xpic_set_tolerances(xpic_ctx* ctx, double rtol, double atol, int maxit)
+{
+  CTX_CHECK(ctx);
+  ctx->rtol = rtol; ctx->atol = atol; ctx->maxit = maxit;
+  return 0;
+}
+
+int xpic_step(xpic_ctx* ctx, int* ksp_iterations)
+{
+  CTX_CHECK(ctx);
+  int its = 0;
+  int rc;
+  switch (ctx->scheme) {
+    case XPIC_ECSIM: rc = step_ecsim(ctx, &its); break;
+    default: set_error("this scheme's timestep is not built yet"); return 5;
+  }
+  if (ksp_iterations) *ksp_iterations = its;
+  return rc;
+}
+
+int xpic_energy(xpic_ctx* ctx, double* out)
+{
+  CTX_CHECK(ctx);
+  const GridDev& g = ctx->g;
+  const double g3 = (double)g.nx * g.ny * g.nzg;
+  for (int f = 0; f < 2; ++f) {
+    double sq, mean[3];
+    XPIC_CALL(field_stats_host(ctx, ctx->field[f == 0 ? XPIC_E : XPIC_B], &sq, mean));
+    const double nrm = std::sqrt(sq);
+    const double w = 0.5 * (nrm * nrm);
+    out[f] = w;
+    out[2 + f] = std::sqrt((w - 0.5 * (mean[0] * mean[0] + mean[1] * mean[1] + mean[2] * mean[2]) / g3) / g3);
+  }
+  for (size_t i = 0; i < ctx->sorts.size(); ++i) {
+    Sort& s = ctx->sorts[i];
+    double o[5];
+    XPIC_CALL(kinetic_sums_host(ctx, s, o));
+    const double frac = 0.5 * s.par.m * (s.par.n / (double)s.par.Np);
+    double K = frac * o[3], sK = 0;
+    if (s.n == 0) K = 0;
+    else {
+      const double sv = o[3] - (o[0] * o[0] + o[1] * o[1] + o[2] * o[2]) / (double)s.n;
+      sK = frac * std::sqrt(std::fabs(sv) / (double)s.n);
+    }
+    out[4 + 2 * i] = K;
+    out[5 + 2 * i] = sK;
+  }
+  return 0;
+}
+
+int xpic_profile_enable(xpic_ctx* ctx, int on) { CTX_CHECK(ctx); ctx->profiling = on != 0; return 0; }
+
+int xpic_profile_reset(xpic_ctx* ctx)
+{
+  CTX_CHECK(ctx);
+  XPIC_CALL(resolve_profile(ctx));
+  for (auto& kv : ctx->prof) { kv.second.launches = 0; kv.second.total_ms = 0; }
+  return 0;
+}
+
+int xpic_profile_get(xpic_ctx* ctx, const char* name, int64_t* launches, double* total_ms)
+{
+  CTX_CHECK(ctx);
+  XPIC_CALL(resolve_profile(ctx));
+  auto it = ctx->prof.find(name);
+  if (it == ctx->prof.end()) { *launches = 0; *total_ms = 0; return 0; }
+  *launches = it->second.launches;
+  *total_ms = it->second.total_ms;
+  return 0;
+}
+
+__global__ void __launch_bounds__(256) k_copy16(const double2* __restrict__ in, double2* __restrict__ out, long n)
+{
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = in[i];
+}
+
+int xpic_probe_copy_bandwidth(xpic_ctx* ctx, int64_t bytes, int reps, double* bytes_per_s)
+{
+  CTX_CHECK(ctx);
+  double2 *a = nullptr, *b = nullptr;
+  const long n = bytes / 16;
+  XPIC_HIP(hipMalloc(&a, n * 16));
+  XPIC_HIP(hipMalloc(&b, n * 16));
+  XPIC_HIP(hipMemsetAsync(a, 1, n * 16, ctx->stream));
+  hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
+  hipLaunchKernelGGL(k_copy16, dim3(2048), dim3(256), 0, ctx->stream, a, b, n);
+  XPIC_HIP(hipEventRecord(e0, ctx->stream));
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_copy16, dim3(2048), dim3(256), 0, ctx->stream, a, b, n);
+  XPIC_HIP(hipEventRecord(e1, ctx->stream));
+  XPIC_HIP(hipStreamSynchronize(ctx->stream));
+  float ms = 0;
+  XPIC_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *bytes_per_s = 2.0 * n * 16 * reps / (ms * 1e-3);
+  ctx->event_pool.push_back(e0);
+  ctx->event_pool.push_back(e1);
+  XPIC_HIP(hipFree(a));
+  XPIC_HIP(hipFree(b));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,186 @@
+// common.h -- shared declarations of the gfx950 implementation (see include/xpic_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/xpic_hip.h"
+
+namespace xpic {
+
+void set_error(const std::string& msg);
+
+#define XPIC_HIP(call)                                                                         \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      ::xpic::set_error(std::string(#call) + ": " + hipGetErrorString(e_) + " at " __FILE__ + \
+        ":" + std::to_string(__LINE__));                                                       \
+      return 1;                                                                                \
+    }                                                                                          \
+  } while (0)
+
+#define XPIC_CHECK(cond, msg)                  \
+  do {                                         \
+    if (!(cond)) {                             \
+      ::xpic::set_error(std::string(msg));     \
+      return 2;                                \
+    }                                          \
+  } while (0)
+
+#define XPIC_CALL(call)        \
+  do {                         \
+    int rc_ = (call);          \
+    if (rc_ != 0) return rc_;  \
+  } while (0)
+
+constexpr int kLStencil = XPIC_LSTENCIL;
+
+// ---------------------------------------------------------------------------------------------
+// Grid of one z-slab.  Field vectors live in HBM as structure-of-arrays
+//     F[c][zs][y][x],  zs in [0, nzs),  nzs = nzl + 2*G
+// x and y are periodic and wrapped in the kernels; z is wrapped in the kernels when the slab is the
+// whole box (G == 0, nranks == 1) and otherwise served by G ghost planes filled by the halo exchange.
+// ---------------------------------------------------------------------------------------------
+struct GridDev {
+  int nx, ny, nzl; // local owned planes
+  int nzg;         // global nz
+  int z0;          // global index of the first owned plane
+  int G;           // ghost planes on each side
+  int nzs;         // stored planes
+  double dx, dy, dz, dt;
+  double Lx, Ly, Lz; // global box (World::set_geometry: geom = n * d, world.cpp:80-91)
+  long plane;        // nx*ny
+  long cstride;      // nzs*plane
+  long nown;         // nzl*plane  (owned nodes per component)
+
+  __host__ __device__ inline int wx(int x) const { return x < 0 ? x + nx : (x >= nx ? x - nx : x); }
+  __host__ __device__ inline int wy(int y) const { return y < 0 ? y + ny : (y >= ny ? y - ny : y); }
+  // local z (relative to the first owned plane, may be in [-G, nzl+G)) -> stored plane
+  __host__ __device__ inline int wz(int z) const
+  {
+    if (G == 0) return z < 0 ? z + nzl : (z >= nzl ? z - nzl : z);
+    return z + G;
+  }
+  __host__ __device__ inline long node(int x, int y, int zs) const { return ((long)zs * ny + y) * nx + x; }
+  // wrapped access: x,y,z are local signed indices
+  __host__ __device__ inline long nodew(int x, int y, int z) const { return node(wx(x), wy(y), wz(z)); }
+};
+
+struct SortDev {
+  double* r[3];   // positions  (SoA)
+  double* v[3];   // velocities (SoA; `Point::p` holds velocity in these schemes)
+  double* r2[3];  // second buffer of the out-of-place sort
+  double* v2[3];
+  int* cell;      // new local cell of each particle (or -1: dropped)
+  int* rank;      // arrival rank of the particle inside its new cell
+  int* cell_count;
+  int* cell_start; // [ncell+1] exclusive prefix of cell_count
+};
+
+struct Sort {
+  xpic_sort_params par;
+  int64_t cap = 0;
+  int64_t n = 0;
+  SortDev d{};
+  double* J = nullptr;      // basic: J
+  double* currI = nullptr;  // ecsim: currI
+  double* currJe = nullptr; // ecsimcorr: currJe
+  double energy = 0, pred_w = 0, corr_w = 0, pred_dK = 0, corr_dK = 0, lambda_dK = 0;
+};
+
+struct ProfileEntry {
+  int64_t launches = 0;
+  double total_ms = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace xpic
+
+struct xpic_ctx {
+  xpic_geometry geom;
+  int scheme;
+  xpic::GridDev g;
+  hipStream_t stream = nullptr;
+  long nvec = 0;    // doubles per stored field vector (3*cstride)
+  long ncell = 0;   // local cells
+  double* field[XPIC_NFIELDS] = {};
+  double* matL = nullptr; // [c1][nzl][ny][123][nx]
+  int* ltab = nullptr;    // [1296] block entry -> packed (k, c1, o1) descriptor
+  std::vector<xpic::Sort> sorts;
+  // Krylov workspace
+  double* kry_V = nullptr; // (m+1) vectors
+  double* kry_w = nullptr;
+  double* red_partial = nullptr; // reduction partials
+  double* red_out = nullptr;     // device results (pinned mirror below)
+  double* red_host = nullptr;
+  int* scan_tmp = nullptr;
+  long scan_tmp_n = 0;
+  double rtol = 1e-7, atol = 1e-7;
+  int maxit = 100;
+  bool profiling = false;
+  std::map<std::string, xpic::ProfileEntry> prof;
+  std::vector<hipEvent_t> event_pool;
+};
+
+namespace xpic {
+
+// RAII-less timer: records an event pair around a launch when profiling is on.
+struct Timed {
+  xpic_ctx* c;
+  ProfileEntry* e = nullptr;
+  hipEvent_t a{}, b{};
+  Timed(xpic_ctx* ctx, const char* name);
+  ~Timed();
+};
+
+hipEvent_t get_event(xpic_ctx* c);
+
+constexpr int kRedBlocks = 1024; // partial-sum blocks of the two-stage reductions
+constexpr int kMaxDots = 32;
+
+// fields.hip
+int vec_set(xpic_ctx* c, double* y, double a);
+int vec_copy(xpic_ctx* c, double* y, const double* x);
+int vec_axpy(xpic_ctx* c, double* y, double a, const double* x);
+int vec_axpby(xpic_ctx* c, double* y, double a, double b, const double* x);          // y = a x + b y
+int vec_waxpby(xpic_ctx* c, double* w, double a, const double* x, double b, const double* y); // w = a x + b y
+int vec_scale_to(xpic_ctx* c, double* y, double a, const double* x);                 // y = a x
+int vec_dot_host(xpic_ctx* c, const double* x, const double* y, double* out);
+int vec_mdot_host(xpic_ctx* c, const double* w, const double* V, int nv, double* out); // out[i] = w . V_i
+int vec_maxpy_norm_host(xpic_ctx* c, double* w, const double* V, int nv, const double* h, double* nrm2); // w -= sum h_i V_i
+int vec_maxpy(xpic_ctx* c, double* x, const double* V, int nv, const double* y);     // x += sum y_i V_i
+int rot_apply(xpic_ctx* c, int sign, double alpha, const double* x, double* y, bool add);
+int matM_apply(xpic_ctx* c, const double* x, double* y, bool add);
+int matL_apply(xpic_ctx* c, const double* x, double* y, bool add);
+int matA_apply(xpic_ctx* c, const double* x, double* y);
+int field_import(xpic_ctx* c, double* dst_soa, const double* src_aos_host);
+int field_export(xpic_ctx* c, const double* src_soa, double* dst_aos_host);
+int field_stats_host(xpic_ctx* c, const double* f, double* sumsq, double* mean3);
+int halo_fill(xpic_ctx* c, double* f); // ghost planes <- periodic images (no-op when G == 0)
+
+// particles.hip
+int sort_alloc(xpic_ctx* c, Sort& s, int64_t cap);
+void sort_free(Sort& s);
+int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap);
+int sort_move(xpic_ctx* c, Sort& s, double step); // r += step*v in place, cells left stale // (optional move by step*v), wrap, bin, scatter
+int sort_append_host(xpic_ctx* c, Sort& s, int64_t n, const double* pts6, int64_t* added);
+int sort_download(xpic_ctx* c, Sort& s, double* pts6, int32_t* cell_of);
+int sort_fill_synthetic(xpic_ctx* c, Sort& s, int ppc, double vth, uint64_t seed);
+int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B);
+int kinetic_sums_host(xpic_ctx* c, Sort& s, double* out5); // sum vx, vy, vz, v^2, count
+int scale_velocities(xpic_ctx* c, Sort& s, double lambda);
+
+// ecsim.hip
+int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, double* matL);
+int build_ltab(xpic_ctx* c);
+
+// krylov.hip
+int solve(xpic_ctx* c, int op, const double* rhs, double* x, double rtol, double atol, int maxit, int* its,
+  int* reason, double* rnorm);
+
+}  // namespace xpic

@@ -1,0 +1,199 @@
+// ecsim.hip -- ecsim::Particles::fill_ecsim_current / decompose_ecsim_current
+// (src/impls/ecsim/particles.cpp:33-173) for cell-sorted SoA particles.
+//
+// One wavefront owns one cell.  All particles of a cell touch the same 3 x 12 Yee nodes, so the cell's
+// contribution to matL is a dense 36 x 36 block  M = sum_p A_p * (s_p s_p^T) o matB_p  (the reference's
+// 1296-entry COO block, :145-163) and its contribution to currI is the 36-vector sum_p s_p o I_p.
+//   phase 1 (lane = particle): CIC weights, B gather, b, I_p, A_p*matB -> LDS, entry-major, padded.
+//   phase 2 (lane = 4 x 6 tile of the block): rank-1 updates out of LDS into 24 register accumulators.
+//   flush: fp64 hardware atomics into the index-free matL rows and the sort's currI.
+#include "common.h"
+#include "device_common.h"
+#include "lstencil.h"
+
+namespace xpic {
+
+namespace {
+
+constexpr int kChunk = 64;       // particles staged per pass = one per lane
+constexpr int kPad = kChunk + 1; // LDS row pitch (conflict-free for lane = particle and lane = entry)
+constexpr int kRows = 48;        // 36 weights + 9 A_p*matB + 3 I_p
+constexpr int kTileR = 4, kTileC = 6;
+constexpr int kTiles = (36 / kTileR) * (36 / kTileC); // 54 lanes carry a tile
+
+__global__ void __launch_bounds__(64) k_ecsim_fill(GridDev g, SortDev s, const double* __restrict__ B,
+  double* __restrict__ currI, double* __restrict__ matL, const int* __restrict__ ltab, double q, double m,
+  double mpw, long ncell, long chunk)
+{
+  // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of cells so that
+  // the B planes and matL rows it touches stay in its own L2.
+  const long b = blockIdx.x;
+  const long cell = (b % 8) * chunk + b / 8;
+  if (cell >= ncell || b / 8 >= chunk) return;
+  const int start = s.cell_start[cell];
+  const int cnt = s.cell_start[cell + 1] - start;
+  if (cnt == 0) return;
+  const int cx = (int)(cell % g.nx), cy = (int)((cell / g.nx) % g.ny), cz = (int)(cell / g.plane);
+
+  __shared__ double sh[kRows * kPad];
+  const int lane = threadIdx.x;
+  const int rt = lane / 6, ct = lane % 6; // tile (rows 4rt.., cols 6ct..) for lane < 54
+  const int c1 = rt / 3, c2 = ct / 2;
+  const bool has_tile = lane < kTiles;
+
+  double acc[kTileR][kTileC];
+#pragma unroll
+  for (int a = 0; a < kTileR; ++a)
+#pragma unroll
+    for (int bb = 0; bb < kTileC; ++bb) acc[a][bb] = 0.0;
+  double accI = 0.0;
+
+  const double dt = g.dt;
+
+  for (int base = 0; base < cnt; base += kChunk) {
+    const int mcnt = min(kChunk, cnt - base);
+    __syncthreads();
+    if (lane < mcnt) {
+      const long p = (long)start + base + lane;
+      const double x = s.r[0][p], y = s.r[1][p], z = s.r[2][p];
+      const double v[3] = {s.v[0][p], s.v[1][p], s.v[2][p]};
+      const W1 w(g, x, y, z);
+      double Ed[3], Bp[3];
+      gather_s1(g, nullptr, B, w, Ed, Bp);
+      // particles.cpp:107-115
+      const double f = (0.5 * dt) * q / m;
+      const double bx = Bp[0] * f, by = Bp[1] * f, bz = Bp[2] * f;
+      const double b2 = bx * bx + by * by + bz * bz;
+      const double vb = v[0] * bx + v[1] * by + v[2] * bz;
+      const double cxv = +(v[1] * bz - v[2] * by), cyv = -(v[0] * bz - v[2] * bx), czv = +(v[0] * by - v[1] * bx);
+      const double iq = q * mpw / (1. + b2);
+      const double Ip[3] = {iq * (v[0] + cxv + vb * bx), iq * (v[1] + cyv + vb * by), iq * (v[2] + czv + vb * bz)};
+      const double A_p = 0.5 * dt * dt * mpw * q * q / m / (1 + b2);
+      const double AB[9] = {
+        A_p * (1.0 + bx * bx), A_p * (+bz + bx * by), A_p * (-by + bx * bz),
+        A_p * (-bz + by * bx), A_p * (1.0 + by * by), A_p * (+bx + by * bz),
+        A_p * (+by + bz * bx), A_p * (-bx + bz * by), A_p * (1.0 + bz * bz)};
+      // staggered-axis weights spread over the cell's 3 node slots (slot = node - cell + 1), :87-89
+      double w3[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int o = w.is[a] - w.in[a] + 1; // ox, oy, oz in {0, 1}
+        w3[a][0] = o == 0 ? w.ws[a][0] : 0.0;
+        w3[a][1] = o == 0 ? w.ws[a][1] : w.ws[a][0];
+        w3[a][2] = o == 0 ? 0.0 : w.ws[a][1];
+      }
+      double* col = sh + lane;
+      // X rows: (k*2 + j)*3 + l ; s = wnz[k]*wny[j]*wsx[.]   (:138, :145)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int l = 0; l < 3; ++l) col[((k * 2 + j) * 3 + l) * kPad] = w.wn[2][k] * w.wn[1][j] * w3[0][l];
+      // Y rows: 12 + (k*3 + l)*2 + i ; s = wnz[k]*wsy[.]*wnx[i]   (:139, :146)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) col[(12 + (k * 3 + l) * 2 + i) * kPad] = w.wn[2][k] * w3[1][l] * w.wn[0][i];
+      // Z rows: 24 + (l*2 + j)*2 + i ; s = wsz[.]*wny[j]*wnx[i]   (:140, :147)
+#pragma unroll
+      for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) col[(24 + (l * 2 + j) * 2 + i) * kPad] = w3[2][l] * w.wn[1][j] * w.wn[0][i];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) col[(36 + e) * kPad] = AB[e];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) col[(45 + e) * kPad] = Ip[e];
+    }
+    __syncthreads();
+
+    if (has_tile) {
+      const double* rp = sh + (kTileR * rt) * kPad;
+      const double* cp = sh + (kTileC * ct) * kPad;
+      const double* ap = sh + (36 + c1 * 3 + c2) * kPad;
+      for (int p = 0; p < mcnt; ++p) {
+        const double ab = ap[p];
+        double r[kTileR], cc[kTileC];
+#pragma unroll
+        for (int a = 0; a < kTileR; ++a) r[a] = rp[a * kPad + p] * ab;
+#pragma unroll
+        for (int bb = 0; bb < kTileC; ++bb) cc[bb] = cp[bb * kPad + p];
+#pragma unroll
+        for (int a = 0; a < kTileR; ++a)
+#pragma unroll
+          for (int bb = 0; bb < kTileC; ++bb) acc[a][bb] += r[a] * cc[bb];
+      }
+    }
+    if (lane < 36) {
+      const double* sp = sh + lane * kPad;
+      const double* ip = sh + (45 + lane / 12) * kPad;
+      for (int p = 0; p < mcnt; ++p) accI += sp[p] * ip[p];
+    }
+  }
+
+  // ---- flush the cell block: MatSetValuesCOO's duplicate summation (simulation.cpp:366) as fp64 atomics
+  if (has_tile) {
+#pragma unroll
+    for (int a = 0; a < kTileR; ++a)
+#pragma unroll
+      for (int bb = 0; bb < kTileC; ++bb) {
+        const int i36 = kTileR * rt + a, j36 = kTileC * ct + bb;
+        const int desc = ltab[i36 * 36 + j36];
+        const int k = desc & 0xff;
+        if (k == 0xff) continue; // |d| = 2 same-component pair: structurally zero
+        const int rx = g.wx(cx + ((desc >> 10) & 3) - 1);
+        const int ry = g.wy(cy + ((desc >> 12) & 3) - 1);
+        const int rz = cz + ((desc >> 14) & 3) - 1;
+        const int rzw = rz < 0 ? rz + g.nzl : (rz >= g.nzl ? rz - g.nzl : rz);
+        const long addr = ((((long)c1 * g.nzl + rzw) * g.ny + ry) * kLStencil + k) * g.nx + rx;
+        unsafeAtomicAdd(&matL[addr], acc[a][bb]);
+      }
+  }
+  if (lane < 36) {
+    const int c = lane / 12;
+    int o[3];
+    block_node_offset(c, lane % 12, o);
+    unsafeAtomicAdd(&currI[c * g.cstride + g.nodew(cx + o[0], cy + o[1], cz + o[2])], accI);
+  }
+}
+
+}  // namespace
+
+// table: (row i36, col j36) of the cell block -> k of the row stencil + row node offset.  The (row, col)
+// node pairs are those of ecsim::Simulation::fill_matrix_indices (src/impls/ecsim/simulation.cpp:408-464).
+int build_ltab(xpic_ctx* c)
+{
+  std::vector<int> tab(36 * 36);
+  for (int i = 0; i < 36; ++i)
+    for (int j = 0; j < 36; ++j) {
+      int c1 = i / 12, c2 = j / 12, o1[3], o2[3];
+      block_node_offset(c1, i % 12, o1);
+      block_node_offset(c2, j % 12, o2);
+      int k = lencode(c1, c2, o2[0] - o1[0], o2[1] - o1[1], o2[2] - o1[2]);
+      int desc = (k < 0 ? 0xff : k) | (c1 << 8) | ((o1[0] + 1) << 10) | ((o1[1] + 1) << 12) | ((o1[2] + 1) << 14);
+      tab[i * 36 + j] = desc;
+    }
+  XPIC_HIP(hipMalloc(&c->ltab, sizeof(int) * tab.size()));
+  XPIC_HIP(hipMemcpy(c->ltab, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, double* matL)
+{
+  if (s.n == 0) return 0;
+  XPIC_CHECK(c->g.G == 0, "ecsim_fill: ghost-row exchange for nranks > 1 is not built yet");
+  Timed t(c, "fill_current");
+  const long chunk = (c->ncell + 7) / 8;
+  const long nblocks = chunk * 8;
+  XPIC_CHECK(nblocks < 2147483647L, "too many cells for one launch");
+  hipLaunchKernelGGL(k_ecsim_fill, dim3((unsigned)nblocks), dim3(64), 0, c->stream, c->g, s.d, B, currI_sort, matL,
+    c->ltab, s.par.q, s.par.m, s.par.n / (double)s.par.Np, (long)c->ncell, chunk);
+  XPIC_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace xpic

@@ -1,0 +1,469 @@
+// fields.hip -- grid-side kernels: BLAS-1 (K14), curl (K11), matM (K12), matL / matA SpMV (K13),
+// layout conversion at the boundary, two-stage reductions.  All HBM-bound; see DESIGN.md for the
+// algorithmic byte counts each kernel is measured against.
+#include "common.h"
+#include "lstencil.h"
+
+namespace xpic {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline dim3 ew_grid(const GridDev& g)
+{
+  long blocks = (g.nown + kBlock * 2 - 1) / (kBlock * 2);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  return dim3((unsigned)blocks, 3, 1);
+}
+
+// ---- element-wise kernels over the owned planes of the 3 components (grid.y = component) ----------
+template <class F>
+__global__ void __launch_bounds__(kBlock) k_ew(GridDev g, F f)
+{
+  const long off = (long)blockIdx.y * g.cstride + (long)g.G * g.plane;
+  const long n = g.nown;
+  const long stride = (long)gridDim.x * kBlock;
+  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) f(off + i);
+}
+
+struct FSet { double* y; double a; __device__ void operator()(long i) const { y[i] = a; } };
+struct FCopy { double* y; const double* x; __device__ void operator()(long i) const { y[i] = x[i]; } };
+struct FAxpy { double* y; double a; const double* x; __device__ void operator()(long i) const { y[i] += a * x[i]; } };
+struct FAxpby { double* y; double a, b; const double* x; __device__ void operator()(long i) const { y[i] = a * x[i] + b * y[i]; } };
+struct FWaxpby { double* w; double a; const double* x; double b; const double* y; __device__ void operator()(long i) const { w[i] = a * x[i] + b * y[i]; } };
+struct FScaleTo { double* y; double a; const double* x; __device__ void operator()(long i) const { y[i] = a * x[i]; } };
+
+template <class F>
+int launch_ew(xpic_ctx* c, F f)
+{
+  hipLaunchKernelGGL(k_ew<F>, ew_grid(c->g), dim3(kBlock), 0, c->stream, c->g, f);
+  XPIC_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- reductions -------------------------------------------------------------------------------------
+__device__ inline double wave_sum(double v)
+{
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// block-reduce NV values, thread 0 writes partial[j*nblocks + block]
+template <int NV>
+__device__ inline void block_reduce_store(double (&acc)[NV], double* partial, int nblocks, int block)
+{
+  __shared__ double sm[NV][kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    double v = wave_sum(acc[j]);
+    if (lane == 0) sm[j][wave] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double v = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) v += sm[threadIdx.x][w];
+    partial[(long)threadIdx.x * nblocks + block] = v;
+  }
+}
+
+struct VPtrs { const double* p[8]; };
+struct HVals { double h[8]; };
+
+// partial[j][blk] = sum_i w[i] * V_j[i]
+template <int NV>
+__global__ void __launch_bounds__(kBlock) k_mdot(GridDev g, const double* w, VPtrs V, double* partial)
+{
+  double acc[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) acc[j] = 0.0;
+  const long off = (long)blockIdx.y * g.cstride + (long)g.G * g.plane;
+  const long stride = (long)gridDim.x * kBlock;
+  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < g.nown; i += stride) {
+    double wi = w[off + i];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) acc[j] += wi * V.p[j][off + i];
+  }
+  block_reduce_store<NV>(acc, partial, gridDim.x * gridDim.y, blockIdx.y * gridDim.x + blockIdx.x);
+}
+
+// w -= sum_j h_j V_j ; optionally partial[blk] = sum w^2 (after the update)
+template <int NV, bool NORM>
+__global__ void __launch_bounds__(kBlock) k_maxpy(GridDev g, double* w, VPtrs V, HVals h, double* partial)
+{
+  double acc[1] = {0.0};
+  const long off = (long)blockIdx.y * g.cstride + (long)g.G * g.plane;
+  const long stride = (long)gridDim.x * kBlock;
+  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < g.nown; i += stride) {
+    double wi = w[off + i];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) wi -= h.h[j] * V.p[j][off + i];
+    w[off + i] = wi;
+    if (NORM) acc[0] += wi * wi;
+  }
+  if (NORM) block_reduce_store<1>(acc, partial, gridDim.x * gridDim.y, blockIdx.y * gridDim.x + blockIdx.x);
+}
+
+// sum of squares and per-component sums of one field: partial rows {sq, sum_c} per component block
+__global__ void __launch_bounds__(kBlock) k_stats(GridDev g, const double* f, double* partial)
+{
+  double acc[2] = {0.0, 0.0};
+  const long off = (long)blockIdx.y * g.cstride + (long)g.G * g.plane;
+  const long stride = (long)gridDim.x * kBlock;
+  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < g.nown; i += stride) {
+    double v = f[off + i];
+    acc[0] += v * v;
+    acc[1] += v;
+  }
+  block_reduce_store<2>(acc, partial, gridDim.x * gridDim.y, blockIdx.y * gridDim.x + blockIdx.x);
+}
+
+// out[j*nseg + s] = sum over segment s of partial[j*nblocks + ...]; one block per (j, s)
+__global__ void __launch_bounds__(kBlock) k_reduce_final(const double* partial, int nblocks, int nseg, double* out)
+{
+  const int j = blockIdx.x / nseg, s = blockIdx.x % nseg;
+  const int seg = nblocks / nseg;
+  double v = 0;
+  for (int i = threadIdx.x; i < seg; i += kBlock) v += partial[(long)j * nblocks + s * seg + i];
+  __shared__ double sm[kBlock / 64];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+    for (int w = 0; w < kBlock / 64; ++w) t += sm[w];
+    out[blockIdx.x] = t;
+  }
+}
+
+inline dim3 red_grid(const GridDev& g)
+{
+  long blocks = (g.nown + kBlock * 4 - 1) / (kBlock * 4);
+  long cap = kRedBlocks / 3;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return dim3((unsigned)blocks, 3, 1);
+}
+
+int finish_reduce(xpic_ctx* c, int nv, int nblocks, int nseg, double* host_out)
+{
+  hipLaunchKernelGGL(k_reduce_final, dim3(nv * nseg), dim3(kBlock), 0, c->stream, c->red_partial, nblocks, nseg, c->red_out);
+  XPIC_HIP(hipGetLastError());
+  XPIC_HIP(hipMemcpyAsync(c->red_host, c->red_out, sizeof(double) * nv * nseg, hipMemcpyDeviceToHost, c->stream));
+  XPIC_HIP(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < nv * nseg; ++i) host_out[i] = c->red_host[i];
+  return 0;
+}
+
+// ---- curl: Rotor::fill_stencil + values (src/utils/operators.cpp:155-215) ---------------------------
+// positive shift: (rot F)_x = (Fz[y+1]-Fz[y])/dy - (Fy[z+1]-Fy[z])/dz, ... ; negative: backward differences.
+template <int SIGN>
+__device__ inline void rot_at(const GridDev& g, const double* F, int x, int y, int z, double& rx, double& ry, double& rz)
+{
+  const double ix = 1.0 / g.dx, iy = 1.0 / g.dy, iz = 1.0 / g.dz;
+  const double* Fx = F;
+  const double* Fy = F + g.cstride;
+  const double* Fz = F + 2 * g.cstride;
+  const long c0 = g.nodew(x, y, z);
+  if (SIGN > 0) {
+    const long xp = g.nodew(x + 1, y, z), yp = g.nodew(x, y + 1, z), zp = g.nodew(x, y, z + 1);
+    rx = +iy * Fz[yp] - iy * Fz[c0] - iz * Fy[zp] + iz * Fy[c0];
+    ry = -ix * Fz[xp] + ix * Fz[c0] + iz * Fx[zp] - iz * Fx[c0];
+    rz = +ix * Fy[xp] - ix * Fy[c0] - iy * Fx[yp] + iy * Fx[c0];
+  }
+  else {
+    const long xm = g.nodew(x - 1, y, z), ym = g.nodew(x, y - 1, z), zm = g.nodew(x, y, z - 1);
+    rx = +iy * Fz[c0] - iy * Fz[ym] - iz * Fy[c0] + iz * Fy[zm];
+    ry = -ix * Fz[c0] + ix * Fz[xm] + iz * Fx[c0] - iz * Fx[zm];
+    rz = +ix * Fy[c0] - ix * Fy[xm] - iy * Fx[c0] + iy * Fx[ym];
+  }
+}
+
+template <int SIGN>
+__global__ void __launch_bounds__(kBlock) k_rot(GridDev g, double alpha, const double* F, double* out, int add)
+{
+  const long n = g.nown;
+  const long stride = (long)gridDim.x * kBlock;
+  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    int x = (int)(i % g.nx), y = (int)((i / g.nx) % g.ny), z = (int)(i / g.plane);
+    double rx, ry, rz;
+    rot_at<SIGN>(g, F, x, y, z, rx, ry, rz);
+    const long o = g.node(x, y, g.wz(z));
+    if (add) {
+      out[o] += alpha * rx;
+      out[o + g.cstride] += alpha * ry;
+      out[o + 2 * g.cstride] += alpha * rz;
+    }
+    else {
+      out[o] = alpha * rx;
+      out[o + g.cstride] = alpha * ry;
+      out[o + 2 * g.cstride] = alpha * rz;
+    }
+  }
+}
+
+// (matM x)_c = 2 x_c + 0.5 dt^2 (rot- rot+ x)_c   (src/impls/ecsim/simulation.cpp:544-551)
+// rot+ is evaluated on the fly at the 2 neighbours each backward difference needs: a 13-point stencil.
+__device__ inline void matM_at(const GridDev& g, const double* F, int x, int y, int z, double& mx, double& my, double& mz)
+{
+  const double ix = 1.0 / g.dx, iy = 1.0 / g.dy, iz = 1.0 / g.dz;
+  double ax, ay, az; // rot+ at (x,y,z)
+  double bx, by, bz; // rot+ at (x-1,y,z)
+  double cx, cy, cz; // rot+ at (x,y-1,z)
+  double dx_, dy_, dz_; // rot+ at (x,y,z-1)
+  rot_at<+1>(g, F, x, y, z, ax, ay, az);
+  rot_at<+1>(g, F, x - 1, y, z, bx, by, bz);
+  rot_at<+1>(g, F, x, y - 1, z, cx, cy, cz);
+  rot_at<+1>(g, F, x, y, z - 1, dx_, dy_, dz_);
+  const double s = 0.5 * g.dt * g.dt;
+  const long c0 = g.nodew(x, y, z);
+  // negative-shift curl of G = rot+ F (operators.cpp:196-213)
+  double rx = +iy * az - iy * cz - iz * ay + iz * dy_;
+  double ry = -ix * az + ix * bz + iz * ax - iz * dx_;
+  double rz = +ix * ay - ix * by - iy * ax + iy * cx;
+  mx = 2.0 * F[c0] + s * rx;
+  my = 2.0 * F[c0 + g.cstride] + s * ry;
+  mz = 2.0 * F[c0 + 2 * g.cstride] + s * rz;
+}
+
+__global__ void __launch_bounds__(kBlock) k_matM(GridDev g, const double* F, double* out, int add)
+{
+  const long n = g.nown;
+  const long stride = (long)gridDim.x * kBlock;
+  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    int x = (int)(i % g.nx), y = (int)((i / g.nx) % g.ny), z = (int)(i / g.plane);
+    double mx, my, mz;
+    matM_at(g, F, x, y, z, mx, my, mz);
+    const long o = g.node(x, y, g.wz(z));
+    if (add) { out[o] += mx; out[o + g.cstride] += my; out[o + 2 * g.cstride] += mz; }
+    else { out[o] = mx; out[o + g.cstride] = my; out[o + 2 * g.cstride] = mz; }
+  }
+}
+
+// ---- matL / matA SpMV ---------------------------------------------------------------------------
+// matL[c1][z][y][k][x]: one workgroup owns the x-row of one (c1, y, z); lane = x.  The 123 coefficient
+// streams of the row are contiguous (123*nx doubles), every load is a full coalesced wave line; the
+// operand vector comes out of L1/L2 (each element is re-used by 123 rows).
+template <int C1, bool WITH_M>
+__device__ inline double row_apply(const GridDev& g, const double* __restrict__ L, const double* __restrict__ X,
+  int x, int y, int z)
+{
+  const double* Lrow = L + ((((long)C1 * g.nzl + z) * g.ny + y) * kLStencil) * g.nx + x;
+  int xs[5];
+#pragma unroll
+  for (int d = -2; d <= 2; ++d) xs[d + 2] = g.wx(x + d);
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < kLStencil; ++k) {
+    const LEntry e = ldecode(C1, k);
+    const long rowbase = e.c2 * g.cstride + ((long)g.wz(z + e.d[2]) * g.ny + g.wy(y + e.d[1])) * g.nx;
+    acc += Lrow[(long)k * g.nx] * X[rowbase + xs[e.d[0] + 2]];
+  }
+  (void)WITH_M;
+  return acc;
+}
+
+template <bool WITH_L, bool WITH_M>
+__global__ void __launch_bounds__(kBlock) k_matA(GridDev g, const double* __restrict__ L, const double* __restrict__ X,
+  double* __restrict__ Y, int add)
+{
+  // grid: x = x-chunks, y = ny, z = nzl ; each workgroup does the three components of its nodes
+  const int x = blockIdx.x * kBlock + threadIdx.x;
+  const int y = blockIdx.y, z = blockIdx.z;
+  if (x >= g.nx) return;
+  double r0 = 0, r1 = 0, r2 = 0;
+  if (WITH_M) matM_at(g, X, x, y, z, r0, r1, r2);
+  if (WITH_L) {
+    r0 += row_apply<0, WITH_M>(g, L, X, x, y, z);
+    r1 += row_apply<1, WITH_M>(g, L, X, x, y, z);
+    r2 += row_apply<2, WITH_M>(g, L, X, x, y, z);
+  }
+  const long o = g.node(x, y, g.wz(z));
+  if (add) { Y[o] += r0; Y[o + g.cstride] += r1; Y[o + 2 * g.cstride] += r2; }
+  else { Y[o] = r0; Y[o + g.cstride] = r1; Y[o + 2 * g.cstride] = r2; }
+}
+
+// ---- boundary layout conversion: [z][y][x][3] (reference DMDA order) <-> SoA with ghost planes ----
+__global__ void __launch_bounds__(kBlock) k_import(GridDev g, const double* aos, double* soa)
+{
+  const long n = g.nown * 3;
+  const long stride = (long)gridDim.x * kBlock;
+  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    long node = i / 3;
+    int c = (int)(i % 3);
+    soa[c * g.cstride + (long)g.G * g.plane + node] = aos[i];
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_export(GridDev g, const double* soa, double* aos)
+{
+  const long n = g.nown * 3;
+  const long stride = (long)gridDim.x * kBlock;
+  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    long node = i / 3;
+    int c = (int)(i % 3);
+    aos[i] = soa[c * g.cstride + (long)g.G * g.plane + node];
+  }
+}
+
+}  // namespace
+
+int vec_set(xpic_ctx* c, double* y, double a) { return launch_ew(c, FSet{y, a}); }
+int vec_copy(xpic_ctx* c, double* y, const double* x) { return launch_ew(c, FCopy{y, x}); }
+int vec_axpy(xpic_ctx* c, double* y, double a, const double* x) { return launch_ew(c, FAxpy{y, a, x}); }
+int vec_axpby(xpic_ctx* c, double* y, double a, double b, const double* x) { return launch_ew(c, FAxpby{y, a, b, x}); }
+int vec_waxpby(xpic_ctx* c, double* w, double a, const double* x, double b, const double* y) { return launch_ew(c, FWaxpby{w, a, x, b, y}); }
+int vec_scale_to(xpic_ctx* c, double* y, double a, const double* x) { return launch_ew(c, FScaleTo{y, a, x}); }
+
+int vec_mdot_host(xpic_ctx* c, const double* w, const double* V, int nv, double* out)
+{
+  Timed t(c, "mdot");
+  dim3 grid = red_grid(c->g);
+  const int nblocks = grid.x * grid.y;
+  for (int j0 = 0; j0 < nv; j0 += 8) {
+    int m = nv - j0 < 8 ? nv - j0 : 8;
+    VPtrs P{};
+    for (int j = 0; j < m; ++j) P.p[j] = V + (long)(j0 + j) * c->nvec;
+    double* part = c->red_partial + (long)j0 * nblocks;
+    switch (m) {
+#define CASE(N) case N: hipLaunchKernelGGL(k_mdot<N>, grid, dim3(kBlock), 0, c->stream, c->g, w, P, part); break;
+      CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+    }
+    XPIC_HIP(hipGetLastError());
+  }
+  return finish_reduce(c, nv, nblocks, 1, out);
+}
+
+int vec_dot_host(xpic_ctx* c, const double* x, const double* y, double* out)
+{
+  return vec_mdot_host(c, x, y, 1, out);
+}
+
+int vec_maxpy_norm_host(xpic_ctx* c, double* w, const double* V, int nv, const double* h, double* nrm2)
+{
+  Timed t(c, "maxpy");
+  dim3 grid = red_grid(c->g);
+  const int nblocks = grid.x * grid.y;
+  for (int j0 = 0; j0 < nv; j0 += 8) {
+    int m = nv - j0 < 8 ? nv - j0 : 8;
+    bool last = (j0 + 8 >= nv) && nrm2;
+    VPtrs P{};
+    HVals H{};
+    for (int j = 0; j < m; ++j) { P.p[j] = V + (long)(j0 + j) * c->nvec; H.h[j] = h[j0 + j]; }
+    switch (m) {
+#define CASE(N)                                                                                                \
+  case N:                                                                                                      \
+    if (last) hipLaunchKernelGGL((k_maxpy<N, true>), grid, dim3(kBlock), 0, c->stream, c->g, w, P, H, c->red_partial); \
+    else hipLaunchKernelGGL((k_maxpy<N, false>), grid, dim3(kBlock), 0, c->stream, c->g, w, P, H, c->red_partial);     \
+    break;
+      CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+    }
+    XPIC_HIP(hipGetLastError());
+  }
+  if (nrm2) return finish_reduce(c, 1, nblocks, 1, nrm2);
+  return 0;
+}
+
+int vec_maxpy(xpic_ctx* c, double* x, const double* V, int nv, const double* y)
+{
+  double neg[kMaxDots];
+  for (int i = 0; i < nv; ++i) neg[i] = -y[i];
+  return vec_maxpy_norm_host(c, x, V, nv, neg, nullptr);
+}
+
+int field_stats_host(xpic_ctx* c, const double* f, double* sumsq, double* mean3)
+{
+  dim3 grid = red_grid(c->g);
+  const int nblocks = grid.x * grid.y;
+  hipLaunchKernelGGL(k_stats, grid, dim3(kBlock), 0, c->stream, c->g, f, c->red_partial);
+  XPIC_HIP(hipGetLastError());
+  double out[6];
+  XPIC_CALL(finish_reduce(c, 2, nblocks, 3, out)); // out[j*3 + comp]
+  *sumsq = out[0] + out[1] + out[2];
+  mean3[0] = out[3]; mean3[1] = out[4]; mean3[2] = out[5];
+  return 0;
+}
+
+int rot_apply(xpic_ctx* c, int sign, double alpha, const double* x, double* y, bool add)
+{
+  Timed t(c, "rot_apply");
+  long blocks = (c->g.nown + kBlock - 1) / kBlock;
+  if (blocks > 65536) blocks = 65536;
+  if (sign > 0) hipLaunchKernelGGL(k_rot<+1>, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, c->g, alpha, x, y, add ? 1 : 0);
+  else hipLaunchKernelGGL(k_rot<-1>, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, c->g, alpha, x, y, add ? 1 : 0);
+  XPIC_HIP(hipGetLastError());
+  return 0;
+}
+
+int matM_apply(xpic_ctx* c, const double* x, double* y, bool add)
+{
+  Timed t(c, "matM_apply");
+  long blocks = (c->g.nown + kBlock - 1) / kBlock;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(k_matM, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, c->g, x, y, add ? 1 : 0);
+  XPIC_HIP(hipGetLastError());
+  return 0;
+}
+
+static dim3 row_grid(const GridDev& g) { return dim3((g.nx + kBlock - 1) / kBlock, g.ny, g.nzl); }
+
+int matL_apply(xpic_ctx* c, const double* x, double* y, bool add)
+{
+  Timed t(c, "matL_apply");
+  hipLaunchKernelGGL((k_matA<true, false>), row_grid(c->g), dim3(kBlock), 0, c->stream, c->g, c->matL, x, y, add ? 1 : 0);
+  XPIC_HIP(hipGetLastError());
+  return 0;
+}
+
+int matA_apply(xpic_ctx* c, const double* x, double* y)
+{
+  Timed t(c, "matA_apply");
+  hipLaunchKernelGGL((k_matA<true, true>), row_grid(c->g), dim3(kBlock), 0, c->stream, c->g, c->matL, x, y, 0);
+  XPIC_HIP(hipGetLastError());
+  return 0;
+}
+
+int field_import(xpic_ctx* c, double* dst, const double* src_host)
+{
+  const long n = c->g.nown * 3;
+  double* tmp = nullptr;
+  XPIC_HIP(hipMalloc(&tmp, sizeof(double) * n));
+  XPIC_HIP(hipMemcpyAsync(tmp, src_host, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  long blocks = (n + kBlock - 1) / kBlock;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(k_import, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, c->g, tmp, dst);
+  XPIC_HIP(hipGetLastError());
+  XPIC_HIP(hipStreamSynchronize(c->stream));
+  XPIC_HIP(hipFree(tmp));
+  return halo_fill(c, dst);
+}
+
+int field_export(xpic_ctx* c, const double* src, double* dst_host)
+{
+  const long n = c->g.nown * 3;
+  double* tmp = nullptr;
+  XPIC_HIP(hipMalloc(&tmp, sizeof(double) * n));
+  long blocks = (n + kBlock - 1) / kBlock;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(k_export, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, c->g, src, tmp);
+  XPIC_HIP(hipGetLastError());
+  XPIC_HIP(hipMemcpyAsync(dst_host, tmp, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  XPIC_HIP(hipStreamSynchronize(c->stream));
+  XPIC_HIP(hipFree(tmp));
+  return 0;
+}
+
+int halo_fill(xpic_ctx* c, double* f)
+{
+  (void)f;
+  if (c->g.G == 0) return 0;
+  set_error("halo exchange for nranks > 1 is not built yet");
+  return 3;
+}
+
+}  // namespace xpic

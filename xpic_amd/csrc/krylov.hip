@@ -1,0 +1,148 @@
+// krylov.hip -- the Krylov drivers behind xpic_solve: restarted GMRES(30) with classical Gram-Schmidt
+// (what PETSc's default KSPGMRES runs for the reference, src/impls/ecsim/simulation.cpp:558-567, minus the
+// ILU(0) preconditioner that lives in PETSc) and CG for the SPD matM.  The operator applies and the
+// fused multi-dot / multi-axpy kernels are in fields.hip; the (m+1) x m Hessenberg least-squares problem
+// is tiny and stays on the host, fed by one device->host copy of the iteration's dot products.
+#include <cmath>
+
+#include "common.h"
+
+namespace xpic {
+
+namespace {
+
+constexpr int kRestart = 30;
+
+int apply_op(xpic_ctx* c, int op, const double* x, double* y)
+{
+  if (op == XPIC_OP_MATA_GMRES) return matA_apply(c, x, y);
+  return matM_apply(c, x, y, false);
+}
+
+int gmres(xpic_ctx* c, int op, const double* b, double* x, double rtol, double atol, int maxit, int* its_out,
+  int* reason, double* rnorm_out)
+{
+  const int m = kRestart;
+  double* V = c->kry_V;
+  double* w = c->kry_w;
+  std::vector<double> H((m + 1) * m, 0.0), cs(m), sn(m), gg(m + 1), h(m + 2), yv(m);
+  XPIC_CALL(vec_set(c, x, 0.0));
+  double bb;
+  XPIC_CALL(vec_dot_host(c, b, b, &bb));
+  const double bnorm = std::sqrt(bb);
+  const double tol = std::max(rtol * bnorm, atol);
+  double rnorm = bnorm;
+  int its = 0;
+  *reason = 0;
+  if (rnorm <= tol) {
+    *its_out = 0; *reason = 1; *rnorm_out = rnorm;
+    return 0;
+  }
+  // r = b (x0 = 0)
+  const double* r = b;
+  while (its < maxit) {
+    XPIC_CALL(vec_scale_to(c, V, 1.0 / rnorm, r)); // V_0 = r / |r|
+    std::fill(gg.begin(), gg.end(), 0.0);
+    gg[0] = rnorm;
+    int j = 0;
+    for (; j < m && its < maxit; ++j) {
+      double* Vj = V + (long)j * c->nvec;
+      XPIC_CALL(apply_op(c, op, Vj, w));
+      XPIC_CALL(vec_mdot_host(c, w, V, j + 1, h.data()));           // VecMDot
+      double nrm2;
+      XPIC_CALL(vec_maxpy_norm_host(c, w, V, j + 1, h.data(), &nrm2)); // VecMAXPY + VecNorm
+      h[j + 1] = std::sqrt(nrm2);
+      if (h[j + 1] != 0.0) XPIC_CALL(vec_scale_to(c, V + (long)(j + 1) * c->nvec, 1.0 / h[j + 1], w));
+      for (int i = 0; i < j; ++i) {
+        const double t = cs[i] * h[i] + sn[i] * h[i + 1];
+        h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1];
+        h[i] = t;
+      }
+      const double den = std::hypot(h[j], h[j + 1]);
+      cs[j] = h[j] / den;
+      sn[j] = h[j + 1] / den;
+      h[j] = den;
+      gg[j + 1] = -sn[j] * gg[j];
+      gg[j] = cs[j] * gg[j];
+      for (int i = 0; i <= j; ++i) H[i * m + j] = h[i];
+      ++its;
+      rnorm = std::abs(gg[j + 1]);
+      if (rnorm <= tol) { ++j; break; }
+    }
+    for (int i = j - 1; i >= 0; --i) {
+      double t = gg[i];
+      for (int k = i + 1; k < j; ++k) t -= H[i * m + k] * yv[k];
+      yv[i] = t / H[i * m + i];
+    }
+    XPIC_CALL(vec_maxpy(c, x, V, j, yv.data())); // x += V y
+    if (rnorm <= tol) break;
+    if (its >= maxit) break;
+    // restart: r = b - A x, kept in w
+    XPIC_CALL(apply_op(c, op, x, w));
+    XPIC_CALL(vec_axpby(c, w, 1.0, -1.0, b)); // w = b - w
+    double rr;
+    XPIC_CALL(vec_dot_host(c, w, w, &rr));
+    rnorm = std::sqrt(rr);
+    // V_0 is rebuilt from w; park r in the last basis slot so that V_0 may be overwritten
+    double* park = V + (long)m * c->nvec;
+    XPIC_CALL(vec_copy(c, park, w));
+    r = park;
+    if (rnorm <= tol) break;
+  }
+  *its_out = its;
+  *rnorm_out = rnorm;
+  *reason = rnorm <= tol ? 2 : -3; // KSP_CONVERGED_RTOL-like / KSP_DIVERGED_ITS
+  return 0;
+}
+
+int cg(xpic_ctx* c, int op, const double* b, double* x, double rtol, double atol, int maxit, int* its_out,
+  int* reason, double* rnorm_out)
+{
+  double* r = c->kry_V;
+  double* p = c->kry_V + c->nvec;
+  double* Ap = c->kry_w;
+  XPIC_CALL(vec_set(c, x, 0.0));
+  XPIC_CALL(vec_copy(c, r, b));
+  XPIC_CALL(vec_copy(c, p, b));
+  double rr;
+  XPIC_CALL(vec_dot_host(c, r, r, &rr));
+  const double tol = std::max(rtol * std::sqrt(rr), atol);
+  int its = 0;
+  while (std::sqrt(rr) > tol && its < maxit) {
+    XPIC_CALL(apply_op(c, op, p, Ap));
+    double pAp;
+    XPIC_CALL(vec_dot_host(c, p, Ap, &pAp));
+    const double alpha = rr / pAp;
+    XPIC_CALL(vec_axpy(c, x, alpha, p));
+    XPIC_CALL(vec_axpy(c, r, -alpha, Ap));
+    double rr1;
+    XPIC_CALL(vec_dot_host(c, r, r, &rr1));
+    const double beta = rr1 / rr;
+    rr = rr1;
+    XPIC_CALL(vec_axpby(c, p, 1.0, beta, r)); // p = r + beta p
+    ++its;
+  }
+  *its_out = its;
+  *rnorm_out = std::sqrt(rr);
+  *reason = std::sqrt(rr) <= tol ? 2 : -3;
+  return 0;
+}
+
+}  // namespace
+
+int solve(xpic_ctx* c, int op, const double* rhs, double* x, double rtol, double atol, int maxit, int* its,
+  int* reason, double* rnorm)
+{
+  int rc;
+  if (op == XPIC_OP_MATM_CG) rc = cg(c, op, rhs, x, rtol, atol, maxit, its, reason, rnorm);
+  else rc = gmres(c, op, rhs, x, rtol, atol, maxit, its, reason, rnorm);
+  if (rc) return rc;
+  if (*reason < 0) {
+    // KSPSetErrorIfNotConverged(ksp, PETSC_TRUE), src/impls/ecsim/simulation.cpp:562
+    set_error("KSP did not converge: " + std::to_string(*its) + " iterations, |r| = " + std::to_string(*rnorm));
+    return 4;
+  }
+  return 0;
+}
+
+}  // namespace xpic

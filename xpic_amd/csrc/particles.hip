@@ -1,0 +1,460 @@
+// particles.hip -- particle-side kernels: SoA storage, move + periodic wrap + cell binning, the
+// out-of-place counting sort that replaces the reference's per-cell std::list splicing, the CIC
+// gather + Boris velocity update, reductions over particles, the synthetic loader.
+#include "common.h"
+#include "device_common.h"
+
+namespace xpic {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline unsigned pgrid(int64_t n, int per_thread = 1)
+{
+  int64_t b = (n + (int64_t)kBlock * per_thread - 1) / ((int64_t)kBlock * per_thread);
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+// pass 1 of update_cells: (BorisPush::update_r) + correct_coordinates + new cell + arrival rank in it
+template <bool MOVE, bool WRAP>
+__global__ void __launch_bounds__(kBlock) k_move_bin(GridDev g, SortDev s, int64_t n, double step)
+{
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n) return;
+  double x = s.r[0][p], y = s.r[1][p], z = s.r[2][p];
+  if (MOVE) {
+    x += s.v[0][p] * step;
+    y += s.v[1][p] * step;
+    z += s.v[2][p] * step;
+  }
+  if (WRAP) {
+    x = bound_periodic(x, g.Lx);
+    y = bound_periodic(y, g.Ly);
+    z = bound_periodic(z, g.Lz);
+  }
+  const int c = cell_of(g, x, y, z);
+  s.cell[p] = c;
+  s.rank[p] = c >= 0 ? atomicAdd(&s.cell_count[c], 1) : 0;
+}
+
+// pass 2: recompute the moved + wrapped position (bitwise the same arithmetic) and scatter the record
+template <bool MOVE, bool WRAP>
+__global__ void __launch_bounds__(kBlock) k_scatter(GridDev g, SortDev s, int64_t n, double step)
+{
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n) return;
+  const int c = s.cell[p];
+  if (c < 0) return;
+  double x = s.r[0][p], y = s.r[1][p], z = s.r[2][p];
+  const double vx = s.v[0][p], vy = s.v[1][p], vz = s.v[2][p];
+  if (MOVE) {
+    x += vx * step;
+    y += vy * step;
+    z += vz * step;
+  }
+  if (WRAP) {
+    x = bound_periodic(x, g.Lx);
+    y = bound_periodic(y, g.Ly);
+    z = bound_periodic(z, g.Lz);
+  }
+  const int64_t d = (int64_t)s.cell_start[c] + s.rank[p];
+  s.r2[0][d] = x; s.r2[1][d] = y; s.r2[2][d] = z;
+  s.v2[0][d] = vx; s.v2[1][d] = vy; s.v2[2][d] = vz;
+}
+
+// ---- exclusive scan of the per-cell counts (3 small kernels; N ints, negligible next to particles) ----
+constexpr int kScanItems = 8; // per thread
+constexpr int kScanTile = kBlock * kScanItems;
+
+__device__ inline int block_excl_scan(int v, int* total)
+{
+  __shared__ int wsum[kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int w = 0; w < kBlock / 64; ++w) {
+    if (w < wave) base += wsum[w];
+    tot += wsum[w];
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ void __launch_bounds__(kBlock) k_scan_tiles(const int* in, long n, int* tile_sums)
+{
+  const long base = (long)blockIdx.x * kScanTile + (long)threadIdx.x * kScanItems;
+  int v = 0;
+  for (int i = 0; i < kScanItems; ++i)
+    if (base + i < n) v += in[base + i];
+  int tot;
+  block_excl_scan(v, &tot);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(kBlock) k_scan_sums(int* tile_sums, int ntiles, int* total_out)
+{
+  // single workgroup, serial over chunks of kBlock tiles
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int b = 0; b < ntiles; b += kBlock) {
+    int i = b + threadIdx.x;
+    int v = i < ntiles ? tile_sums[i] : 0;
+    int tot;
+    int ex = block_excl_scan(v, &tot);
+    int carry = carry_s;
+    if (i < ntiles) tile_sums[i] = carry + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total_out = carry_s;
+}
+
+__global__ void __launch_bounds__(kBlock) k_scan_apply(const int* in, long n, const int* tile_sums, int* out)
+{
+  const long base = (long)blockIdx.x * kScanTile + (long)threadIdx.x * kScanItems;
+  int vals[kScanItems];
+  int v = 0;
+  for (int i = 0; i < kScanItems; ++i) {
+    vals[i] = (base + i < n) ? in[base + i] : 0;
+    v += vals[i];
+  }
+  int tot;
+  int ex = block_excl_scan(v, &tot) + tile_sums[blockIdx.x];
+  for (int i = 0; i < kScanItems; ++i) {
+    if (base + i < n) out[base + i] = ex;
+    ex += vals[i];
+  }
+}
+
+// ecsim::Particles::second_push (src/impls/ecsim/particles.cpp:175-192)
+__global__ void __launch_bounds__(kBlock) k_second_push(GridDev g, SortDev s, int64_t n, const double* __restrict__ E,
+  const double* __restrict__ B, double qm)
+{
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n) return;
+  const W1 w(g, s.r[0][p], s.r[1][p], s.r[2][p]);
+  double Ep[3], Bp[3];
+  gather_s1(g, E, B, w, Ep, Bp);
+  double v[3] = {s.v[0][p], s.v[1][p], s.v[2][p]};
+  update_vEB(g.dt, qm, Ep, Bp, v);
+  s.v[0][p] = v[0]; s.v[1][p] = v[1]; s.v[2][p] = v[2];
+}
+
+__device__ inline double wave_sum(double v)
+{
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// sums of vx, vy, vz, v^2 (Energy::calculate_kinetic, src/diagnostics/energy.cpp:61-108)
+__global__ void __launch_bounds__(kBlock) k_kinetic(SortDev s, int64_t n, double* partial, int nblocks)
+{
+  double a[4] = {0, 0, 0, 0};
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += stride) {
+    const double vx = s.v[0][p], vy = s.v[1][p], vz = s.v[2][p];
+    a[0] += vx; a[1] += vy; a[2] += vz;
+    a[3] += vx * vx + vy * vy + vz * vz;
+  }
+  __shared__ double sm[4][kBlock / 64];
+  for (int j = 0; j < 4; ++j) {
+    double v = wave_sum(a[j]);
+    if ((threadIdx.x & 63) == 0) sm[j][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double v = 0;
+    for (int w = 0; w < kBlock / 64; ++w) v += sm[threadIdx.x][w];
+    partial[(long)threadIdx.x * nblocks + blockIdx.x] = v;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_sum_rows(const double* partial, int nblocks, double* out)
+{
+  double v = 0;
+  for (int i = threadIdx.x; i < nblocks; i += kBlock) v += partial[(long)blockIdx.x * nblocks + i];
+  __shared__ double sm[kBlock / 64];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+    for (int w = 0; w < kBlock / 64; ++w) t += sm[w];
+    out[blockIdx.x] = t;
+  }
+}
+
+// BorisPush::update_r (src/algorithms/boris_push.cpp:19-22) over a whole sort
+__global__ void __launch_bounds__(kBlock) k_move(SortDev s, int64_t n, double step)
+{
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n) return;
+  s.r[0][p] += s.v[0][p] * step;
+  s.r[1][p] += s.v[1][p] * step;
+  s.r[2][p] += s.v[2][p] * step;
+}
+
+__global__ void __launch_bounds__(kBlock) k_scale_v(SortDev s, int64_t n, double lambda)
+{
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n) return;
+  s.v[0][p] *= lambda; s.v[1][p] *= lambda; s.v[2][p] *= lambda;
+}
+
+// AoS Point records (host staging buffer on device) -> SoA tail of the sort
+__global__ void __launch_bounds__(kBlock) k_unpack(SortDev s, int64_t at, int64_t n, const double* pts6)
+{
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  for (int c = 0; c < 3; ++c) {
+    s.r[c][at + i] = pts6[6 * i + c];
+    s.v[c][at + i] = pts6[6 * i + 3 + c];
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_pack(GridDev g, SortDev s, int64_t n, double* pts6, int* cell)
+{
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  for (int c = 0; c < 3; ++c) {
+    pts6[6 * i + c] = s.r[c][i];
+    pts6[6 * i + 3 + c] = s.v[c][i];
+  }
+  cell[i] = cell_of(g, s.r[0][i], s.r[1][i], s.r[2][i]);
+}
+
+// ---- synthetic loader (bench / smoke only): counter-based splitmix64 stream per particle -----------
+__device__ inline uint64_t splitmix(uint64_t& x)
+{
+  uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ inline double u01(uint64_t& st) { return ((splitmix(st) >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+
+__global__ void __launch_bounds__(kBlock) k_synthetic(GridDev g, SortDev s, int64_t n, int ppc, double vth, uint64_t seed)
+{
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n) return;
+  const int64_t cell = p / ppc;
+  const int cx = (int)(cell % g.nx), cy = (int)((cell / g.nx) % g.ny), cz = (int)(cell / g.plane);
+  uint64_t st = seed * 0xD1342543DE82EF95ull + (uint64_t)p * 0x2545F4914F6CDD1Dull;
+  // strictly inside the cell so that the generated order IS the sorted order
+  const double fx = u01(st) * 0.999999 + 0.0000005, fy = u01(st) * 0.999999 + 0.0000005, fz = u01(st) * 0.999999 + 0.0000005;
+  s.r[0][p] = (cx + fx) * g.dx;
+  s.r[1][p] = (cy + fy) * g.dy;
+  s.r[2][p] = (cz + g.z0 + fz) * g.dz;
+  double v[3];
+  for (int c = 0; c < 3; ++c) {
+    const double u1 = u01(st), u2 = u01(st);
+    v[c] = vth * sqrt(-2.0 * log(u1)) * sin(2.0 * M_PI * u2);
+  }
+  const double gam = sqrt(1.0 + v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  s.v[0][p] = v[0] / gam; s.v[1][p] = v[1] / gam; s.v[2][p] = v[2] / gam;
+}
+
+__global__ void __launch_bounds__(kBlock) k_fill_counts(int* count, int* start, long ncell, int ppc)
+{
+  const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (i < ncell) count[i] = ppc;
+  if (i <= ncell) start[i] = (int)(i * ppc);
+}
+
+int exclusive_scan(xpic_ctx* c, const int* in, long n, int* out, int* total_host)
+{
+  const int ntiles = (int)((n + kScanTile - 1) / kScanTile);
+  if (c->scan_tmp_n < ntiles + 1) {
+    if (c->scan_tmp) XPIC_HIP(hipFree(c->scan_tmp));
+    XPIC_HIP(hipMalloc(&c->scan_tmp, sizeof(int) * (ntiles + 1)));
+    c->scan_tmp_n = ntiles + 1;
+  }
+  hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(kBlock), 0, c->stream, in, n, c->scan_tmp);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, c->stream, c->scan_tmp, ntiles, c->scan_tmp + ntiles);
+  hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(kBlock), 0, c->stream, in, n, c->scan_tmp, out);
+  XPIC_HIP(hipGetLastError());
+  // out[n] = total
+  XPIC_HIP(hipMemcpyAsync(out + n, c->scan_tmp + ntiles, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+  if (total_host) {
+    XPIC_HIP(hipMemcpyAsync(total_host, c->scan_tmp + ntiles, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    XPIC_HIP(hipStreamSynchronize(c->stream));
+  }
+  return 0;
+}
+
+}  // namespace
+
+int sort_alloc(xpic_ctx* c, Sort& s, int64_t cap)
+{
+  XPIC_CHECK(cap > 0 && cap < (int64_t)2147483000, "sort capacity must be in (0, 2^31)");
+  s.cap = cap;
+  for (int a = 0; a < 3; ++a) {
+    XPIC_HIP(hipMalloc(&s.d.r[a], sizeof(double) * cap));
+    XPIC_HIP(hipMalloc(&s.d.v[a], sizeof(double) * cap));
+    XPIC_HIP(hipMalloc(&s.d.r2[a], sizeof(double) * cap));
+    XPIC_HIP(hipMalloc(&s.d.v2[a], sizeof(double) * cap));
+  }
+  XPIC_HIP(hipMalloc(&s.d.cell, sizeof(int) * cap));
+  XPIC_HIP(hipMalloc(&s.d.rank, sizeof(int) * cap));
+  XPIC_HIP(hipMalloc(&s.d.cell_count, sizeof(int) * (c->ncell + 1)));
+  XPIC_HIP(hipMalloc(&s.d.cell_start, sizeof(int) * (c->ncell + 1)));
+  XPIC_HIP(hipMemsetAsync(s.d.cell_count, 0, sizeof(int) * (c->ncell + 1), c->stream));
+  XPIC_HIP(hipMemsetAsync(s.d.cell_start, 0, sizeof(int) * (c->ncell + 1), c->stream));
+  s.n = 0;
+  return 0;
+}
+
+void sort_free(Sort& s)
+{
+  for (int a = 0; a < 3; ++a) {
+    (void)hipFree(s.d.r[a]); (void)hipFree(s.d.v[a]); (void)hipFree(s.d.r2[a]); (void)hipFree(s.d.v2[a]);
+  }
+  (void)hipFree(s.d.cell); (void)hipFree(s.d.rank); (void)hipFree(s.d.cell_count); (void)hipFree(s.d.cell_start);
+  (void)hipFree(s.J); (void)hipFree(s.currI); (void)hipFree(s.currJe);
+  s = Sort{};
+}
+
+// (optional) r += step*v, periodic wrap, re-bin, drop what left the box: the whole of
+// first_push + update_cells_seq (src/impls/ecsim/particles.cpp:21-31, src/interfaces/particles.cpp:79-116)
+int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap)
+{
+  XPIC_HIP(hipMemsetAsync(s.d.cell_count, 0, sizeof(int) * (c->ncell + 1), c->stream));
+  const bool move = step != 0.0;
+  if (s.n > 0) {
+    Timed t(c, "move_bin");
+    const unsigned nb = pgrid(s.n);
+#define LAUNCH(M, W) hipLaunchKernelGGL((k_move_bin<M, W>), dim3(nb), dim3(kBlock), 0, c->stream, c->g, s.d, s.n, step)
+    if (move && wrap) LAUNCH(true, true);
+    else if (move) LAUNCH(true, false);
+    else if (wrap) LAUNCH(false, true);
+    else LAUNCH(false, false);
+#undef LAUNCH
+    XPIC_HIP(hipGetLastError());
+  }
+  int total = 0;
+  {
+    Timed t(c, "scan");
+    XPIC_CALL(exclusive_scan(c, s.d.cell_count, c->ncell, s.d.cell_start, &total));
+  }
+  if (s.n > 0) {
+    Timed t(c, "scatter");
+    const unsigned nb = pgrid(s.n);
+#define LAUNCH(M, W) hipLaunchKernelGGL((k_scatter<M, W>), dim3(nb), dim3(kBlock), 0, c->stream, c->g, s.d, s.n, step)
+    if (move && wrap) LAUNCH(true, true);
+    else if (move) LAUNCH(true, false);
+    else if (wrap) LAUNCH(false, true);
+    else LAUNCH(false, false);
+#undef LAUNCH
+    XPIC_HIP(hipGetLastError());
+  }
+  for (int a = 0; a < 3; ++a) {
+    std::swap(s.d.r[a], s.d.r2[a]);
+    std::swap(s.d.v[a], s.d.v2[a]);
+  }
+  s.n = total;
+  return 0;
+}
+
+int sort_append_host(xpic_ctx* c, Sort& s, int64_t n, const double* pts6, int64_t* added)
+{
+  XPIC_CHECK(s.n + n <= s.cap, "sort capacity exceeded in add_particles");
+  const int64_t before = s.n;
+  if (n > 0) {
+    double* tmp = nullptr;
+    XPIC_HIP(hipMalloc(&tmp, sizeof(double) * 6 * n));
+    XPIC_HIP(hipMemcpyAsync(tmp, pts6, sizeof(double) * 6 * n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_unpack, dim3(pgrid(n)), dim3(kBlock), 0, c->stream, s.d, s.n, n, tmp);
+    XPIC_HIP(hipGetLastError());
+    XPIC_HIP(hipStreamSynchronize(c->stream));
+    XPIC_HIP(hipFree(tmp));
+    s.n += n;
+  }
+  // add_particle never wraps: points outside the box are dropped (particles.cpp:55-56)
+  XPIC_CALL(sort_rebin(c, s, 0.0, false));
+  if (added) *added = s.n - before;
+  return 0;
+}
+
+int sort_download(xpic_ctx* c, Sort& s, double* pts6, int32_t* cell_of_out)
+{
+  if (s.n == 0) return 0;
+  double* tmp = nullptr;
+  int* tc = nullptr;
+  XPIC_HIP(hipMalloc(&tmp, sizeof(double) * 6 * s.n));
+  XPIC_HIP(hipMalloc(&tc, sizeof(int) * s.n));
+  hipLaunchKernelGGL(k_pack, dim3(pgrid(s.n)), dim3(kBlock), 0, c->stream, c->g, s.d, s.n, tmp, tc);
+  XPIC_HIP(hipGetLastError());
+  XPIC_HIP(hipMemcpyAsync(pts6, tmp, sizeof(double) * 6 * s.n, hipMemcpyDeviceToHost, c->stream));
+  if (cell_of_out) XPIC_HIP(hipMemcpyAsync(cell_of_out, tc, sizeof(int) * s.n, hipMemcpyDeviceToHost, c->stream));
+  XPIC_HIP(hipStreamSynchronize(c->stream));
+  XPIC_HIP(hipFree(tmp));
+  XPIC_HIP(hipFree(tc));
+  return 0;
+}
+
+int sort_fill_synthetic(xpic_ctx* c, Sort& s, int ppc, double vth, uint64_t seed)
+{
+  const int64_t n = (int64_t)c->ncell * ppc;
+  XPIC_CHECK(n <= s.cap, "sort capacity exceeded in fill_synthetic");
+  hipLaunchKernelGGL(k_synthetic, dim3(pgrid(n)), dim3(kBlock), 0, c->stream, c->g, s.d, n, ppc, vth, seed);
+  hipLaunchKernelGGL(k_fill_counts, dim3((unsigned)((c->ncell + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
+    s.d.cell_count, s.d.cell_start, (long)c->ncell, ppc);
+  XPIC_HIP(hipGetLastError());
+  s.n = n;
+  return 0;
+}
+
+int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B)
+{
+  if (s.n == 0) return 0;
+  Timed t(c, "second_push");
+  hipLaunchKernelGGL(k_second_push, dim3(pgrid(s.n)), dim3(kBlock), 0, c->stream, c->g, s.d, s.n, E, B, s.par.q / s.par.m);
+  XPIC_HIP(hipGetLastError());
+  return 0;
+}
+
+int kinetic_sums_host(xpic_ctx* c, Sort& s, double* out5)
+{
+  for (int i = 0; i < 5; ++i) out5[i] = 0;
+  out5[4] = (double)s.n;
+  if (s.n == 0) return 0;
+  int nblocks = (int)pgrid(s.n, 8);
+  if (nblocks > kRedBlocks) nblocks = kRedBlocks;
+  hipLaunchKernelGGL(k_kinetic, dim3(nblocks), dim3(kBlock), 0, c->stream, s.d, s.n, c->red_partial, nblocks);
+  hipLaunchKernelGGL(k_sum_rows, dim3(4), dim3(kBlock), 0, c->stream, c->red_partial, nblocks, c->red_out);
+  XPIC_HIP(hipGetLastError());
+  XPIC_HIP(hipMemcpyAsync(c->red_host, c->red_out, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
+  XPIC_HIP(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < 4; ++i) out5[i] = c->red_host[i];
+  return 0;
+}
+
+int sort_move(xpic_ctx* c, Sort& s, double step)
+{
+  if (s.n == 0) return 0;
+  Timed t(c, "move");
+  hipLaunchKernelGGL(k_move, dim3(pgrid(s.n)), dim3(kBlock), 0, c->stream, s.d, s.n, step);
+  XPIC_HIP(hipGetLastError());
+  return 0;
+}
+
+int scale_velocities(xpic_ctx* c, Sort& s, double lambda)
+{
+  if (s.n == 0) return 0;
+  hipLaunchKernelGGL(k_scale_v, dim3(pgrid(s.n)), dim3(kBlock), 0, c->stream, s.d, s.n, lambda);
+  XPIC_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace xpic
