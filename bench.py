@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- xpic hot-path benchmark on MI355X (contract: see the task statement / DESIGN.md section 6).
+
+A "step" is one full ECSIM timestep (first_push + re-bin, current/mass-matrix assembly, implicit field solve,
+second_push, field update) of BASELINE.json's headline configuration: 256^3 cells, 64 particles per cell,
+one electron species, uniform B0 -- all resident in HBM before the timed region.  One process per GPU.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy rate
+
+
+def cpu_baseline(args):
+    """Times the CPU oracle (kind "port": the reference-faithful restatement) on a bounded sample of the same
+    workload on this host's cores: same scheme, same ppc, smaller grid."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+
+    n = args.cpu_grid
+    ppc = args.ppc
+    threads = oracle_lib.default_threads()
+    o = oracle_lib.OracleSim("ecsim", (n, n, n), (args.dx,) * 3, args.dt)
+    s = o.add_sort(ppc, 1.0, -1.0, 1.0)
+    rng = np.random.default_rng(1)
+    npart = ppc * n ** 3
+    pts = np.empty((npart, 6))
+    pts[:, :3] = rng.random((npart, 3)) * (n * args.dx)
+    v = rng.normal(0, args.vth, (npart, 3))
+    pts[:, 3:] = v / np.sqrt(1.0 + (v * v).sum(1, keepdims=True))
+    o.add_particles(s, pts)
+    del pts, v
+    B = np.zeros(o.fshape())
+    B[..., 2] = args.b0
+    o.set_field("B", B)
+    o.set_field("B0", B)
+    o.step()  # warm-up (first touch, allocator)
+    t0 = time.perf_counter()
+    its = 0
+    nsteps = args.cpu_steps
+    for _ in range(nsteps):
+        its += o.step()
+    dt = time.perf_counter() - t0
+    return {
+        "value": npart * nsteps / dt,
+        "unit": "particles/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"oracle ecsim step, {n}^3 cells x {ppc} ppc ({npart} particles), {nsteps} steps, "
+                  f"{its} GMRES(30) iterations, {dt:.1f} s on {threads} OpenMP threads",
+        "ksp_iters_per_s_at_sample_grid": None,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--grid", type=int, default=256)
+    ap.add_argument("--ppc", type=int, default=64)
+    ap.add_argument("--dx", type=float, default=0.5)
+    ap.add_argument("--dt", type=float, default=1.0)
+    ap.add_argument("--vth", type=float, default=0.014)  # T = 0.1 keV electrons (tests/ecsim/ecsim_ex1.cpp:66-70)
+    ap.add_argument("--b0", type=float, default=0.2)
+    ap.add_argument("--cpu-grid", type=int, default=40)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the xpic HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import xpic_amd as X
+
+    n = args.grid
+    N = n ** 3
+    ctx = X.Context("ecsim", (n, n, n), (args.dx,) * 3, args.dt, device=local_rank)
+    npart = args.ppc * N
+    s = ctx.add_sort(args.ppc, 1.0, -1.0, 1.0, capacity=int(npart * 1.02) + 1024)
+    ctx.fill_synthetic(s, args.ppc, args.vth, seed=1234 + rank)
+    import numpy as np
+
+    # SetMagneticField(SetUniformField): B = B0 = (0, 0, b0)
+    B = np.zeros(ctx.fshape())
+    B[..., 2] = args.b0
+    ctx.set_field(X.B, B)
+    ctx.set_field(X.B0, B)
+    del B
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        ctx.step()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    its = 0
+    for _ in range(args.steps):
+        its += ctx.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        it_t = torch.tensor([its], dtype=torch.float64, device="cuda")
+        dist.all_reduce(it_t, op=dist.ReduceOp.SUM)
+        its_total = float(it_t.item())
+    else:
+        its_total = float(its)
+
+    prof = {k: ctx.profile_get(k) for k in ("matA_apply", "solve_matA", "fill_current", "move_bin", "scatter",
+                                            "second_push", "mdot", "maxpy", "matL_zero", "scan", "rot_apply")}
+    n_apply, ms_apply = prof["matA_apply"]
+    n_solve, ms_solve = prof["solve_matA"]
+    # algorithmic bytes of one matA apply: 123 fp64 coefficients per row, 3N rows, + read x + write y
+    bytes_apply = (123 * 3 * 8 + 2 * 24) * N
+    achieved = bytes_apply / (ms_apply / max(n_apply, 1) * 1e-3) / 1e9 if n_apply else 0.0
+    count = ctx.count(s)
+    assert count == npart, "particles were lost in a periodic box"
+
+    line = {
+        "metric": "particles pushed/sec (ECSIM full step) + KSP iters/sec, 256^3 grid 64ppc",
+        "value": world * npart * args.steps / elapsed,
+        "unit": "particles/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"3D ECSIM electromagnetic, {n}^3 cells, {args.ppc} ppc, 1 electron species, "
+                        f"GMRES(30) on matL+matM rtol=atol=1e-7 (BASELINE.json configs[2])",
+            "grid": [n, n, n], "ppc": args.ppc, "particles_per_gpu": npart, "dx": args.dx, "dt": args.dt,
+            "parallelism": "1 GPU" if world == 1 else f"{world} independent replicas (z-slab decomposition not built yet)",
+        },
+        "ksp_iters_per_s": its_total / world / (ms_solve * 1e-3) if ms_solve else None,
+        "ksp_iterations_per_step": its_total / world / args.steps,
+        "phase_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},
+        "roofline": {
+            "kernel": "k_matA (matL+matM SpMV)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "bytes_per_launch": bytes_apply, "launches": n_apply, "avg_ms": ms_apply / max(n_apply, 1),
+        },
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -75,6 +75,7 @@ static int advance_fields(xpic_ctx* c, int op, const double* curr, double* out, 
   XPIC_CALL(rot_apply(c, -1, +c->g.dt, Bm, rhs, true));                           // + dt rotB(B)  :264, :554
   int reason;
   double rn;
+  Timed t(c, op == XPIC_OP_MATA_GMRES ? "solve_matA" : "solve_matM");
   XPIC_CALL(solve(c, op, rhs, out, c->rtol, c->atol, c->maxit, its, &reason, &rn));
   return 0;
 }
