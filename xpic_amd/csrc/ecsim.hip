@@ -1,14 +1,24 @@
 // ecsim.hip -- ecsim::Particles::fill_ecsim_current / decompose_ecsim_current
 // (src/impls/ecsim/particles.cpp:33-173) for cell-sorted SoA particles.
 //
-// One wavefront owns one cell.  All particles of a cell touch the same 3 x 12 Yee nodes, so the cell's
-// contribution to matL is a dense 36 x 36 block  M = sum_p A_p * (s_p s_p^T) o matB_p  (the reference's
-// 1296-entry COO block, :145-163) and its contribution to currI is the 36-vector sum_p s_p o I_p.
-//   phase 1 (lane = particle): CIC weights, B gather, b, I_p, A_p*matB -> LDS, entry-major, padded.
-//   phase 2 (lane = 4 x 6 tile of the block): rank-1 updates out of LDS into 24 register accumulators.
-//   flush: fp64 hardware atomics into the index-free matL rows and the sort's currI.
-#include <cstdlib>
-
+// All particles of a cell touch the same 3 x 12 Yee nodes, so the cell's contribution to matL is a dense
+// 36 x 36 block  M = sum_p A_p * (s_p s_p^T) o matB_p  (the reference's 1296-entry COO block, :145-163)
+// and its contribution to currI is the 36-vector sum_p s_p o I_p.
+//
+// Work decomposition (v2, "pencil march"):
+//   * one workgroup (8 waves) owns one x-pencil of cells (fixed cy, cz) and marches along x in chunks of
+//     8 cells, one cell per wave;
+//   * per cell:  phase 1 (lane = particle)  CIC weights, B gather, b, I_p, A_p*matB -> the wave's LDS stage;
+//                phase 2 (lane = 4 x 6 tile) rank-1 updates out of LDS into 24 register accumulators;
+//   * per chunk: the 8 cell blocks are merged in an LDS window indexed [matL line][x] (a "line" is one
+//     (row component, row y/z offset, k) coefficient stream of the index-free matL), which sums the
+//     duplicates of x-neighbouring cells on chip; finished columns are streamed out with plain,
+//     64-byte-aligned read-modify-write; two unfinished columns are carried to the next chunk;
+//   * pencils whose rows overlap (|dcy| <= 2 and |dcz| <= 2, periodically) never run in the same launch:
+//     launches are coloured by (cy mod 3, cz mod 3) (+ remainder colours), so the RMW needs no atomics and
+//     the result is bitwise reproducible.  MatSetValuesCOO's duplicate summation (simulation.cpp:366) thus
+//     happens in LDS (x) and in launch order (y, z).
+// v1 flushed every cell block with ~1200 scattered fp64 atomics: 85 % of the kernel time at 256^3.
 #include "common.h"
 #include "device_common.h"
 #include "lstencil.h"
@@ -17,177 +27,371 @@ namespace xpic {
 
 namespace {
 
-constexpr int kChunk = 64;       // particles staged per pass = one per lane
-constexpr int kPad = kChunk + 1; // LDS row pitch (conflict-free for lane = particle and lane = entry)
-constexpr int kRows = 48;        // 36 weights + 9 A_p*matB + 3 I_p
+constexpr int kW = 4;             // waves per workgroup = cells per chunk
+constexpr int kCP = 32;           // particles staged per pass and wave
+constexpr int kPadP = kCP + 1;    // LDS row pitch (conflict-free for lane = particle and lane = entry)
+constexpr int kRows = 48;         // 36 weights + 9 A_p*matB + 3 I_p
+constexpr int kStage = kRows * kPadP;
 constexpr int kTileR = 4, kTileC = 6;
 constexpr int kTiles = (36 / kTileR) * (36 / kTileC); // 54 lanes carry a tile
+constexpr int kMatLines = 816;    // distinct (c1, row dy, row dz, k) streams one pencil can touch
+constexpr int kCurLines = 16;     // (c, dy, dz) streams of currI
+constexpr int kLines = kMatLines + kCurLines;
+constexpr int kSlots = kW + 2;    // window columns: 8 finished + 2 carried
+constexpr int kThreads = kW * 64;
 
-__global__ void __launch_bounds__(64) k_ecsim_fill(GridDev g, SortDev s, const double* __restrict__ B,
-  double* __restrict__ currI, double* __restrict__ matL, const int* __restrict__ ltab, double q, double m,
-  double mpw, long ncell, long chunk, int dbg)
+static_assert(kLines * kSlots <= kW * kStage, "the merge window must fit in the (dead) staging area");
+
+__device__ inline void wave_sync()
 {
-  // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of cells so that
-  // the B planes and matL rows it touches stay in its own L2.
-  const long b = blockIdx.x;
-  const long cell = (b % 8) * chunk + b / 8;
-  if (cell >= ncell || b / 8 >= chunk) return;
-  const int start = s.cell_start[cell];
-  const int cnt = s.cell_start[cell + 1] - start;
-  if (cnt == 0) return;
-  const int cx = (int)(cell % g.nx), cy = (int)((cell / g.nx) % g.ny), cz = (int)(cell / g.plane);
+  // the stage of a wave is private to it and a wave's LDS operations complete in order: draining the LDS
+  // counter orders its writes before its reads.  No workgroup barrier, and (unlike a fence) no wait on
+  // the global prefetches in flight.
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
 
-  __shared__ double sh[kRows * kPad];
-  const int lane = threadIdx.x;
+// raw workgroup barrier that only drains LDS traffic: global prefetches stay in flight across it
+__device__ inline void lds_barrier()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+struct Prefetch {
+  int start, cnt;  // cell_start of the cell this wave handles next
+  double p[6];     // x, y, z, vx, vy, vz of lane's particle of the next pass
+  double b;        // lane's value of the next cell's 54-value B neighbourhood
+};
+
+// B neighbourhood of cell (cx,cy,cz) = every B value a CIC gather from inside that cell can touch:
+//   Bx at (xn in cx..cx+1, ys in cy-1..cy+1, zs in cz-1..cz+1)   -> [ 0,18): (kl*3 + jl)*2 + i
+//   By at (xs in cx-1..cx+1, yn in cy..cy+1, zs in cz-1..cz+1)   -> [18,36): (kl*2 + j)*3 + il
+//   Bz at (xs in cx-1..cx+1, ys in cy-1..cy+1, zn in cz..cz+1)   -> [36,54): (k*3 + jl)*3 + il
+__device__ inline double load_bnb(const GridDev& g, const double* __restrict__ B, int lane, int cx, int cy, int cz)
+{
+  if (lane >= 54) return 0.0;
+  int c, ox, oy, oz;
+  if (lane < 18) { c = 0; ox = lane % 2; oy = (lane / 2) % 3 - 1; oz = lane / 6 - 1; }
+  else if (lane < 36) { const int l = lane - 18; c = 1; ox = l % 3 - 1; oy = (l / 3) % 2; oz = l / 6 - 1; }
+  else { const int l = lane - 36; c = 2; ox = l % 3 - 1; oy = (l / 3) % 3 - 1; oz = l / 9; }
+  return B[c * g.cstride + g.nodew(cx + ox, cy + oy, cz + oz)];
+}
+
+__global__ void __launch_bounds__(kThreads) k_ecsim_fill(GridDev g, SortDev s, const double* __restrict__ B,
+  double* currI, double* matL, const int* __restrict__ etab, const int* __restrict__ linetab, double q, double m,
+  double mpw, int cy0, int cystep, int ncy, int cz0, int czstep)
+{
+  const int cy = cy0 + (int)(blockIdx.x % ncy) * cystep;
+  const int cz = cz0 + (int)(blockIdx.x / ncy) * czstep;
+
+  __shared__ double sh[kW * kStage];
+  __shared__ double carry[kLines * 2];
+  __shared__ double* lbase[kLines];
+  __shared__ double bnb[kW][54];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double* st = sh + wave * kStage;
   const int rt = lane / 6, ct = lane % 6; // tile (rows 4rt.., cols 6ct..) for lane < 54
   const int c1 = rt / 3, c2 = ct / 2;
   const bool has_tile = lane < kTiles;
+  const double dt = g.dt;
 
-  double acc[kTileR][kTileC];
+  // per-lane flush descriptors: (line, row x offset) of the 24 tile entries, constant over the march
+  int edesc[kTileR][kTileC];
 #pragma unroll
   for (int a = 0; a < kTileR; ++a)
 #pragma unroll
-    for (int bb = 0; bb < kTileC; ++bb) acc[a][bb] = 0.0;
-  double accI = 0.0;
-
-  const double dt = g.dt;
-
-  for (int base = 0; base < cnt; base += kChunk) {
-    const int mcnt = min(kChunk, cnt - base);
-    __syncthreads();
-    if (lane < mcnt) {
-      const long p = (long)start + base + lane;
-      const double x = s.r[0][p], y = s.r[1][p], z = s.r[2][p];
-      const double v[3] = {s.v[0][p], s.v[1][p], s.v[2][p]};
-      const W1 w(g, x, y, z);
-      double Ed[3], Bp[3];
-      gather_s1(g, nullptr, B, w, Ed, Bp);
-      // particles.cpp:107-115
-      const double f = (0.5 * dt) * q / m;
-      const double bx = Bp[0] * f, by = Bp[1] * f, bz = Bp[2] * f;
-      const double b2 = bx * bx + by * by + bz * bz;
-      const double vb = v[0] * bx + v[1] * by + v[2] * bz;
-      const double cxv = +(v[1] * bz - v[2] * by), cyv = -(v[0] * bz - v[2] * bx), czv = +(v[0] * by - v[1] * bx);
-      const double iq = q * mpw / (1. + b2);
-      const double Ip[3] = {iq * (v[0] + cxv + vb * bx), iq * (v[1] + cyv + vb * by), iq * (v[2] + czv + vb * bz)};
-      const double A_p = 0.5 * dt * dt * mpw * q * q / m / (1 + b2);
-      const double AB[9] = {
-        A_p * (1.0 + bx * bx), A_p * (+bz + bx * by), A_p * (-by + bx * bz),
-        A_p * (-bz + by * bx), A_p * (1.0 + by * by), A_p * (+bx + by * bz),
-        A_p * (+by + bz * bx), A_p * (-bx + bz * by), A_p * (1.0 + bz * bz)};
-      // staggered-axis weights spread over the cell's 3 node slots (slot = node - cell + 1), :87-89
-      double w3[3][3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const int o = w.is[a] - w.in[a] + 1; // ox, oy, oz in {0, 1}
-        w3[a][0] = o == 0 ? w.ws[a][0] : 0.0;
-        w3[a][1] = o == 0 ? w.ws[a][1] : w.ws[a][0];
-        w3[a][2] = o == 0 ? 0.0 : w.ws[a][1];
-      }
-      double* col = sh + lane;
-      // X rows: (k*2 + j)*3 + l ; s = wnz[k]*wny[j]*wsx[.]   (:138, :145)
-#pragma unroll
-      for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int l = 0; l < 3; ++l) col[((k * 2 + j) * 3 + l) * kPad] = w.wn[2][k] * w.wn[1][j] * w3[0][l];
-      // Y rows: 12 + (k*3 + l)*2 + i ; s = wnz[k]*wsy[.]*wnx[i]   (:139, :146)
-#pragma unroll
-      for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int l = 0; l < 3; ++l)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) col[(12 + (k * 3 + l) * 2 + i) * kPad] = w.wn[2][k] * w3[1][l] * w.wn[0][i];
-      // Z rows: 24 + (l*2 + j)*2 + i ; s = wsz[.]*wny[j]*wnx[i]   (:140, :147)
-#pragma unroll
-      for (int l = 0; l < 3; ++l)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) col[(24 + (l * 2 + j) * 2 + i) * kPad] = w3[2][l] * w.wn[1][j] * w.wn[0][i];
-#pragma unroll
-      for (int e = 0; e < 9; ++e) col[(36 + e) * kPad] = AB[e];
-#pragma unroll
-      for (int e = 0; e < 3; ++e) col[(45 + e) * kPad] = Ip[e];
-    }
-    __syncthreads();
-
-    if (has_tile && !(dbg & 2)) {
-      const double* rp = sh + (kTileR * rt) * kPad;
-      const double* cp = sh + (kTileC * ct) * kPad;
-      const double* ap = sh + (36 + c1 * 3 + c2) * kPad;
-      for (int p = 0; p < mcnt; ++p) {
-        const double ab = ap[p];
-        double r[kTileR], cc[kTileC];
-#pragma unroll
-        for (int a = 0; a < kTileR; ++a) r[a] = rp[a * kPad + p] * ab;
-#pragma unroll
-        for (int bb = 0; bb < kTileC; ++bb) cc[bb] = cp[bb * kPad + p];
-#pragma unroll
-        for (int a = 0; a < kTileR; ++a)
-#pragma unroll
-          for (int bb = 0; bb < kTileC; ++bb) acc[a][bb] += r[a] * cc[bb];
-      }
-    }
-    if (lane < 36) {
-      const double* sp = sh + lane * kPad;
-      const double* ip = sh + (45 + lane / 12) * kPad;
-      for (int p = 0; p < mcnt; ++p) accI += sp[p] * ip[p];
-    }
-  }
-
-  // ---- flush the cell block: MatSetValuesCOO's duplicate summation (simulation.cpp:366) as fp64 atomics
-  if (dbg & 1) { // timing experiments only: keep the accumulators alive without the atomics
-    double t = accI;
-    for (int a = 0; a < kTileR; ++a) for (int bb = 0; bb < kTileC; ++bb) t += acc[a][bb];
-    if (t == 1.2345e300) currI[0] = t;
-    return;
-  }
-  if (has_tile) {
-#pragma unroll
-    for (int a = 0; a < kTileR; ++a)
-#pragma unroll
-      for (int bb = 0; bb < kTileC; ++bb) {
-        const int i36 = kTileR * rt + a, j36 = kTileC * ct + bb;
-        const int desc = ltab[i36 * 36 + j36];
-        const int k = desc & 0xff;
-        if (k == 0xff) continue; // |d| = 2 same-component pair: structurally zero
-        const int rx = g.wx(cx + ((desc >> 10) & 3) - 1);
-        const int ry = g.wy(cy + ((desc >> 12) & 3) - 1);
-        const int rz = cz + ((desc >> 14) & 3) - 1;
-        const int rzw = rz < 0 ? rz + g.nzl : (rz >= g.nzl ? rz - g.nzl : rz);
-        const long addr = ((((long)c1 * g.nzl + rzw) * g.ny + ry) * kLStencil + k) * g.nx + rx;
-        unsafeAtomicAdd(&matL[addr], acc[a][bb]);
-      }
-  }
+    for (int bb = 0; bb < kTileC; ++bb)
+      edesc[a][bb] = has_tile ? etab[(kTileR * rt + a) * 36 + kTileC * ct + bb] : -1;
+  int cdesc = -1; // currI: lanes < 36
   if (lane < 36) {
     const int c = lane / 12;
     int o[3];
     block_node_offset(c, lane % 12, o);
-    unsafeAtomicAdd(&currI[c * g.cstride + g.nodew(cx + o[0], cy + o[1], cz + o[2])], accI);
+    const int id = c == 0 ? o[2] * 2 + o[1] : (c == 1 ? 4 + o[2] * 3 + (o[1] + 1) : 10 + (o[2] + 1) * 2 + o[1]);
+    cdesc = ((kMatLines + id) << 2) | (o[0] + 1);
+  }
+  // the currI row of lanes < 36 rides in the tile loop: row `lane` times I_p[lane / 12]
+  const int irow = lane < 36 ? lane : 0, icol = 45 + (lane < 36 ? lane / 12 : 0);
+
+  for (int i = threadIdx.x; i < kLines * 2; i += kThreads) carry[i] = 0.0;
+  // address of column 0 of every line of this pencil
+  for (int line = threadIdx.x; line < kLines; line += kThreads) {
+    const int ld = linetab[line];
+    const int ry = g.wy(cy + ((ld >> 2) & 3) - 1);
+    const int rz = cz + ((ld >> 4) & 3) - 1;
+    const int rzw = rz < 0 ? rz + g.nzl : (rz >= g.nzl ? rz - g.nzl : rz);
+    lbase[line] = line < kMatLines
+      ? matL + ((((long)(ld & 3) * g.nzl + rzw) * g.ny + ry) * kLStencil + (ld >> 6)) * g.nx
+      : currI + (ld & 3) * g.cstride + g.node(0, ry, g.wz(rz));
+  }
+
+  // cells are visited in the order 1, 2, ..., nx-1, 0 so that finished columns start 64-byte aligned
+  auto cell_x = [&](int i) { return (i + 1 == g.nx) ? 0 : i + 1; };
+  auto prefetch_cell = [&](int i, Prefetch& pf) {
+    pf.start = 0; pf.cnt = 0; pf.b = 0.0;
+    if (i >= g.nx) return;
+    const int cx = cell_x(i);
+    const long cell = ((long)cz * g.ny + cy) * g.nx + cx;
+    pf.start = __builtin_amdgcn_readfirstlane(s.cell_start[cell]);
+    pf.cnt = __builtin_amdgcn_readfirstlane(s.cell_start[cell + 1]) - pf.start;
+    pf.b = load_bnb(g, B, lane, cx, cy, cz);
+    if (lane < min(kCP, pf.cnt)) {
+      const long p = (long)pf.start + lane;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { pf.p[a] = s.r[a][p]; pf.p[3 + a] = s.v[a][p]; }
+    }
+  };
+
+  Prefetch pf;
+  prefetch_cell(wave, pf);
+
+  const int nch = (g.nx + kW - 1) / kW;
+  for (int j = 0; j < nch; ++j) {
+    const int i = j * kW + wave;
+    const bool active = i < g.nx;
+
+    double acc[kTileR][kTileC];
+#pragma unroll
+    for (int a = 0; a < kTileR; ++a)
+#pragma unroll
+      for (int bb = 0; bb < kTileC; ++bb) acc[a][bb] = 0.0;
+    double accI = 0.0;
+
+    if (active) {
+      const int start = pf.start, cnt = pf.cnt;
+      if (lane < 54) bnb[wave][lane] = pf.b;
+      double cur[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) cur[a] = pf.p[a];
+      for (int base = 0; base < cnt; base += kCP) {
+        const int mcnt = min(kCP, cnt - base);
+        // next pass of this cell: loads in flight during this pass's phase 1 and 2
+        double nxt[6] = {0, 0, 0, 0, 0, 0};
+        if (base + kCP + lane < cnt) {
+          const long p = (long)start + base + kCP + lane;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) { nxt[a] = s.r[a][p]; nxt[3 + a] = s.v[a][p]; }
+        }
+        wave_sync();
+        if (lane < mcnt) {
+          const double v[3] = {cur[3], cur[4], cur[5]};
+          const W1 w(g, cur[0], cur[1], cur[2]);
+          // interpolate_B_s1 (ecsim/simulation.cpp:64-118) out of the cell's LDS neighbourhood, same loop
+          // and product order as the global-memory gather
+          const int ox = w.is[0] - w.in[0] + 1, oy = w.is[1] - w.in[1] + 1, oz = w.is[2] - w.in[2] + 1;
+          double Bp[3] = {0.0, 0.0, 0.0};
+          const double* nb = bnb[wave];
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+              for (int ii = 0; ii < 2; ++ii) {
+                Bp[0] += nb[((oz + k) * 3 + (oy + jj)) * 2 + ii] * (w.ws[2][k] * w.ws[1][jj] * w.wn[0][ii]);
+                Bp[1] += nb[18 + ((oz + k) * 2 + jj) * 3 + (ox + ii)] * (w.ws[2][k] * w.wn[1][jj] * w.ws[0][ii]);
+                Bp[2] += nb[36 + (k * 3 + (oy + jj)) * 3 + (ox + ii)] * (w.wn[2][k] * w.ws[1][jj] * w.ws[0][ii]);
+              }
+          // particles.cpp:107-115
+          const double f = (0.5 * dt) * q / m;
+          const double bx = Bp[0] * f, by = Bp[1] * f, bz = Bp[2] * f;
+          const double b2 = bx * bx + by * by + bz * bz;
+          const double vb = v[0] * bx + v[1] * by + v[2] * bz;
+          const double cxv = +(v[1] * bz - v[2] * by), cyv = -(v[0] * bz - v[2] * bx), czv = +(v[0] * by - v[1] * bx);
+          const double iq = q * mpw / (1. + b2);
+          const double Ip[3] = {iq * (v[0] + cxv + vb * bx), iq * (v[1] + cyv + vb * by), iq * (v[2] + czv + vb * bz)};
+          const double A_p = 0.5 * dt * dt * mpw * q * q / m / (1 + b2);
+          const double AB[9] = {
+            A_p * (1.0 + bx * bx), A_p * (+bz + bx * by), A_p * (-by + bx * bz),
+            A_p * (-bz + by * bx), A_p * (1.0 + by * by), A_p * (+bx + by * bz),
+            A_p * (+by + bz * bx), A_p * (-bx + bz * by), A_p * (1.0 + bz * bz)};
+          // staggered-axis weights spread over the cell's 3 node slots (slot = node - cell + 1), :87-89
+          double w3[3][3];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            const int o = w.is[a] - w.in[a] + 1; // ox, oy, oz in {0, 1}
+            w3[a][0] = o == 0 ? w.ws[a][0] : 0.0;
+            w3[a][1] = o == 0 ? w.ws[a][1] : w.ws[a][0];
+            w3[a][2] = o == 0 ? 0.0 : w.ws[a][1];
+          }
+          double* col = st + lane;
+          // X rows: (k*2 + j)*3 + l ; s = wnz[k]*wny[j]*wsx[.]   (:138, :145)
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+              for (int l = 0; l < 3; ++l) col[((k * 2 + jj) * 3 + l) * kPadP] = w.wn[2][k] * w.wn[1][jj] * w3[0][l];
+          // Y rows: 12 + (k*3 + l)*2 + i ; s = wnz[k]*wsy[.]*wnx[i]   (:139, :146)
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+#pragma unroll
+              for (int ii = 0; ii < 2; ++ii) col[(12 + (k * 3 + l) * 2 + ii) * kPadP] = w.wn[2][k] * w3[1][l] * w.wn[0][ii];
+          // Z rows: 24 + (l*2 + j)*2 + i ; s = wsz[.]*wny[j]*wnx[i]   (:140, :147)
+#pragma unroll
+          for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+              for (int ii = 0; ii < 2; ++ii) col[(24 + (l * 2 + jj) * 2 + ii) * kPadP] = w3[2][l] * w.wn[1][jj] * w.wn[0][ii];
+#pragma unroll
+          for (int e = 0; e < 9; ++e) col[(36 + e) * kPadP] = AB[e];
+#pragma unroll
+          for (int e = 0; e < 3; ++e) col[(45 + e) * kPadP] = Ip[e];
+        }
+        wave_sync();
+
+        if (has_tile) {
+          // rank-1 updates, software pipelined by hand: the 13 LDS operands of particle p+1 are requested
+          // before the 28 FMAs of particle p (column mcnt <= 32 is the pad column: harmless to read)
+          const double* rp = st + (kTileR * rt) * kPadP;
+          const double* cp = st + (kTileC * ct) * kPadP;
+          const double* ap = st + (36 + c1 * 3 + c2) * kPadP;
+          const double* sp = st + irow * kPadP;
+          const double* ip = st + icol * kPadP;
+          double r[kTileR], cc[kTileC], ab, si, ii_;
+          ab = ap[0];
+#pragma unroll
+          for (int a = 0; a < kTileR; ++a) r[a] = rp[a * kPadP];
+#pragma unroll
+          for (int bb = 0; bb < kTileC; ++bb) cc[bb] = cp[bb * kPadP];
+          si = sp[0];
+          ii_ = ip[0];
+#pragma unroll 2
+          for (int p = 0; p < mcnt; ++p) {
+            double rn[kTileR], cn[kTileC];
+            const double abn = ap[p + 1];
+#pragma unroll
+            for (int a = 0; a < kTileR; ++a) rn[a] = rp[a * kPadP + p + 1];
+#pragma unroll
+            for (int bb = 0; bb < kTileC; ++bb) cn[bb] = cp[bb * kPadP + p + 1];
+            const double sin_ = sp[p + 1], iin = ip[p + 1];
+#pragma unroll
+            for (int a = 0; a < kTileR; ++a) {
+              const double ra = r[a] * ab;
+#pragma unroll
+              for (int bb = 0; bb < kTileC; ++bb) acc[a][bb] += ra * cc[bb];
+            }
+            accI += si * ii_;
+            ab = abn; si = sin_; ii_ = iin;
+#pragma unroll
+            for (int a = 0; a < kTileR; ++a) r[a] = rn[a];
+#pragma unroll
+            for (int bb = 0; bb < kTileC; ++bb) cc[bb] = cn[bb];
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) cur[a] = nxt[a];
+      }
+    }
+
+    // next chunk's cell: particle data and B neighbourhood travel while this chunk is merged and flushed
+    prefetch_cell(i + kW, pf);
+
+    // ---- merge the chunk's cell blocks in the window (aliased over the now dead stages)
+    lds_barrier();
+    double* win = sh; // [kLines][kSlots]
+    for (int t = threadIdx.x; t < kLines * kSlots; t += kThreads) {
+      const int line = t / kSlots, slot = t % kSlots;
+      win[t] = slot < 2 ? carry[line * 2 + slot] : 0.0;
+    }
+    lds_barrier();
+    if (active) {
+      // row node x of cell (unwrapped) u = i+1 with offset o is column u+o; window column 0 is kW*j
+#pragma unroll
+      for (int a = 0; a < kTileR; ++a)
+#pragma unroll
+        for (int bb = 0; bb < kTileC; ++bb) {
+          const int d = edesc[a][bb];
+          if (d >= 0) unsafeAtomicAdd(&win[(d >> 2) * kSlots + wave + (d & 3)], acc[a][bb]);
+        }
+      if (cdesc >= 0) unsafeAtomicAdd(&win[(cdesc >> 2) * kSlots + wave + (cdesc & 3)], accI);
+    }
+    lds_barrier();
+    // ---- stream out the finished columns (plain RMW, kW consecutive doubles per line), keep 2 in carry.
+    // All loads of a thread's items are issued before the first store, so one HBM latency is exposed per
+    // chunk instead of one per item.
+    const int ndone = min(kW, g.nx - j * kW);
+    {
+      constexpr int kItems = (kLines * kW + kThreads - 1) / kThreads;
+      const int slot = threadIdx.x % kW, line0 = threadIdx.x / kW;
+      double val[kItems], old[kItems];
+      double* ptr[kItems];
+#pragma unroll
+      for (int mm = 0; mm < kItems; ++mm) {
+        const int line = line0 + mm * (kThreads / kW);
+        const bool ok = line < kLines && slot < ndone;
+        val[mm] = ok ? win[line * kSlots + slot] : 0.0;
+        ptr[mm] = ok ? lbase[line] + (j * kW + slot) : nullptr;
+      }
+#pragma unroll
+      for (int mm = 0; mm < kItems; ++mm) old[mm] = val[mm] != 0.0 ? *ptr[mm] : 0.0;
+#pragma unroll
+      for (int mm = 0; mm < kItems; ++mm)
+        if (val[mm] != 0.0) *ptr[mm] = old[mm] + val[mm];
+    }
+    for (int t = threadIdx.x; t < kLines * 2; t += kThreads) carry[t] = win[(t >> 1) * kSlots + ndone + (t & 1)];
+    lds_barrier();
+  }
+
+  // ---- the two columns still carried are x = nx, nx+1 = 0, 1 (periodic): columns this workgroup has
+  // already written, so they are added with atomics (2 of nx columns)
+  __syncthreads();
+  for (int t = threadIdx.x; t < kLines * 2; t += kThreads) {
+    const double val = carry[t];
+    if (val != 0.0) unsafeAtomicAdd(lbase[t >> 1] + g.wx(t & 1), val);
   }
 }
 
 }  // namespace
 
-// table: (row i36, col j36) of the cell block -> k of the row stencil + row node offset.  The (row, col)
-// node pairs are those of ecsim::Simulation::fill_matrix_indices (src/impls/ecsim/simulation.cpp:408-464).
+// Tables.  The (row, col) node pairs of the cell block are those of
+// ecsim::Simulation::fill_matrix_indices (src/impls/ecsim/simulation.cpp:408-464).
+//   etab[i36*36 + j36] = (line << 2) | (row x offset + 1), or -1 for a structural zero (|d| = 2, same comp.)
+//   linetab[line]      = c | (row dy + 1) << 2 | (row dz + 1) << 4 | k << 6
 int build_ltab(xpic_ctx* c)
 {
-  std::vector<int> tab(36 * 36);
+  std::vector<int> etab(36 * 36, -1), linetab(kLines, 0);
+  std::map<int, int> line_of;
   for (int i = 0; i < 36; ++i)
     for (int j = 0; j < 36; ++j) {
       int c1 = i / 12, c2 = j / 12, o1[3], o2[3];
       block_node_offset(c1, i % 12, o1);
       block_node_offset(c2, j % 12, o2);
       int k = lencode(c1, c2, o2[0] - o1[0], o2[1] - o1[1], o2[2] - o1[2]);
-      int desc = (k < 0 ? 0xff : k) | (c1 << 8) | ((o1[0] + 1) << 10) | ((o1[1] + 1) << 12) | ((o1[2] + 1) << 14);
-      tab[i * 36 + j] = desc;
+      if (k < 0) continue;
+      int key = c1 | ((o1[1] + 1) << 2) | ((o1[2] + 1) << 4) | (k << 6);
+      auto it = line_of.find(key);
+      if (it == line_of.end()) {
+        int id = (int)line_of.size();
+        XPIC_CHECK(id < kMatLines, "matL line table overflow");
+        it = line_of.emplace(key, id).first;
+        linetab[id] = key;
+      }
+      etab[i * 36 + j] = (it->second << 2) | (o1[0] + 1);
     }
-  XPIC_HIP(hipMalloc(&c->ltab, sizeof(int) * tab.size()));
-  XPIC_HIP(hipMemcpy(c->ltab, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
+  XPIC_CHECK((int)line_of.size() == kMatLines, "unexpected number of matL lines per pencil");
+  for (int cidx = 0; cidx < 3; ++cidx)
+    for (int l = 0; l < 12; ++l) {
+      int o[3];
+      block_node_offset(cidx, l, o);
+      int id = cidx == 0 ? o[2] * 2 + o[1] : (cidx == 1 ? 4 + o[2] * 3 + (o[1] + 1) : 10 + (o[2] + 1) * 2 + o[1]);
+      linetab[kMatLines + id] = cidx | ((o[1] + 1) << 2) | ((o[2] + 1) << 4);
+    }
+  XPIC_HIP(hipMalloc(&c->ltab, sizeof(int) * (etab.size() + linetab.size())));
+  XPIC_HIP(hipMemcpy(c->ltab, etab.data(), sizeof(int) * etab.size(), hipMemcpyHostToDevice));
+  XPIC_HIP(hipMemcpy(c->ltab + etab.size(), linetab.data(), sizeof(int) * linetab.size(), hipMemcpyHostToDevice));
   return 0;
+}
+
+// colour classes of one periodic axis: 0,1,2 = residues mod 3 over the first 3*floor(n/3) indices,
+// 3.. = the n mod 3 trailing indices one by one.  Same-colour indices are >= 3 apart periodically.
+static void colour_class(int n, int colour, int* first, int* step, int* count)
+{
+  const int body = n - n % 3;
+  if (colour < 3) { *first = colour; *step = 3; *count = body / 3; }
+  else { *first = body + (colour - 3); *step = 1; *count = 1; }
 }
 
 int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, double* matL)
@@ -195,12 +399,18 @@ int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, d
   if (s.n == 0) return 0;
   XPIC_CHECK(c->g.G == 0, "ecsim_fill: ghost-row exchange for nranks > 1 is not built yet");
   Timed t(c, "fill_current");
-  const long chunk = (c->ncell + 7) / 8;
-  const long nblocks = chunk * 8;
-  static const int dbg = getenv("XPIC_FILL_DBG") ? atoi(getenv("XPIC_FILL_DBG")) : 0;
-  XPIC_CHECK(nblocks < 2147483647L, "too many cells for one launch");
-  hipLaunchKernelGGL(k_ecsim_fill, dim3((unsigned)nblocks), dim3(64), 0, c->stream, c->g, s.d, B, currI_sort, matL,
-    c->ltab, s.par.q, s.par.m, s.par.n / (double)s.par.Np, (long)c->ncell, chunk, dbg);
+  const GridDev& g = c->g;
+  const int ncol_y = 3 + g.ny % 3, ncol_z = 3 + g.nzl % 3;
+  for (int b = 0; b < ncol_z; ++b)
+    for (int a = 0; a < ncol_y; ++a) {
+      int cy0, cys, ncy, cz0, czs, ncz;
+      colour_class(g.ny, a, &cy0, &cys, &ncy);
+      colour_class(g.nzl, b, &cz0, &czs, &ncz);
+      if (ncy == 0 || ncz == 0) continue;
+      hipLaunchKernelGGL(k_ecsim_fill, dim3((unsigned)(ncy * ncz)), dim3(kThreads), 0, c->stream, g, s.d, B,
+        currI_sort, matL, c->ltab, c->ltab + 36 * 36, s.par.q, s.par.m, s.par.n / (double)s.par.Np, cy0, cys, ncy,
+        cz0, czs);
+    }
   XPIC_HIP(hipGetLastError());
   return 0;
 }

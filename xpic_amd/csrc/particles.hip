@@ -22,7 +22,7 @@ template <bool MOVE, bool WRAP>
 __global__ void __launch_bounds__(kBlock) k_move_bin(GridDev g, SortDev s, int64_t n, double step)
 {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (p >= n) return;
+  if (p >= n) return; // whole trailing lanes drop out together: ballots below only see live lanes
   double x = s.r[0][p], y = s.r[1][p], z = s.r[2][p];
   if (MOVE) {
     x += s.v[0][p] * step;
@@ -36,7 +36,22 @@ __global__ void __launch_bounds__(kBlock) k_move_bin(GridDev g, SortDev s, int64
   }
   const int c = cell_of(g, x, y, z);
   s.cell[p] = c;
-  s.rank[p] = c >= 0 ? atomicAdd(&s.cell_count[c], 1) : 0;
+  // Arrival rank inside the new cell.  The input is (nearly) cell-sorted, so a wave sees a handful of distinct
+  // cells: one returning atomic per distinct cell and wave instead of one per particle.
+  int rank = 0;
+  unsigned long long todo = __ballot(c >= 0);
+  const int lane = threadIdx.x & 63;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int lc = __shfl(c, leader, 64);
+    const unsigned long long same = __ballot(c == lc) & todo;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&s.cell_count[lc], __popcll(same));
+    base = __shfl(base, leader, 64);
+    if (c == lc) rank = base + __popcll(same & ((1ull << lane) - 1ull));
+    todo &= ~same;
+  }
+  s.rank[p] = rank;
 }
 
 // pass 2: recompute the moved + wrapped position (bitwise the same arithmetic) and scatter the record
