@@ -1,6 +1,8 @@
 // fields.hip -- grid-side kernels: BLAS-1 (K14), curl (K11), matM (K12), matL / matA SpMV (K13),
 // layout conversion at the boundary, two-stage reductions.  All HBM-bound; see DESIGN.md for the
 // algorithmic byte counts each kernel is measured against.
+#include <utility>
+
 #include "common.h"
 #include "lstencil.h"
 
@@ -244,46 +246,109 @@ __global__ void __launch_bounds__(kBlock) k_matM(GridDev g, const double* F, dou
 }
 
 // ---- matL / matA SpMV ---------------------------------------------------------------------------
-// matL[c1][z][y][k][x]: one workgroup owns the x-row of one (c1, y, z); lane = x.  The 123 coefficient
-// streams of the row are contiguous (123*nx doubles), every load is a full coalesced wave line; the
-// operand vector comes out of L1/L2 (each element is re-used by 123 rows).
-template <int C1, bool WITH_M>
-__device__ inline double row_apply(const GridDev& g, const double* __restrict__ L, const double* __restrict__ X,
-  int x, int y, int z)
+// matL[c1][z][y][k][x]: one thread per row (c1, node), lane = x, so each of the 123 coefficient streams of a
+// wave is one contiguous 512-byte line; the operand vector comes out of L1/L2 (every element is used by 123
+// rows).  The stencil (c2, dx, dy, dz) of every k is a compile-time constant: the term list is expanded with
+// an integer_sequence so that all address arithmetic folds into immediates and wave-uniform row bases.
+struct RowCtx {
+  const char* Lb;    // wave-uniform: first coefficient of the row block (c1, z, y), x = 0
+  const char* Xb;    // operand vector
+  unsigned x8;       // lane: 8 * x
+  unsigned xs8[5];   // lane: 8 * wrap(x + d), d = -2..2
+  unsigned nx8;      // 8 * nx
+  unsigned crow[3];  // wave-uniform byte offsets: component c2,
+  unsigned yrow[5];  //   row wrap(y + d),
+  unsigned zrow[5];  //   plane wrap(z + d)          (a field vector is < 4 GiB by construction)
+};
+
+template <int C1, int K>
+__device__ __forceinline__ void lterm(double (&acc)[2], const RowCtx& r)
 {
-  const double* Lrow = L + ((((long)C1 * g.nzl + z) * g.ny + y) * kLStencil) * g.nx + x;
-  int xs[5];
-#pragma unroll
-  for (int d = -2; d <= 2; ++d) xs[d + 2] = g.wx(x + d);
-  double acc = 0.0;
-#pragma unroll
-  for (int k = 0; k < kLStencil; ++k) {
-    const LEntry e = ldecode(C1, k);
-    const long rowbase = e.c2 * g.cstride + ((long)g.wz(z + e.d[2]) * g.ny + g.wy(y + e.d[1])) * g.nx;
-    acc += Lrow[(long)k * g.nx] * X[rowbase + xs[e.d[0] + 2]];
-  }
-  (void)WITH_M;
-  return acc;
+  constexpr LEntry e = ldecode(C1, K);
+  const unsigned srow = r.crow[e.c2] + r.zrow[e.d[2] + 2] + r.yrow[e.d[1] + 2]; // scalar
+  const double xv = *reinterpret_cast<const double*>(r.Xb + (size_t)(srow + r.xs8[e.d[0] + 2]));
+  const double lv = *reinterpret_cast<const double*>(r.Lb + (size_t)K * r.nx8 + r.x8);
+  acc[K & 1] += lv * xv;
 }
 
-template <bool WITH_L, bool WITH_M>
-__global__ void __launch_bounds__(kBlock) k_matA(GridDev g, const double* __restrict__ L, const double* __restrict__ X,
-  double* __restrict__ Y, int add)
+template <int C1, int... Ks>
+__device__ __forceinline__ double row_apply(std::integer_sequence<int, Ks...>, const GridDev& g,
+  const double* __restrict__ L, const double* __restrict__ X, int x, int y, int z)
 {
-  // grid: x = x-chunks, y = ny, z = nzl ; each workgroup does the three components of its nodes
-  const int x = blockIdx.x * kBlock + threadIdx.x;
-  const int y = blockIdx.y, z = blockIdx.z;
-  if (x >= g.nx) return;
-  double r0 = 0, r1 = 0, r2 = 0;
-  if (WITH_M) matM_at(g, X, x, y, z, r0, r1, r2);
-  if (WITH_L) {
-    r0 += row_apply<0, WITH_M>(g, L, X, x, y, z);
-    r1 += row_apply<1, WITH_M>(g, L, X, x, y, z);
-    r2 += row_apply<2, WITH_M>(g, L, X, x, y, z);
+  RowCtx r;
+  r.Lb = reinterpret_cast<const char*>(L + ((((long)C1 * g.nzl + z) * g.ny + y) * kLStencil) * g.nx);
+  r.Xb = reinterpret_cast<const char*>(X);
+  r.x8 = 8u * (unsigned)x;
+  r.nx8 = 8u * (unsigned)g.nx;
+#pragma unroll
+  for (int d = -2; d <= 2; ++d) {
+    r.xs8[d + 2] = 8u * (unsigned)g.wx(x + d);
+    // every extent is >= 4 > |d|: one fold is enough
+    r.yrow[d + 2] = 8u * (unsigned)(g.wy(y + d) * g.nx);
+    r.zrow[d + 2] = 8u * (unsigned)((long)g.wz(z + d) * g.plane);
   }
-  const long o = g.node(x, y, g.wz(z));
-  if (add) { Y[o] += r0; Y[o + g.cstride] += r1; Y[o + 2 * g.cstride] += r2; }
-  else { Y[o] = r0; Y[o + g.cstride] = r1; Y[o + 2 * g.cstride] = r2; }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) r.crow[c] = 8u * (unsigned)(c * g.cstride);
+  double acc[2] = {0.0, 0.0};
+  (lterm<C1, Ks>(acc, r), ...);
+  return acc[0] + acc[1];
+}
+
+// one component of matM x = 2 x + 0.5 dt^2 rot(-) rot(+) x, written for component C with the cyclic
+// axes A = C+1, B = C+2:  (rot- G)_C = d-_A G_B - d-_B G_A,  G_B = d+_C F_A - d+_A F_C,  G_A = d+_B F_C - d+_C F_B
+template <int C>
+__device__ __forceinline__ double matM_comp(const GridDev& g, const double* __restrict__ F, int x, int y, int z)
+{
+  constexpr int A = (C + 1) % 3, B = (C + 2) % 3;
+  const double ih[3] = {1.0 / g.dx, 1.0 / g.dy, 1.0 / g.dz};
+  auto at = [&](int comp, int ox, int oy, int oz) { return F[comp * g.cstride + g.nodew(x + ox, y + oy, z + oz)]; };
+  auto sh = [&](int axis, int s, int& ox, int& oy, int& oz) { (axis == 0 ? ox : (axis == 1 ? oy : oz)) += s; };
+  // G_comp at offset (ox,oy,oz): forward differences
+  auto dplus = [&](int comp, int axis, int ox, int oy, int oz) {
+    int px = ox, py = oy, pz = oz;
+    sh(axis, +1, px, py, pz);
+    return (at(comp, px, py, pz) - at(comp, ox, oy, oz)) * ih[axis];
+  };
+  auto GB = [&](int ox, int oy, int oz) { return dplus(A, C, ox, oy, oz) - dplus(C, A, ox, oy, oz); };
+  auto GA = [&](int ox, int oy, int oz) { return dplus(C, B, ox, oy, oz) - dplus(B, C, ox, oy, oz); };
+  int ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;
+  sh(A, -1, ax, ay, az);
+  sh(B, -1, bx, by, bz);
+  const double r = (GB(0, 0, 0) - GB(ax, ay, az)) * ih[A] - (GA(0, 0, 0) - GA(bx, by, bz)) * ih[B];
+  return 2.0 * at(C, 0, 0, 0) + (0.5 * g.dt * g.dt) * r;
+}
+
+constexpr int kRowX = 64, kRowY = 4;
+
+template <bool WITH_L, bool WITH_M>
+__global__ void __launch_bounds__(kRowX* kRowY, 4) k_matA(GridDev g, const double* __restrict__ L,
+  const double* __restrict__ X, double* __restrict__ Y, int add)
+{
+  // grid.x = 3 * x-chunks (component fastest: the three rows of a node share their operand footprint),
+  // grid.y = y-chunks, grid.z = z
+  const int c1 = blockIdx.x % 3;
+  const int x = (blockIdx.x / 3) * kRowX + threadIdx.x;
+  // y is the same for the 64 lanes of a wave (blockDim.x == 64): tell the compiler, so that every row base
+  // below is scalar arithmetic
+  const int y = blockIdx.y * kRowY + __builtin_amdgcn_readfirstlane(threadIdx.y), z = blockIdx.z;
+  if (x >= g.nx || y >= g.ny) return;
+  using Seq = std::make_integer_sequence<int, kLStencil>;
+  double r = 0.0;
+  if (c1 == 0) {
+    if (WITH_M) r = matM_comp<0>(g, X, x, y, z);
+    if (WITH_L) r += row_apply<0>(Seq{}, g, L, X, x, y, z);
+  }
+  else if (c1 == 1) {
+    if (WITH_M) r = matM_comp<1>(g, X, x, y, z);
+    if (WITH_L) r += row_apply<1>(Seq{}, g, L, X, x, y, z);
+  }
+  else {
+    if (WITH_M) r = matM_comp<2>(g, X, x, y, z);
+    if (WITH_L) r += row_apply<2>(Seq{}, g, L, X, x, y, z);
+  }
+  const long o = c1 * g.cstride + g.node(x, y, g.wz(z));
+  if (add) Y[o] += r;
+  else Y[o] = r;
 }
 
 // ---- boundary layout conversion: [z][y][x][3] (reference DMDA order) <-> SoA with ghost planes ----
@@ -410,12 +475,12 @@ int matM_apply(xpic_ctx* c, const double* x, double* y, bool add)
   return 0;
 }
 
-static dim3 row_grid(const GridDev& g) { return dim3((g.nx + kBlock - 1) / kBlock, g.ny, g.nzl); }
+static dim3 row_grid(const GridDev& g) { return dim3(3 * ((g.nx + kRowX - 1) / kRowX), (g.ny + kRowY - 1) / kRowY, g.nzl); }
 
 int matL_apply(xpic_ctx* c, const double* x, double* y, bool add)
 {
   Timed t(c, "matL_apply");
-  hipLaunchKernelGGL((k_matA<true, false>), row_grid(c->g), dim3(kBlock), 0, c->stream, c->g, c->matL, x, y, add ? 1 : 0);
+  hipLaunchKernelGGL((k_matA<true, false>), row_grid(c->g), dim3(kRowX, kRowY), 0, c->stream, c->g, c->matL, x, y, add ? 1 : 0);
   XPIC_HIP(hipGetLastError());
   return 0;
 }
@@ -423,7 +488,7 @@ int matL_apply(xpic_ctx* c, const double* x, double* y, bool add)
 int matA_apply(xpic_ctx* c, const double* x, double* y)
 {
   Timed t(c, "matA_apply");
-  hipLaunchKernelGGL((k_matA<true, true>), row_grid(c->g), dim3(kBlock), 0, c->stream, c->g, c->matL, x, y, 0);
+  hipLaunchKernelGGL((k_matA<true, true>), row_grid(c->g), dim3(kRowX, kRowY), 0, c->stream, c->g, c->matL, x, y, 0);
   XPIC_HIP(hipGetLastError());
   return 0;
 }
