@@ -1,0 +1,199 @@
+"""GPU parity tests of the `basic` and `ecsimcorr` paths (2nd-order gather, Boris, Esirkepov deposit, the
+second KSP solve and the lambda rescale), through the C ABI, against the CPU oracle and the reference's tables."""
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_ecsim import GOLD, canon, make_pair
+
+pytestmark = pytest.mark.gpu
+
+GRID = ((12, 10, 8), (0.5, 0.4, 0.25), 0.2)
+
+
+def by_position(pts):
+    """Order by position rounded to 1e-9 (the storage cell is stale between a push and update_cells)."""
+    k = np.round(pts[:, :3], 9)
+    return pts[np.lexsort((k[:, 2], k[:, 1], k[:, 0]))]
+
+
+def test_basic_push_matches_oracle(oracle):
+    """a4-a7: half move, Shape, SimpleInterpolation, update_vEB, half move, Shape(old,new), Esirkepov."""
+    import xpic_amd as X
+
+    n, d, dt = GRID
+    o, g = make_pair(oracle, "basic", n, d, dt, [(5, 1.0, -1.0, 1.0), (5, 1.0, 1.0, 4.0)], B0=(0.2, -0.1, 0.7), vth=0.2)
+    assert oracle.lib().orc_basic_push(o.h) == 0
+    g.vec_set(X.J, 0.0)
+    for s in range(2):
+        g.basic_push(s)
+    for s in range(2):
+        po, pg = by_position(o.particles(s)[0]), by_position(g.particles(s)[0])
+        assert np.abs(po - pg).max() <= 1e-13
+        a, b = o.sort_current(s, "J"), g.sort_current(s, X.J)
+        assert np.abs(a).max() > 0
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
+    a, b = o.get_field("J"), g.get_field(X.J)
+    assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
+
+
+def test_esirkepov_continuity_on_device(oracle):
+    """The deposited J satisfies the discrete continuity equation with the reference's own charge density
+    (ParticlesChargeDensity::collect, charge_conservation.cpp:67-97) to round-off."""
+    import xpic_amd as X
+
+    n, d, dt = GRID
+    o, g = make_pair(oracle, "basic", n, d, dt, [(6, 1.0, -1.0, 1.0)], B0=(0.0, 0.0, 0.5), vth=0.2)
+    rho0 = o.charge_density(0)
+    g.vec_set(X.J, 0.0)
+    g.basic_push(0)
+    g.update_cells(0)
+    pts, _ = g.particles(0)
+    o.clear(0)
+    assert o.add_particles(0, pts) == pts.shape[0]
+    rho1 = o.charge_density(0)
+    J = g.get_field(X.J)
+    div = np.zeros(rho0.shape)
+    oracle.lib().orc_div_neg(o.h, oracle._dp(np.ascontiguousarray(J)), oracle._dp(div))
+    res = (rho1 - rho0) / dt + div
+    assert np.abs(res).max() <= 1e-11 * max(np.abs(div).max(), 1e-30)
+
+
+def test_basic_steps_match_oracle(oracle):
+    import xpic_amd as X
+
+    n, d, dt = GRID
+    o, g = make_pair(oracle, "basic", n, d, 0.1, [(6, 1.0, -1.0, 1.0)], B0=(0.0, 0.3, 0.0), vth=0.1)
+    for t in range(5):
+        assert o.step() == 0
+        g.step()
+        for name, fid in (("E", X.E), ("B", X.B), ("J", X.J)):
+            a, b = o.get_field(name), g.get_field(fid)
+            assert np.abs(a - b).max() <= 1e-11 * np.abs(a).max(), (t, name)
+    assert o.count(0) == g.count(0)
+    po, co = canon(*o.particles(0))
+    pg, cg = canon(*g.particles(0))
+    assert np.array_equal(co, cg)
+    assert np.abs(po - pg).max() <= 1e-12
+
+
+def test_reference_golden_basic_ex1(oracle):
+    """tests/basic/basic_ex1.cpp through the HIP path: 20 rows of energy.txt to every printed digit."""
+    import xpic_amd as X
+
+    oracle.lib().orc_reset_rng()
+    o = oracle.OracleSim("basic", (10, 10, 10), (0.05, 0.05, 0.05), 0.025)
+    so = o.add_sort(100, 1.0, -1.0, 1.0, (0.1, 0.1, 0.1))
+    o.load_maxwell_box(so, True)
+    pts, _ = o.particles(so)
+    g = X.Context("basic", (10, 10, 10), (0.05, 0.05, 0.05), 0.025)
+    sg = g.add_sort(100, 1.0, -1.0, 1.0, capacity=200000)
+    assert g.add_particles(sg, pts) == 99999
+    _, gold = oracle.read_table(os.path.join(GOLD, "basic_ex1", "energy.txt"))
+
+    def row(en):
+        return np.array([float("% .6e" % v) for v in (en[0], en[1], en[4], en[2], en[3], en[5])])
+
+    assert np.abs(row(g.energy()) - gold[0, 1:]).max() < 1e-10
+    for t in range(1, 21):
+        g.step()
+        assert np.abs(row(g.energy()) - gold[t, 1:]).max() < 1e-10, t
+    for name, fid in (("E", X.E), ("B", X.B)):
+        pass
+    for t in range(21, 51):
+        g.step()
+    for name, fid in (("E", X.E), ("B", X.B)):
+        dump = np.fromfile(os.path.join(GOLD, "basic_ex1", f"{name}_050.f32"), dtype=np.float32)
+        mine = g.get_field(fid).astype(np.float32).ravel()
+        assert np.abs(mine - dump).max() <= 2e-6 * np.abs(dump).max(), name
+
+
+def test_ecsimcorr_phases_match_oracle(oracle):
+    """a13: first_push, second_push (with pred_w), final_update (corr_w, lambda) one by one."""
+    import xpic_amd as X
+
+    n, d, dt = GRID
+    o, g = make_pair(oracle, "ecsimcorr", n, d, dt, [(6, 1.0, -1.0, 1.0)], B0=(0.1, 0.0, 0.4), vth=0.2)
+    L = oracle.lib()
+    rng = np.random.default_rng(11)
+    Ep = rng.normal(0, 0.05, o.fshape())
+    Ec = rng.normal(0, 0.05, o.fshape())
+    for name, fid, F in (("Ep", X.EP, Ep), ("Ec", X.EC, Ec)):
+        o.set_field(name, F)
+        g.set_field(fid, F)
+    k0o, k0g = L.orc_calculate_energy(o.h, 0), g.calculate_energy(0)
+    assert np.isclose(k0o, k0g, rtol=1e-13)
+    assert L.orc_ecsimcorr_first_push(o.h, 0) == 0
+    g.ecsimcorr_first_push(0)
+    L.orc_update_cells(o.h, 0)
+    g.update_cells(0)
+    assert L.orc_ecsimcorr_second_push(o.h, 0) == 0
+    g.vec_set(X.CURRJE, 0.0)
+    g.ecsimcorr_second_push(0)
+    a, b = o.sort_current(0, "currJe"), g.sort_current(0, X.CURRJE)
+    assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
+    so, sg = o.ecsimcorr_scalars(0), g.ecsimcorr_scalars(0)
+    assert np.isclose(so["pred_w"], sg["pred_w"], rtol=1e-11)
+    L.orc_ecsimcorr_final_update(o.h, 0)
+    g.ecsimcorr_final_update(0)
+    so, sg = o.ecsimcorr_scalars(0), g.ecsimcorr_scalars(0)
+    for k in so:
+        assert np.isclose(so[k], sg[k], rtol=1e-10, atol=1e-16), k
+    L.orc_update_cells(o.h, 0)
+    g.update_cells(0)
+    po, co = canon(*o.particles(0))
+    pg, cg = canon(*g.particles(0))
+    assert np.array_equal(co, cg)
+    assert np.abs(po - pg).max() <= 1e-12
+
+
+def test_ecsimcorr_steps_match_oracle(oracle):
+    import xpic_amd as X
+
+    n, d, dt = GRID
+    o, g = make_pair(oracle, "ecsimcorr", n, d, 0.5, [(8, 1.0, -1.0, 1.0)], B0=(0.0, 0.0, 0.2), vth=0.05)
+    for s in (o, g):
+        s.set_tolerances(1e-11, 1e-50, 300)
+    for t in range(3):
+        io, ig = o.step(), g.step()
+        assert io > 0 and abs(io - ig) <= 2
+        for name, fid in (("E", X.E), ("B", X.B)):
+            a, b = o.get_field(name), g.get_field(fid)
+            assert np.abs(a - b).max() <= 1e-6 * np.abs(a).max(), (t, name)
+        so, sg = o.ecsimcorr_scalars(0), g.ecsimcorr_scalars(0)
+        assert np.isclose(so["energy"], sg["energy"], rtol=1e-9)
+        assert np.isclose(so["lambda_dK"], sg["lambda_dK"], rtol=1e-5, atol=1e-14)
+    assert o.count(0) == g.count(0)
+
+
+def test_reference_golden_ecsimcorr_ex1(oracle):
+    """tests/ecsimcorr/ecsimcorr_ex1.cpp through the HIP path: row 1 of energy.txt to every printed digit."""
+    import xpic_amd as X
+
+    oracle.lib().orc_reset_rng()
+    o = oracle.OracleSim("ecsimcorr", (10, 10, 10), (0.5, 0.5, 0.5), 1.5)
+    so = o.add_sort(100, 1.0, -1.0, 1.0, (0.1, 0.1, 0.1))
+    o.load_maxwell_box(so, True)
+    pts, _ = o.particles(so)
+    g = X.Context("ecsimcorr", (10, 10, 10), (0.5, 0.5, 0.5), 1.5)
+    sg = g.add_sort(100, 1.0, -1.0, 1.0, capacity=200000)
+    assert g.add_particles(sg, pts) == 100000
+    _, gold = oracle.read_table(os.path.join(GOLD, "ecsimcorr_ex1", "energy.txt"))
+    _, goldc = oracle.read_table(os.path.join(GOLD, "ecsimcorr_ex1", "energy_conservation.txt"))
+
+    def row(en):
+        return np.array([float("% .6e" % v) for v in (en[0], en[1], en[4], en[2], en[3], en[5])])
+
+    assert np.abs(row(g.energy()) - gold[0, 1:]).max() < 1e-10
+    for t in range(1, 4):
+        assert g.step() > 0
+        en = g.energy()
+        sc = g.ecsimcorr_scalars(sg)
+        if t == 1:
+            assert np.abs(row(en) - gold[1, 1:]).max() < 1e-10
+            assert abs(sc["lambda_dK"] - goldc[1, 4]) < 2e-10
+        else:
+            assert np.allclose(row(en), gold[t, 1:], rtol=1e-3)
+        assert abs(sc["pred_dK"] - 1.5 * sc["pred_w"]) < 1e-14  # PWD column
+        assert abs(sc["corr_dK"] - 1.5 * sc["corr_w"]) < 1e-14  # LdK column

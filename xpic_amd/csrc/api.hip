@@ -123,6 +123,95 @@ static int step_ecsim(xpic_ctx* c, int* its)
   return 0;
 }
 
+// basic::Simulation::timestep_implementation (src/impls/basic/simulation.cpp:30-100);
+// rotE = -(dt/2) rot(+), rotB = +dt rot(-) (:23-24)
+static int step_basic(xpic_ctx* c)
+{
+  const double dt = c->g.dt;
+  double *E = c->field[XPIC_E], *B = c->field[XPIC_B], *B0 = c->field[XPIC_B0], *J = c->field[XPIC_J];
+  XPIC_CALL(vec_set(c, J, 0.0));
+  // push_particles :45-72
+  XPIC_CALL(vec_axpy(c, B, -1.0, B0));
+  XPIC_CALL(halo_fill(c, E));
+  XPIC_CALL(rot_apply(c, +1, -(0.5 * dt), E, B, true));
+  XPIC_CALL(vec_axpy(c, B, +1.0, B0));
+  XPIC_CALL(halo_fill(c, B));
+  for (auto& s : c->sorts) {
+    XPIC_HIP(hipMemsetAsync(s.J, 0, sizeof(double) * c->nvec, c->stream));
+    XPIC_CALL(esirkepov_push(c, s, 0, E, B, s.J, nullptr)); // sort->push()
+    XPIC_CALL(vec_axpy(c, J, 1.0, s.J));                    // VecAXPY(simulation_.J, 1, J) particles.cpp:51
+    XPIC_CALL(sort_rebin(c, s, 0.0, true));                 // sort->update_cells()
+  }
+  // push_fields :74-100
+  XPIC_CALL(vec_axpy(c, B, -1.0, B0));
+  XPIC_CALL(rot_apply(c, +1, -(0.5 * dt), E, B, true));
+  XPIC_CALL(halo_fill(c, B));
+  XPIC_CALL(rot_apply(c, -1, +dt, B, E, true));
+  XPIC_CALL(vec_axpy(c, E, -dt, J));
+  XPIC_CALL(vec_axpy(c, B, +1.0, B0));
+  return 0;
+}
+
+static int calc_energy(xpic_ctx* c, Sort& s)
+{
+  double o[5];
+  XPIC_CALL(kinetic_sums_host(c, s, o));
+  s.energy = 0.5 * s.par.m * (s.par.n / s.par.Np) * o[3]; // Energy::get_kinetic summed, ecsimcorr/particles.cpp:134-150
+  return 0;
+}
+
+// ecsimcorr::Particles::final_update (src/impls/ecsimcorr/particles.cpp:93-126)
+static int corr_final_update(xpic_ctx* c, Sort& s)
+{
+  XPIC_CALL(vec_dot_host(c, s.currJe, c->field[XPIC_EC], &s.corr_w));
+  const double K0 = s.energy;
+  XPIC_CALL(calc_energy(c, s));
+  const double K = s.energy;
+  const double lambda2 = 1.0 + c->g.dt * (s.corr_w - s.pred_w) / K;
+  XPIC_CALL(scale_velocities(c, s, std::sqrt(lambda2)));
+  s.lambda_dK = (lambda2 - 1.0) * K;
+  s.pred_dK = K - K0;
+  s.corr_dK = lambda2 * K - K0;
+  s.energy = lambda2 * K;
+  return 0;
+}
+
+// ecsimcorr::Simulation::timestep_implementation (src/impls/ecsimcorr/simulation.cpp:21-90)
+static int step_ecsimcorr(xpic_ctx* c, int* its)
+{
+  double *Ep = c->field[XPIC_EP], *B = c->field[XPIC_B];
+  // clear_sources :34-49
+  XPIC_CALL(vec_set(c, c->field[XPIC_CURRJE], 0.0));
+  for (auto& s : c->sorts) {
+    XPIC_HIP(hipMemsetAsync(s.currJe, 0, sizeof(double) * c->nvec, c->stream));
+    XPIC_CALL(calc_energy(c, s));
+  }
+  // first_push: half move + Esirkepov, re-bin, ECSIM current + matL
+  for (auto& s : c->sorts) XPIC_CALL(esirkepov_push(c, s, 1, nullptr, nullptr, s.currJe, nullptr));
+  for (auto& s : c->sorts) XPIC_CALL(sort_rebin(c, s, 0.0, true));
+  XPIC_CALL(ecsim_fill_current(c));
+  int its0 = 0, its1 = 0;
+  XPIC_CALL(advance_fields(c, XPIC_OP_MATA_GMRES, c->field[XPIC_CURRI], Ep, &its0)); // KSP "predict"
+  // second_push (ecsim/simulation.cpp:212-239 with the ecsimcorr particles)
+  XPIC_CALL(halo_fill(c, Ep));
+  XPIC_CALL(halo_fill(c, B));
+  for (auto& s : c->sorts) {
+    XPIC_CALL(esirkepov_push(c, s, 2, Ep, B, s.currJe, &s.pred_w));
+    XPIC_CALL(vec_axpy(c, c->field[XPIC_CURRJE], 1.0, s.currJe)); // particles.cpp:89
+  }
+  for (auto& s : c->sorts) XPIC_CALL(sort_rebin(c, s, 0.0, true)); // correct_coordinates + update_cells
+  // correct_fields :52-63: KSP "correct" on matM with the Esirkepov current
+  XPIC_CALL(advance_fields(c, XPIC_OP_MATM_GMRES, c->field[XPIC_CURRJE], c->field[XPIC_EC], &its1));
+  // final_update :65-90
+  for (auto& s : c->sorts) XPIC_CALL(corr_final_update(c, s));
+  XPIC_CALL(halo_fill(c, c->field[XPIC_EC]));
+  XPIC_CALL(matL_apply(c, c->field[XPIC_EC], c->field[XPIC_CURRI], true)); // currI += matL Ec :78
+  std::swap(c->field[XPIC_EP], c->field[XPIC_EC]);                         // VecSwap(Ep, Ec) :86
+  XPIC_CALL(ecsim_final_update(c));
+  *its = its0 + its1;
+  return 0;
+}
+
 }  // namespace xpic
 
 using namespace xpic;
@@ -399,11 +488,52 @@ int xpic_ecsim_second_push(xpic_ctx* ctx, int sort)
   return ecsim_second_push(ctx, ctx->sorts[sort], ctx->field[XPIC_EP], ctx->field[XPIC_B]);
 }
 
-int xpic_basic_push(xpic_ctx*, int) { set_error("basic::push is not built yet"); return 5; }
-int xpic_ecsimcorr_first_push(xpic_ctx*, int) { set_error("ecsimcorr is not built yet"); return 5; }
-int xpic_ecsimcorr_second_push(xpic_ctx*, int) { set_error("ecsimcorr is not built yet"); return 5; }
-int xpic_ecsimcorr_final_update(xpic_ctx*, int) { set_error("ecsimcorr is not built yet"); return 5; }
-int xpic_ecsimcorr_scalars(xpic_ctx*, int, double*) { set_error("ecsimcorr is not built yet"); return 5; }
+int xpic_basic_push(xpic_ctx* ctx, int sort)
+{
+  CTX_CHECK(ctx); SORT_CHECK(sort);
+  XPIC_CHECK(ctx->scheme == XPIC_BASIC, "xpic_basic_push needs the basic scheme");
+  Sort& s = ctx->sorts[sort];
+  XPIC_CALL(halo_fill(ctx, ctx->field[XPIC_E]));
+  XPIC_CALL(halo_fill(ctx, ctx->field[XPIC_B]));
+  XPIC_HIP(hipMemsetAsync(s.J, 0, sizeof(double) * ctx->nvec, ctx->stream));
+  XPIC_CALL(esirkepov_push(ctx, s, 0, ctx->field[XPIC_E], ctx->field[XPIC_B], s.J, nullptr));
+  return vec_axpy(ctx, ctx->field[XPIC_J], 1.0, s.J);
+}
+
+int xpic_ecsimcorr_first_push(xpic_ctx* ctx, int sort)
+{
+  CTX_CHECK(ctx); SORT_CHECK(sort);
+  XPIC_CHECK(ctx->scheme == XPIC_ECSIMCORR, "needs the ecsimcorr scheme");
+  Sort& s = ctx->sorts[sort];
+  XPIC_HIP(hipMemsetAsync(s.currJe, 0, sizeof(double) * ctx->nvec, ctx->stream));
+  return esirkepov_push(ctx, s, 1, nullptr, nullptr, s.currJe, nullptr);
+}
+
+int xpic_ecsimcorr_second_push(xpic_ctx* ctx, int sort)
+{
+  CTX_CHECK(ctx); SORT_CHECK(sort);
+  XPIC_CHECK(ctx->scheme == XPIC_ECSIMCORR, "needs the ecsimcorr scheme");
+  Sort& s = ctx->sorts[sort];
+  XPIC_CALL(halo_fill(ctx, ctx->field[XPIC_EP]));
+  XPIC_CALL(halo_fill(ctx, ctx->field[XPIC_B]));
+  XPIC_CALL(esirkepov_push(ctx, s, 2, ctx->field[XPIC_EP], ctx->field[XPIC_B], s.currJe, &s.pred_w));
+  return vec_axpy(ctx, ctx->field[XPIC_CURRJE], 1.0, s.currJe);
+}
+
+int xpic_ecsimcorr_final_update(xpic_ctx* ctx, int sort)
+{
+  CTX_CHECK(ctx); SORT_CHECK(sort);
+  XPIC_CHECK(ctx->scheme == XPIC_ECSIMCORR, "needs the ecsimcorr scheme");
+  return corr_final_update(ctx, ctx->sorts[sort]);
+}
+
+int xpic_ecsimcorr_scalars(xpic_ctx* ctx, int sort, double* o)
+{
+  CTX_CHECK(ctx); SORT_CHECK(sort);
+  const Sort& t = ctx->sorts[sort];
+  o[0] = t.pred_w; o[1] = t.corr_w; o[2] = t.lambda_dK; o[3] = t.pred_dK; o[4] = t.corr_dK; o[5] = t.energy;
+  return 0;
+}
 
 int xpic_calculate_energy(xpic_ctx* ctx, int sort, double* energy)
 {
@@ -445,8 +575,9 @@ int xpic_step(xpic_ctx* ctx, int* ksp_iterations)
   int its = 0;
   int rc;
   switch (ctx->scheme) {
+    case XPIC_BASIC: rc = step_basic(ctx); break;
     case XPIC_ECSIM: rc = step_ecsim(ctx, &its); break;
-    default: set_error("this scheme's timestep is not built yet"); return 5;
+    default: rc = step_ecsimcorr(ctx, &its); break;
   }
   if (ksp_iterations) *ksp_iterations = its;
   return rc;

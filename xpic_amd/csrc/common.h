@@ -179,6 +179,9 @@ int scale_velocities(xpic_ctx* c, Sort& s, double lambda);
 int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, double* matL);
 int build_ltab(xpic_ctx* c);
 
+// esirkepov.hip: mode 0 basic::push, 1 ecsimcorr first_push, 2 ecsimcorr second_push
+int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double* B, double* J, double* pred_w_host);
+
 // krylov.hip
 int solve(xpic_ctx* c, int op, const double* rhs, double* x, double rtol, double atol, int maxit, int* its,
   int* reason, double* rnorm);
