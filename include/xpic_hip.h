@@ -21,6 +21,7 @@
 #ifndef XPIC_HIP_H
 #define XPIC_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -150,6 +151,25 @@ int xpic_step(xpic_ctx* ctx, int* ksp_iterations);
 /* Energy::calculate_field/calculate_kinetic (src/diagnostics/energy.cpp:43-108):
  * out = {wE, wB, sE, sB, wK_0, sK_0, wK_1, sK_1, ...} */
 int xpic_energy(xpic_ctx* ctx, double* out);
+
+/* ---- z-slab decomposition (DMDA da_processors_z = nranks; src/utils/world.cpp:36-38).  A context created with
+ * nranks > 1 owns planes [rank*nz/nranks, (rank+1)*nz/nranks) and must be given a communicator before any
+ * call that moves data between slabs (steps, solves, operator applies, re-binning, energy): those calls are
+ * collective over the ranks.  Replaces update_cells_mpi (src/interfaces/particles.cpp:118-248), DMGlobalToLocal /
+ * DMLocalToGlobal(ADD) and the all-reduces inside VecDot/VecNorm/KSPSolve. */
+/* RCCL over xGMI: rank 0 creates the id, every rank (one process per GPU) passes the same 128 bytes */
+int xpic_comm_rccl_unique_id(void* id128);
+int xpic_comm_init_rccl(xpic_ctx* ctx, const void* id128);
+/* host-staged transport supplied by the caller (tests: torch.distributed/gloo).  Ring semantics: send `down` to
+ * rank-1 and `up` to rank+1; receive the upper neighbour's `down` message into from_up and the lower neighbour's
+ * `up` message into from_down (with 2 ranks both neighbours are the same peer: messages are matched in this order) */
+typedef struct xpic_comm_callbacks {
+  void* user;
+  int (*sendrecv)(void* user, const void* down, size_t ndown, const void* up, size_t nup, void* from_up,
+    size_t nfrom_up, void* from_down, size_t nfrom_down);
+  int (*allreduce_sum)(void* user, double* buf, int n);
+} xpic_comm_callbacks;
+int xpic_comm_init_callbacks(xpic_ctx* ctx, const xpic_comm_callbacks* cb);
 
 /* ---- measurement: HIP-event timers around kernel families, on the context's own stream */
 int xpic_profile_enable(xpic_ctx* ctx, int on);

@@ -1,0 +1,93 @@
+"""Worker of tests/test_gpu_slabs.py: `nranks` processes share ONE GPU, each owns a z-slab, the exchange goes
+through gloo (xpic_comm_init_callbacks).  Every rank runs the same seeded problem; rank 0 also runs it on a
+single-slab context and checks that the decomposed run reproduces it."""
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import xpic_amd as X  # noqa: E402
+from xpic_amd.parallel import GlooRing  # noqa: E402
+
+
+def build(scheme, n, d, dt, rank, nranks, seed):
+    rng = np.random.default_rng(seed)
+    vth = 0.25 if scheme == "ecsim" else 0.1  # Esirkepov moves must stay below one cell (dz = 0.25, dt = 0.2)
+    ctx = X.Context(scheme, n, d, dt, device=0, rank=rank, nranks=nranks)
+    N = n[0] * n[1] * n[2]
+    sorts = [(8, 1.0, -1.0, 1.0), (8, 1.0, 1.0, 16.0)]
+    L = np.array(n) * np.array(d)
+    for (Np, dens, q, m) in sorts:
+        s = ctx.add_sort(Np, dens, q, m, capacity=3 * 8 * N)
+        pts = np.empty((8 * N, 6))
+        pts[:, :3] = rng.random((8 * N, 3)) * L
+        pts[:, 3:] = rng.normal(0, vth, (8 * N, 3))
+        ctx.add_particles(s, pts)  # add_particle keeps what lies in the local slab
+    shape = (n[2], n[1], n[0], 3)
+    E = rng.normal(0, 0.02, shape)
+    B = rng.normal(0, 0.02, shape) + np.array([0.0, 0.1, 0.3])
+    B0 = np.zeros(shape) + np.array([0.0, 0.1, 0.3])
+    z0, nzl = ctx.z0, ctx.nzl
+    for fid, F in ((X.E, E), (X.B, B), (X.B0, B0)):
+        ctx.set_field(fid, F[z0:z0 + nzl])
+    ctx.set_tolerances(1e-12, 1e-50, 400)
+    return ctx
+
+
+def gather_field(ctx, fid, nranks):
+    loc = ctx.get_field(fid)
+    parts = [None] * nranks
+    dist.all_gather_object(parts, loc)
+    return np.concatenate(parts, axis=0)
+
+
+def main():
+    scheme = sys.argv[1]
+    dist.init_process_group("gloo")
+    rank, nranks = dist.get_rank(), dist.get_world_size()
+    n, d = (12, 10, 12 * nranks), (0.5, 0.4, 0.25)
+    dt = 0.2 if scheme != "ecsim" else 0.8
+    ctx = build(scheme, n, d, dt, rank, nranks, seed=42)
+    GlooRing().attach(ctx)
+    counts0 = [ctx.count(s) for s in range(2)]
+    nsteps = 3
+    its = [ctx.step() for _ in range(nsteps)]
+    en = ctx.energy()
+    fields = {name: gather_field(ctx, fid, nranks) for name, fid in (("E", X.E), ("B", X.B))}
+    counts = [ctx.count(s) for s in range(2)]
+    allc = [None] * nranks
+    dist.all_gather_object(allc, (counts0, counts))
+    ok = True
+    if rank == 0:
+        ref = build(scheme, n, d, dt, 0, 1, seed=42)
+        rits = [ref.step() for _ in range(nsteps)]
+        ren = ref.energy()
+        tot0 = [sum(c[0][s] for c in allc) for s in range(2)]
+        tot1 = [sum(c[1][s] for c in allc) for s in range(2)]
+        print("particles before/after", tot0, tot1, "single-slab", [ref.count(s) for s in range(2)], flush=True)
+        ok &= tot1 == [ref.count(s) for s in range(2)]
+        ok &= any(c[1] != c[0] for c in allc)  # particles did migrate between the slabs
+        for name, fid in (("E", X.E), ("B", X.B)):
+            a = ref.get_field(fid)
+            err = np.abs(a - fields[name]).max() / np.abs(a).max()
+            print(name, "rel err vs single slab", err, flush=True)
+            ok &= err < 1e-8
+        print("energy", en, ren, "its", its, rits, flush=True)
+        ok &= np.allclose(en, ren, rtol=1e-9, atol=1e-15)
+        if scheme != "basic":
+            ok &= all(abs(a - b) <= 2 for a, b in zip(its, rits))
+    flag = [ok]
+    dist.broadcast_object_list(flag, src=0)
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    if not flag[0]:
+        sys.exit(1)
+    print(f"rank {rank}/{nranks} ok", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -28,7 +28,8 @@ SYMBOLS = [
     "xpic_update_cells", "xpic_ecsim_fill_current", "xpic_ecsim_second_push", "xpic_basic_push",
     "xpic_ecsimcorr_first_push", "xpic_ecsimcorr_second_push", "xpic_ecsimcorr_final_update",
     "xpic_calculate_energy", "xpic_ecsimcorr_scalars", "xpic_solve", "xpic_set_tolerances", "xpic_step",
-    "xpic_energy", "xpic_profile_enable", "xpic_profile_reset", "xpic_profile_get", "xpic_probe_copy_bandwidth",
+    "xpic_energy", "xpic_comm_rccl_unique_id", "xpic_comm_init_rccl", "xpic_comm_init_callbacks",
+    "xpic_profile_enable", "xpic_profile_reset", "xpic_profile_get", "xpic_probe_copy_bandwidth",
 ]
 
 
@@ -83,10 +84,53 @@ class Context:
         self.d = tuple(float(v) for v in d)
         self.dt = float(dt)
         self.scheme = scheme
+        self.rank, self.nranks = rank, nranks
+        self.nzl = self.n[2] // nranks  # planes of this z-slab
+        self.z0 = rank * self.nzl
         self.h = C.c_void_p()
         self._ck(self.L.xpic_create(C.byref(g), SCHEMES[scheme], C.byref(self.h)))
-        self.N = self.n[0] * self.n[1] * self.n[2]
+        self.N = self.n[0] * self.n[1] * self.nzl  # local cells
         self.nsorts = 0
+        self._cb = None
+
+    # ---- z-slab communicator
+    def comm_init_rccl(self, id128):
+        buf = (C.c_char * 128).from_buffer_copy(bytes(id128))
+        self._ck(self.L.xpic_comm_init_rccl(self.h, buf))
+
+    def comm_init_callbacks(self, sendrecv, allreduce_sum):
+        """sendrecv(down: bytes, up: bytes, n_from_up, n_from_down) -> (from_up: bytes, from_down: bytes);
+        allreduce_sum(np.ndarray[float64]) -> reduces in place.  Used by tests (torch.distributed / gloo)."""
+        SR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                         C.c_void_p, C.c_size_t)
+        AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+
+        def _sr(user, down, nd, up, nu, fu, nfu, fd, nfd):
+            try:
+                a, b = sendrecv(C.string_at(down, nd) if nd else b"", C.string_at(up, nu) if nu else b"", nfu, nfd)
+                if nfu:
+                    C.memmove(fu, a, nfu)
+                if nfd:
+                    C.memmove(fd, b, nfd)
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("xpic comm callback failed:", e, flush=True)
+                return 1
+
+        def _ar(user, buf, n):
+            try:
+                arr = np.ctypeslib.as_array(buf, shape=(n,))
+                allreduce_sum(arr)
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("xpic comm callback failed:", e, flush=True)
+                return 1
+
+        class CB(C.Structure):
+            _fields_ = [("user", C.c_void_p), ("sendrecv", SR), ("allreduce_sum", AR)]
+
+        self._cb = CB(None, SR(_sr), AR(_ar))
+        self._ck(self.L.xpic_comm_init_callbacks(self.h, C.byref(self._cb)))
 
     def _ck(self, rc):
         if rc != 0:
@@ -137,7 +181,7 @@ class Context:
 
     # ---- fields
     def fshape(self):
-        return (self.n[2], self.n[1], self.n[0], 3)
+        return (self.nzl, self.n[1], self.n[0], 3)
 
     def set_field(self, f, v):
         v = np.ascontiguousarray(v, dtype=np.float64).reshape(self.fshape())
@@ -265,6 +309,14 @@ class Context:
         o = C.c_double()
         self._ck(self.L.xpic_probe_copy_bandwidth(self.h, C.c_int64(nbytes), reps, C.byref(o)))
         return o.value
+
+
+def rccl_unique_id():
+    L = load_library()
+    buf = (C.c_char * 128)()
+    if L.xpic_comm_rccl_unique_id(buf) != 0:
+        raise XpicError(L.xpic_last_error().decode())
+    return bytes(buf)
 
 
 def lstencil_decode(c1, k):

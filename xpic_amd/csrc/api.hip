@@ -56,6 +56,10 @@ static int resolve_profile(xpic_ctx* c)
   return 0;
 }
 
+// matL holds one extra row plane below and above the slab when there are neighbours (rows of their nodes that
+// this rank's cells contribute to)
+static size_t matL_doubles(const GridDev& g) { return (size_t)3 * (g.nzl + (g.G ? 2 : 0)) * g.plane * kLStencil; }
+
 static bool valid_field(int f) { return f >= 0 && f < XPIC_NFIELDS; }
 
 #define CTX_CHECK(c) XPIC_CHECK((c) != nullptr, "null context")
@@ -87,15 +91,17 @@ static int ecsim_fill_current(xpic_ctx* c)
   const GridDev& g = c->g;
   {
     Timed t(c, "matL_zero");
-    XPIC_HIP(hipMemsetAsync(c->matL, 0, sizeof(double) * 3 * g.nown * kLStencil, c->stream)); // MatZeroEntries :164
+    XPIC_HIP(hipMemsetAsync(c->matL, 0, sizeof(double) * matL_doubles(g), c->stream)); // MatZeroEntries :164
   }
   XPIC_CALL(vec_set(c, c->field[XPIC_CURRI], 0.0));
-  XPIC_CALL(halo_fill(c, c->field[XPIC_B])); // DMGlobalToLocal(B) :474
+  XPIC_CALL(halo_fill(c, c->field[XPIC_B], 1)); // DMGlobalToLocal(B) :474
   for (auto& s : c->sorts) {
     XPIC_HIP(hipMemsetAsync(s.currI, 0, sizeof(double) * c->nvec, c->stream));
     XPIC_CALL(ecsim_fill_sort(c, s, c->field[XPIC_B], s.currI, c->matL));
+    XPIC_CALL(halo_add(c, s.currI, 1));                          // DMLocalToGlobal(ADD) particles.cpp:56
     XPIC_CALL(vec_axpy(c, c->field[XPIC_CURRI], 1.0, s.currI)); // particles.cpp:57
   }
+  XPIC_CALL(matL_exchange_ghost_rows(c));
   return 0;
 }
 
@@ -139,6 +145,7 @@ static int step_basic(xpic_ctx* c)
   for (auto& s : c->sorts) {
     XPIC_HIP(hipMemsetAsync(s.J, 0, sizeof(double) * c->nvec, c->stream));
     XPIC_CALL(esirkepov_push(c, s, 0, E, B, s.J, nullptr)); // sort->push()
+    XPIC_CALL(halo_add(c, s.J, 3));                         // DMLocalToGlobal(ADD) particles.cpp:50
     XPIC_CALL(vec_axpy(c, J, 1.0, s.J));                    // VecAXPY(simulation_.J, 1, J) particles.cpp:51
     XPIC_CALL(sort_rebin(c, s, 0.0, true));                 // sort->update_cells()
   }
@@ -155,7 +162,7 @@ static int step_basic(xpic_ctx* c)
 static int calc_energy(xpic_ctx* c, Sort& s)
 {
   double o[5];
-  XPIC_CALL(kinetic_sums_host(c, s, o));
+  XPIC_CALL(kinetic_sums_global(c, s, o));
   s.energy = 0.5 * s.par.m * (s.par.n / s.par.Np) * o[3]; // Energy::get_kinetic summed, ecsimcorr/particles.cpp:134-150
   return 0;
 }
@@ -197,6 +204,7 @@ static int step_ecsimcorr(xpic_ctx* c, int* its)
   XPIC_CALL(halo_fill(c, B));
   for (auto& s : c->sorts) {
     XPIC_CALL(esirkepov_push(c, s, 2, Ep, B, s.currJe, &s.pred_w));
+    XPIC_CALL(halo_add(c, s.currJe, 3));                          // DMLocalToGlobal(ADD) particles.cpp:88
     XPIC_CALL(vec_axpy(c, c->field[XPIC_CURRJE], 1.0, s.currJe)); // particles.cpp:89
   }
   for (auto& s : c->sorts) XPIC_CALL(sort_rebin(c, s, 0.0, true)); // correct_coordinates + update_cells
@@ -226,7 +234,9 @@ int xpic_create(const xpic_geometry* geom, int scheme, xpic_ctx** out)
   XPIC_CHECK(geom && out, "null argument");
   XPIC_CHECK(geom->periodic[0] && geom->periodic[1] && geom->periodic[2], "only DM_BOUNDARY_PERIODIC is supported");
   XPIC_CHECK(geom->n[0] >= 4 && geom->n[1] >= 4 && geom->n[2] >= 4, "every grid extent must be >= 4 cells");
-  XPIC_CHECK(geom->nranks == 1 && geom->rank == 0, "nranks > 1 (z-slab decomposition) is not built yet");
+  XPIC_CHECK(geom->nranks >= 1 && geom->rank >= 0 && geom->rank < geom->nranks, "bad rank / nranks");
+  XPIC_CHECK(geom->n[2] % geom->nranks == 0, "nz must be divisible by the number of z-slabs");
+  XPIC_CHECK(geom->nranks == 1 || geom->n[2] / geom->nranks >= 6, "a z-slab must hold at least 6 planes");
   XPIC_CHECK(scheme == XPIC_BASIC || scheme == XPIC_ECSIM || scheme == XPIC_ECSIMCORR, "unknown scheme");
   int ndev = 0;
   XPIC_HIP(hipGetDeviceCount(&ndev));
@@ -237,7 +247,9 @@ int xpic_create(const xpic_geometry* geom, int scheme, xpic_ctx** out)
   c->scheme = scheme;
   GridDev& g = c->g;
   g.nx = geom->n[0]; g.ny = geom->n[1]; g.nzg = geom->n[2];
-  g.nzl = g.nzg; g.z0 = 0; g.G = 0;
+  g.nzl = g.nzg / geom->nranks;
+  g.z0 = geom->rank * g.nzl;
+  g.G = geom->nranks > 1 ? 3 : 0; // ceil(shape_radius) + 1 planes: c-2 .. c+3 of the 2nd-order shape pair
   g.nzs = g.nzl + 2 * g.G;
   g.dx = geom->d[0]; g.dy = geom->d[1]; g.dz = geom->d[2]; g.dt = geom->dt;
   g.Lx = g.nx * g.dx; g.Ly = g.ny * g.dy; g.Lz = g.nzg * g.dz;
@@ -254,11 +266,11 @@ int xpic_create(const xpic_geometry* geom, int scheme, xpic_ctx** out)
     XPIC_HIP(hipMemsetAsync(c->field[f], 0, sizeof(double) * c->nvec, c->stream));
   }
   XPIC_HIP(hipMalloc(&c->red_partial, sizeof(double) * kMaxDots * kRedBlocks));
-  XPIC_HIP(hipMalloc(&c->red_out, sizeof(double) * 64));
+  XPIC_HIP(hipMalloc(&c->red_out, sizeof(double) * 128));
   XPIC_HIP(hipHostMalloc(&c->red_host, sizeof(double) * 64));
   if (scheme != XPIC_BASIC) {
-    XPIC_HIP(hipMalloc(&c->matL, sizeof(double) * 3 * g.nown * kLStencil));
-    XPIC_HIP(hipMemsetAsync(c->matL, 0, sizeof(double) * 3 * g.nown * kLStencil, c->stream));
+    XPIC_HIP(hipMalloc(&c->matL, sizeof(double) * matL_doubles(g)));
+    XPIC_HIP(hipMemsetAsync(c->matL, 0, sizeof(double) * matL_doubles(g), c->stream));
     XPIC_HIP(hipMalloc(&c->kry_V, sizeof(double) * c->nvec * 31));
     XPIC_HIP(hipMalloc(&c->kry_w, sizeof(double) * c->nvec));
     XPIC_HIP(hipMemsetAsync(c->kry_V, 0, sizeof(double) * c->nvec * 31, c->stream));
@@ -279,6 +291,8 @@ int xpic_destroy(xpic_ctx* ctx)
   (void)hipFree(ctx->matL); (void)hipFree(ctx->ltab); (void)hipFree(ctx->kry_V); (void)hipFree(ctx->kry_w);
   (void)hipFree(ctx->red_partial); (void)hipFree(ctx->red_out); (void)hipHostFree(ctx->red_host);
   (void)hipFree(ctx->scan_tmp);
+  for (int i = 0; i < 4; ++i) (void)hipFree(ctx->halo_buf[i]);
+  comm_free(ctx);
   for (auto& kv : ctx->prof)
     for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -433,7 +447,7 @@ int xpic_matL_get(xpic_ctx* ctx, double* out)
   CTX_CHECK(ctx);
   XPIC_CHECK(ctx->matL, "scheme has no matL");
   const GridDev& g = ctx->g;
-  const size_t n = (size_t)3 * g.nown * kLStencil;
+  const size_t n = matL_doubles(g);
   std::vector<double> tmp(n);
   XPIC_HIP(hipMemcpyAsync(tmp.data(), ctx->matL, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
   XPIC_HIP(hipStreamSynchronize(ctx->stream));
@@ -443,7 +457,7 @@ int xpic_matL_get(xpic_ctx* ctx, double* out)
       for (int y = 0; y < g.ny; ++y)
         for (int k = 0; k < kLStencil; ++k)
           for (int x = 0; x < g.nx; ++x) {
-            size_t src = ((((size_t)c1 * g.nzl + z) * g.ny + y) * kLStencil + k) * g.nx + x;
+            size_t src = ((((size_t)c1 * (g.nzl + (g.G ? 2 : 0)) + z + (g.G ? 1 : 0)) * g.ny + y) * kLStencil + k) * g.nx + x;
             size_t row = (((size_t)z * g.ny + y) * g.nx + x) * 3 + c1;
             out[row * kLStencil + k] = tmp[src];
           }
@@ -497,6 +511,7 @@ int xpic_basic_push(xpic_ctx* ctx, int sort)
   XPIC_CALL(halo_fill(ctx, ctx->field[XPIC_B]));
   XPIC_HIP(hipMemsetAsync(s.J, 0, sizeof(double) * ctx->nvec, ctx->stream));
   XPIC_CALL(esirkepov_push(ctx, s, 0, ctx->field[XPIC_E], ctx->field[XPIC_B], s.J, nullptr));
+  XPIC_CALL(halo_add(ctx, s.J, 3));
   return vec_axpy(ctx, ctx->field[XPIC_J], 1.0, s.J);
 }
 
@@ -517,6 +532,7 @@ int xpic_ecsimcorr_second_push(xpic_ctx* ctx, int sort)
   XPIC_CALL(halo_fill(ctx, ctx->field[XPIC_EP]));
   XPIC_CALL(halo_fill(ctx, ctx->field[XPIC_B]));
   XPIC_CALL(esirkepov_push(ctx, s, 2, ctx->field[XPIC_EP], ctx->field[XPIC_B], s.currJe, &s.pred_w));
+  XPIC_CALL(halo_add(ctx, s.currJe, 3));
   return vec_axpy(ctx, ctx->field[XPIC_CURRJE], 1.0, s.currJe);
 }
 
@@ -540,7 +556,7 @@ int xpic_calculate_energy(xpic_ctx* ctx, int sort, double* energy)
   CTX_CHECK(ctx); SORT_CHECK(sort);
   Sort& s = ctx->sorts[sort];
   double o[5];
-  XPIC_CALL(kinetic_sums_host(ctx, s, o));
+  XPIC_CALL(kinetic_sums_global(ctx, s, o));
   s.energy = 0.5 * s.par.m * (s.par.n / s.par.Np) * o[3];
   if (energy) *energy = s.energy;
   return 0;
@@ -599,13 +615,13 @@ int xpic_energy(xpic_ctx* ctx, double* out)
   for (size_t i = 0; i < ctx->sorts.size(); ++i) {
     Sort& s = ctx->sorts[i];
     double o[5];
-    XPIC_CALL(kinetic_sums_host(ctx, s, o));
+    XPIC_CALL(kinetic_sums_global(ctx, s, o));
     const double frac = 0.5 * s.par.m * (s.par.n / (double)s.par.Np);
     double K = frac * o[3], sK = 0;
-    if (s.n == 0) K = 0;
+    if (o[4] == 0) K = 0;
     else {
-      const double sv = o[3] - (o[0] * o[0] + o[1] * o[1] + o[2] * o[2]) / (double)s.n;
-      sK = frac * std::sqrt(std::fabs(sv) / (double)s.n);
+      const double sv = o[3] - (o[0] * o[0] + o[1] * o[1] + o[2] * o[2]) / o[4];
+      sK = frac * std::sqrt(std::fabs(sv) / o[4]);
     }
     out[4 + 2 * i] = K;
     out[5 + 2 * i] = sK;

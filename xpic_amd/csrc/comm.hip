@@ -1,0 +1,148 @@
+// comm.hip -- the exchange layer of the z-slab decomposition (replaces the reference's MPI / PetscSF traffic,
+// SURVEY.md section 2.2 C1-C11): ring send/receive with the two z-neighbours and a sum all-reduce.
+//   kind 1: RCCL over xGMI, straight on device buffers, on the context's stream (production);
+//   kind 2: host callbacks (buffers staged through pinned host memory) -- lets tests drive two ranks that
+//           share one GPU through torch.distributed/gloo;
+//   kind 0: single rank, every call is a no-op.
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "common.h"
+
+namespace xpic {
+
+#define XPIC_NCCL(call)                                                                              \
+  do {                                                                                               \
+    ncclResult_t r_ = (call);                                                                        \
+    if (r_ != ncclSuccess) {                                                                         \
+      set_error(std::string(#call) + ": " + ncclGetErrorString(r_) + " at " __FILE__ ":" + std::to_string(__LINE__)); \
+      return 7;                                                                                      \
+    }                                                                                                \
+  } while (0)
+
+static int ensure_host(xpic_ctx* c, size_t bytes)
+{
+  if (c->comm.host_bytes >= bytes) return 0;
+  for (int i = 0; i < 4; ++i) {
+    if (c->comm.host[i]) XPIC_HIP(hipHostFree(c->comm.host[i]));
+    XPIC_HIP(hipHostMalloc(&c->comm.host[i], bytes));
+  }
+  c->comm.host_bytes = bytes;
+  return 0;
+}
+
+// send `down` to rank-1 and `up` to rank+1; receive the up-neighbour's `down` message into from_up and the
+// down-neighbour's `up` message into from_down.  All pointers are device pointers; sizes in bytes.
+int comm_ring(xpic_ctx* c, const void* down, size_t ndown, const void* up, size_t nup, void* from_up, size_t nfrom_up,
+  void* from_down, size_t nfrom_down)
+{
+  Comm& m = c->comm;
+  XPIC_CHECK(m.kind != 0, "comm_ring called on a single-rank context");
+  const int lo = (m.rank - 1 + m.nranks) % m.nranks, hi = (m.rank + 1) % m.nranks;
+  if (m.kind == 1) {
+    ncclComm_t nc = (ncclComm_t)m.nccl;
+    XPIC_NCCL(ncclGroupStart());
+    if (ndown) XPIC_NCCL(ncclSend(down, ndown, ncclChar, lo, nc, c->stream));
+    if (nup) XPIC_NCCL(ncclSend(up, nup, ncclChar, hi, nc, c->stream));
+    if (nfrom_up) XPIC_NCCL(ncclRecv(from_up, nfrom_up, ncclChar, hi, nc, c->stream));
+    if (nfrom_down) XPIC_NCCL(ncclRecv(from_down, nfrom_down, ncclChar, lo, nc, c->stream));
+    XPIC_NCCL(ncclGroupEnd());
+    return 0;
+  }
+  size_t mx = ndown;
+  if (nup > mx) mx = nup;
+  if (nfrom_up > mx) mx = nfrom_up;
+  if (nfrom_down > mx) mx = nfrom_down;
+  XPIC_CALL(ensure_host(c, mx));
+  if (ndown) XPIC_HIP(hipMemcpyAsync(m.host[0], down, ndown, hipMemcpyDeviceToHost, c->stream));
+  if (nup) XPIC_HIP(hipMemcpyAsync(m.host[1], up, nup, hipMemcpyDeviceToHost, c->stream));
+  XPIC_HIP(hipStreamSynchronize(c->stream));
+  int rc = m.cb.sendrecv(m.cb.user, m.host[0], ndown, m.host[1], nup, m.host[2], nfrom_up, m.host[3], nfrom_down);
+  XPIC_CHECK(rc == 0, "comm callback sendrecv failed");
+  if (nfrom_up) XPIC_HIP(hipMemcpyAsync(from_up, m.host[2], nfrom_up, hipMemcpyHostToDevice, c->stream));
+  if (nfrom_down) XPIC_HIP(hipMemcpyAsync(from_down, m.host[3], nfrom_down, hipMemcpyHostToDevice, c->stream));
+  XPIC_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int comm_allreduce_sum(xpic_ctx* c, double* dbuf, int n)
+{
+  Comm& m = c->comm;
+  if (m.kind == 0 || n == 0) return 0;
+  if (m.kind == 1) {
+    XPIC_NCCL(ncclAllReduce(dbuf, dbuf, n, ncclDouble, ncclSum, (ncclComm_t)m.nccl, c->stream));
+    return 0;
+  }
+  XPIC_CALL(ensure_host(c, sizeof(double) * n));
+  XPIC_HIP(hipMemcpyAsync(m.host[0], dbuf, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  XPIC_HIP(hipStreamSynchronize(c->stream));
+  int rc = m.cb.allreduce_sum(m.cb.user, (double*)m.host[0], n);
+  XPIC_CHECK(rc == 0, "comm callback allreduce failed");
+  XPIC_HIP(hipMemcpyAsync(dbuf, m.host[0], sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+int comm_allreduce_sum_host(xpic_ctx* c, double* hbuf, int n)
+{
+  if (c->comm.kind == 0 || n == 0) return 0;
+  XPIC_CHECK(n <= 32, "host all-reduce limited to 32 values");
+  double* d = c->red_out + 32;
+  XPIC_HIP(hipMemcpyAsync(d, hbuf, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  XPIC_CALL(comm_allreduce_sum(c, d, n));
+  XPIC_HIP(hipMemcpyAsync(hbuf, d, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  XPIC_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+void comm_free(xpic_ctx* c)
+{
+  if (c->comm.kind == 1 && c->comm.nccl) (void)ncclCommDestroy((ncclComm_t)c->comm.nccl);
+  for (int i = 0; i < 4; ++i)
+    if (c->comm.host[i]) (void)hipHostFree(c->comm.host[i]);
+  c->comm = Comm{};
+}
+
+}  // namespace xpic
+
+using namespace xpic;
+
+extern "C" {
+
+int xpic_comm_rccl_unique_id(void* id128)
+{
+  XPIC_CHECK(id128, "null argument");
+  ncclUniqueId id;
+  XPIC_NCCL(ncclGetUniqueId(&id));
+  memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+  return 0;
+}
+
+int xpic_comm_init_rccl(xpic_ctx* ctx, const void* id128)
+{
+  XPIC_CHECK(ctx && id128, "null argument");
+  XPIC_CHECK(ctx->geom.nranks > 1, "context was created with nranks == 1");
+  ncclUniqueId id;
+  memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+  ncclComm_t nc;
+  XPIC_HIP(hipSetDevice(ctx->geom.device));
+  XPIC_NCCL(ncclCommInitRank(&nc, ctx->geom.nranks, id, ctx->geom.rank));
+  ctx->comm.kind = 1;
+  ctx->comm.nccl = nc;
+  ctx->comm.rank = ctx->geom.rank;
+  ctx->comm.nranks = ctx->geom.nranks;
+  return 0;
+}
+
+int xpic_comm_init_callbacks(xpic_ctx* ctx, const xpic_comm_callbacks* cb)
+{
+  XPIC_CHECK(ctx && cb && cb->sendrecv && cb->allreduce_sum, "null argument");
+  XPIC_CHECK(ctx->geom.nranks > 1, "context was created with nranks == 1");
+  ctx->comm.kind = 2;
+  ctx->comm.cb = *cb;
+  ctx->comm.rank = ctx->geom.rank;
+  ctx->comm.nranks = ctx->geom.nranks;
+  return 0;
+}
+
+}  // extern "C"

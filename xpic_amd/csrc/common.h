@@ -90,7 +90,21 @@ struct Sort {
   double* J = nullptr;      // basic: J
   double* currI = nullptr;  // ecsim: currI
   double* currJe = nullptr; // ecsimcorr: currJe
+  // particle migration between z-slabs (nranks > 1)
+  double* mig_send[2] = {nullptr, nullptr};
+  double* mig_recv = nullptr;
+  int *mig_cell = nullptr, *mig_rank = nullptr, *mig_count = nullptr;
+  int mig_cap = 0;
   double energy = 0, pred_w = 0, corr_w = 0, pred_dK = 0, corr_dK = 0, lambda_dK = 0;
+};
+
+struct Comm {
+  int kind = 0; // 0 single rank, 1 RCCL, 2 host callbacks
+  int rank = 0, nranks = 1;
+  void* nccl = nullptr;
+  xpic_comm_callbacks cb{};
+  void* host[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t host_bytes = 0;
 };
 
 struct ProfileEntry {
@@ -122,6 +136,9 @@ struct xpic_ctx {
   long scan_tmp_n = 0;
   double rtol = 1e-7, atol = 1e-7;
   int maxit = 100;
+  xpic::Comm comm;
+  double* halo_buf[4] = {}; // send down, send up, recv from up, recv from down
+  size_t halo_bytes = 0;
   bool profiling = false;
   std::map<std::string, xpic::ProfileEntry> prof;
   std::vector<hipEvent_t> event_pool;
@@ -161,7 +178,9 @@ int matA_apply(xpic_ctx* c, const double* x, double* y);
 int field_import(xpic_ctx* c, double* dst_soa, const double* src_aos_host);
 int field_export(xpic_ctx* c, const double* src_soa, double* dst_aos_host);
 int field_stats_host(xpic_ctx* c, const double* f, double* sumsq, double* mean3);
-int halo_fill(xpic_ctx* c, double* f); // ghost planes <- periodic images (no-op when G == 0)
+int halo_fill(xpic_ctx* c, double* f, int width = 3); // ghost planes <- neighbours' owned planes (no-op when G == 0)
+int halo_add(xpic_ctx* c, double* f, int width);      // owned planes += neighbours' ghost planes (DMLocalToGlobal ADD)
+int matL_exchange_ghost_rows(xpic_ctx* c);
 
 // particles.hip
 int sort_alloc(xpic_ctx* c, Sort& s, int64_t cap);
@@ -172,7 +191,8 @@ int sort_append_host(xpic_ctx* c, Sort& s, int64_t n, const double* pts6, int64_
 int sort_download(xpic_ctx* c, Sort& s, double* pts6, int32_t* cell_of);
 int sort_fill_synthetic(xpic_ctx* c, Sort& s, int ppc, double vth, uint64_t seed);
 int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B);
-int kinetic_sums_host(xpic_ctx* c, Sort& s, double* out5); // sum vx, vy, vz, v^2, count
+int kinetic_sums_host(xpic_ctx* c, Sort& s, double* out5);   // local sums of vx, vy, vz, v^2 and the count
+int kinetic_sums_global(xpic_ctx* c, Sort& s, double* out5); // summed over the slabs
 int scale_velocities(xpic_ctx* c, Sort& s, double lambda);
 
 // ecsim.hip
@@ -181,6 +201,14 @@ int build_ltab(xpic_ctx* c);
 
 // esirkepov.hip: mode 0 basic::push, 1 ecsimcorr first_push, 2 ecsimcorr second_push
 int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double* B, double* J, double* pred_w_host);
+
+// comm.hip
+int comm_ring(xpic_ctx* c, const void* down, size_t ndown, const void* up, size_t nup, void* from_up, size_t nfrom_up,
+  void* from_down, size_t nfrom_down);
+int comm_allreduce_sum(xpic_ctx* c, double* dbuf, int n);
+int comm_allreduce_sum_host(xpic_ctx* c, double* hbuf, int n);
+void comm_free(xpic_ctx* c);
+int ensure_halo_buf(xpic_ctx* c, size_t bytes);
 
 // krylov.hip
 int solve(xpic_ctx* c, int op, const double* rhs, double* x, double rtol, double atol, int maxit, int* its,

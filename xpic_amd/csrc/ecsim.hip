@@ -119,9 +119,11 @@ __global__ void __launch_bounds__(kThreads) k_ecsim_fill(GridDev g, SortDev s, c
     const int ld = linetab[line];
     const int ry = g.wy(cy + ((ld >> 2) & 3) - 1);
     const int rz = cz + ((ld >> 4) & 3) - 1;
-    const int rzw = rz < 0 ? rz + g.nzl : (rz >= g.nzl ? rz - g.nzl : rz);
+    // single slab: periodic fold; with z-neighbours matL carries one ghost row plane on each side
+    const int rzw = g.G == 0 ? (rz < 0 ? rz + g.nzl : (rz >= g.nzl ? rz - g.nzl : rz)) : rz + 1;
+    const int nzp = g.nzl + (g.G ? 2 : 0);
     lbase[line] = line < kMatLines
-      ? matL + ((((long)(ld & 3) * g.nzl + rzw) * g.ny + ry) * kLStencil + (ld >> 6)) * g.nx
+      ? matL + ((((long)(ld & 3) * nzp + rzw) * g.ny + ry) * kLStencil + (ld >> 6)) * g.nx
       : currI + (ld & 3) * g.cstride + g.node(0, ry, g.wz(rz));
   }
 
@@ -397,7 +399,6 @@ static void colour_class(int n, int colour, int* first, int* step, int* count)
 int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, double* matL)
 {
   if (s.n == 0) return 0;
-  XPIC_CHECK(c->g.G == 0, "ecsim_fill: ghost-row exchange for nranks > 1 is not built yet");
   Timed t(c, "fill_current");
   const GridDev& g = c->g;
   const int ncol_y = 3 + g.ny % 3, ncol_z = 3 + g.nzl % 3;

@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(kThreadsB) k_esirkepov_push(GridDev g, SortDev
           }
         }
         if (!ok) {
-          // the reference would overflow Shape::shape here; deposit nothing and report (like the oracle)
+          // the reference would overflow Shape::shape here; deposit nothing and report
           ++bad;
 #pragma unroll
           for (int e = 0; e < kSRows; ++e) col[e * kBPad] = 0.0;
@@ -285,7 +285,6 @@ int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double
 {
   if (pred_w_host) *pred_w_host = 0.0;
   if (s.n == 0) return 0;
-  XPIC_CHECK(c->g.G == 0, "esirkepov_push: halo exchange for nranks > 1 is not built yet");
   const GridDev& g = c->g;
   XPIC_CHECK(g.nx >= 6 && g.ny >= 6 && g.nzl >= 6, "the Esirkepov tile needs every grid extent >= 6");
   const double qm = s.par.q / s.par.m;
@@ -309,7 +308,11 @@ int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double
   XPIC_HIP(hipStreamSynchronize(c->stream));
   int bad;
   memcpy(&bad, &c->red_host[1], sizeof(int));
-  if (pred_w_host) *pred_w_host = c->red_host[0];
+  if (pred_w_host) {
+    double pw = c->red_host[0];
+    XPIC_CALL(comm_allreduce_sum_host(c, &pw, 1)); // MPI_Allreduce(pred_w), ecsimcorr/particles.cpp:85
+    *pred_w_host = pw;
+  }
   if (bad) {
     set_error(std::to_string(bad) + " particle(s) moved more than one cell in an Esirkepov step "
       "(the reference overflows Shape::shape[] here, src/utils/shape.h:18,91-92)");

@@ -154,6 +154,7 @@ int finish_reduce(xpic_ctx* c, int nv, int nblocks, int nseg, double* host_out)
 {
   hipLaunchKernelGGL(k_reduce_final, dim3(nv * nseg), dim3(kBlock), 0, c->stream, c->red_partial, nblocks, nseg, c->red_out);
   XPIC_HIP(hipGetLastError());
+  XPIC_CALL(comm_allreduce_sum(c, c->red_out, nv * nseg)); // the MPI_Allreduce inside VecDot/VecMDot/VecNorm
   XPIC_HIP(hipMemcpyAsync(c->red_host, c->red_out, sizeof(double) * nv * nseg, hipMemcpyDeviceToHost, c->stream));
   XPIC_HIP(hipStreamSynchronize(c->stream));
   for (int i = 0; i < nv * nseg; ++i) host_out[i] = c->red_host[i];
@@ -276,7 +277,7 @@ __device__ __forceinline__ double row_apply(std::integer_sequence<int, Ks...>, c
   const double* __restrict__ L, const double* __restrict__ X, int x, int y, int z)
 {
   RowCtx r;
-  r.Lb = reinterpret_cast<const char*>(L + ((((long)C1 * g.nzl + z) * g.ny + y) * kLStencil) * g.nx);
+  r.Lb = reinterpret_cast<const char*>(L + ((((long)C1 * (g.nzl + (g.G ? 2 : 0)) + z + (g.G ? 1 : 0)) * g.ny + y) * kLStencil) * g.nx);
   r.Xb = reinterpret_cast<const char*>(X);
   r.x8 = 8u * (unsigned)x;
   r.nx8 = 8u * (unsigned)g.nx;
@@ -505,7 +506,7 @@ int field_import(xpic_ctx* c, double* dst, const double* src_host)
   XPIC_HIP(hipGetLastError());
   XPIC_HIP(hipStreamSynchronize(c->stream));
   XPIC_HIP(hipFree(tmp));
-  return halo_fill(c, dst);
+  return 0; // ghost planes are refreshed by whoever reads them next (halo_fill is collective over the slabs)
 }
 
 int field_export(xpic_ctx* c, const double* src, double* dst_host)
@@ -523,12 +524,115 @@ int field_export(xpic_ctx* c, const double* src, double* dst_host)
   return 0;
 }
 
-int halo_fill(xpic_ctx* c, double* f)
+// ---- z-halo exchange (DMGlobalToLocal / DMLocalToGlobal(ADD) of the slab decomposition) --------------
+namespace {
+
+// buf[c][w][plane] <-> f[c][zs0 + w][plane]
+template <int OP> // 0: pack f -> buf, 1: unpack buf -> f, 2: add buf into f
+__global__ void __launch_bounds__(kBlock) k_planes(GridDev g, double* f, double* buf, int zs0, int width)
 {
-  (void)f;
-  if (c->g.G == 0) return 0;
-  set_error("halo exchange for nranks > 1 is not built yet");
-  return 3;
+  const long per = (long)width * g.plane;
+  const long n = 3 * per;
+  const long stride = (long)gridDim.x * kBlock;
+  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const int c = (int)(i / per);
+    const long o = c * g.cstride + (long)zs0 * g.plane + (i % per);
+    if (OP == 0) buf[i] = f[o];
+    else if (OP == 1) f[o] = buf[i];
+    else f[o] += buf[i];
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_add_into(double* dst, const double* src, long n)
+{
+  const long stride = (long)gridDim.x * kBlock;
+  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) dst[i] += src[i];
+}
+
+inline unsigned plane_grid(long n)
+{
+  long b = (n + kBlock - 1) / kBlock;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+int ensure_halo_buf(xpic_ctx* c, size_t bytes)
+{
+  if (c->halo_bytes >= bytes) return 0;
+  for (int i = 0; i < 4; ++i) {
+    if (c->halo_buf[i]) XPIC_HIP(hipFree(c->halo_buf[i]));
+    XPIC_HIP(hipMalloc(&c->halo_buf[i], bytes));
+  }
+  c->halo_bytes = bytes;
+  return 0;
+}
+
+int halo_fill(xpic_ctx* c, double* f, int width)
+{
+  const GridDev& g = c->g;
+  if (g.G == 0) return 0;
+  XPIC_CHECK(width <= g.G && width <= g.nzl, "halo width exceeds the ghost layer");
+  Timed t(c, "halo");
+  const long n = 3L * width * g.plane;
+  const size_t bytes = sizeof(double) * n;
+  XPIC_CALL(ensure_halo_buf(c, bytes));
+  const unsigned nb = plane_grid(n);
+  // my bottom owned planes go down, my top owned planes go up
+  hipLaunchKernelGGL(k_planes<0>, dim3(nb), dim3(kBlock), 0, c->stream, g, f, c->halo_buf[0], g.G, width);
+  hipLaunchKernelGGL(k_planes<0>, dim3(nb), dim3(kBlock), 0, c->stream, g, f, c->halo_buf[1], g.G + g.nzl - width, width);
+  XPIC_HIP(hipGetLastError());
+  XPIC_CALL(comm_ring(c, c->halo_buf[0], bytes, c->halo_buf[1], bytes, c->halo_buf[2], bytes, c->halo_buf[3], bytes));
+  // from the upper neighbour: its bottom planes = my upper ghost; from the lower: its top planes = my lower ghost
+  hipLaunchKernelGGL(k_planes<1>, dim3(nb), dim3(kBlock), 0, c->stream, g, f, c->halo_buf[2], g.G + g.nzl, width);
+  hipLaunchKernelGGL(k_planes<1>, dim3(nb), dim3(kBlock), 0, c->stream, g, f, c->halo_buf[3], g.G - width, width);
+  XPIC_HIP(hipGetLastError());
+  return 0;
+}
+
+int halo_add(xpic_ctx* c, double* f, int width)
+{
+  const GridDev& g = c->g;
+  if (g.G == 0) return 0;
+  XPIC_CHECK(width <= g.G && width <= g.nzl, "halo width exceeds the ghost layer");
+  Timed t(c, "halo");
+  const long n = 3L * width * g.plane;
+  const size_t bytes = sizeof(double) * n;
+  XPIC_CALL(ensure_halo_buf(c, bytes));
+  const unsigned nb = plane_grid(n);
+  // what I deposited below my slab belongs to the lower neighbour's top planes, above -> upper neighbour's bottom
+  hipLaunchKernelGGL(k_planes<0>, dim3(nb), dim3(kBlock), 0, c->stream, g, f, c->halo_buf[0], g.G - width, width);
+  hipLaunchKernelGGL(k_planes<0>, dim3(nb), dim3(kBlock), 0, c->stream, g, f, c->halo_buf[1], g.G + g.nzl, width);
+  XPIC_HIP(hipGetLastError());
+  XPIC_CALL(comm_ring(c, c->halo_buf[0], bytes, c->halo_buf[1], bytes, c->halo_buf[2], bytes, c->halo_buf[3], bytes));
+  hipLaunchKernelGGL(k_planes<2>, dim3(nb), dim3(kBlock), 0, c->stream, g, f, c->halo_buf[2], g.G + g.nzl - width, width);
+  hipLaunchKernelGGL(k_planes<2>, dim3(nb), dim3(kBlock), 0, c->stream, g, f, c->halo_buf[3], g.G, width);
+  XPIC_HIP(hipGetLastError());
+  return 0;
+}
+
+// matL rows of the first ghost plane below / above the slab were filled by cells of this rank but belong to the
+// neighbours (MatSetValuesCOO ships such entries to the owner, src/impls/ecsim/simulation.cpp:366): send and add.
+int matL_exchange_ghost_rows(xpic_ctx* c)
+{
+  const GridDev& g = c->g;
+  if (g.G == 0) return 0;
+  Timed t(c, "matL_ghost_rows");
+  const long per = (long)g.ny * kLStencil * g.nx; // one z-plane of one component
+  const size_t bytes = sizeof(double) * per;
+  XPIC_CALL(ensure_halo_buf(c, bytes));
+  const int nzp = g.nzl + 2;
+  for (int c1 = 0; c1 < 3; ++c1) {
+    double* base = c->matL + (long)c1 * nzp * per;
+    XPIC_CALL(comm_ring(c, base, bytes, base + (long)(nzp - 1) * per, bytes, c->halo_buf[2], bytes, c->halo_buf[3], bytes));
+    // upper neighbour's ghost-below rows are my top owned plane; lower neighbour's ghost-above rows my bottom plane
+    hipLaunchKernelGGL(k_add_into, dim3(plane_grid(per)), dim3(kBlock), 0, c->stream, base + (long)g.nzl * per, c->halo_buf[2], per);
+    hipLaunchKernelGGL(k_add_into, dim3(plane_grid(per)), dim3(kBlock), 0, c->stream, base + per, c->halo_buf[3], per);
+    XPIC_HIP(hipGetLastError());
+  }
+  return 0;
 }
 
 }  // namespace xpic

@@ -13,8 +13,9 @@ namespace {
 
 constexpr int kRestart = 30;
 
-int apply_op(xpic_ctx* c, int op, const double* x, double* y)
+int apply_op(xpic_ctx* c, int op, double* x, double* y)
 {
+  XPIC_CALL(halo_fill(c, x, 2)); // the VecScatter inside MatMult: matL reaches 2 planes, matM 1
   if (op == XPIC_OP_MATA_GMRES) return matA_apply(c, x, y);
   return matM_apply(c, x, y, false);
 }

@@ -17,24 +17,61 @@ inline unsigned pgrid(int64_t n, int per_thread = 1)
   return (unsigned)b;
 }
 
-// pass 1 of update_cells: (BorisPush::update_r) + correct_coordinates + new cell + arrival rank in it
-template <bool MOVE, bool WRAP>
-__global__ void __launch_bounds__(kBlock) k_move_bin(GridDev g, SortDev s, int64_t n, double step)
+// destination of a (moved, wrapped) position in the slab decomposition:
+//   >= 0 local cell, -1 dropped (outside the global box), -2 / -3 owned by the lower / upper z-neighbour,
+//   -4 further away than a neighbour (reported as an error)
+__device__ inline int dest_of(const GridDev& g, int rank, int nranks, double x, double y, double z)
+{
+  const int cx = (int)floor(x / g.dx), cy = (int)floor(y / g.dy), czg = (int)floor(z / g.dz);
+  if (cx < 0 || cx >= g.nx || cy < 0 || cy >= g.ny || czg < 0 || czg >= g.nzg) return -1;
+  const int dest = czg / g.nzl;
+  if (dest == rank) return ((czg - g.z0) * g.ny + cy) * g.nx + cx;
+  if (dest == (rank + 1) % nranks) return -3;
+  if (dest == (rank - 1 + nranks) % nranks) return -2;
+  return -4;
+}
+
+struct Migr {
+  int rank, nranks;
+  double* send[2];   // outgoing Point records for the lower / upper neighbour
+  int* sendcount;    // [0] down, [1] up, [2] error flags
+  int send_cap;
+};
+
+// pass 1 of update_cells: (BorisPush::update_r) + correct_coordinates + new cell + arrival rank in it;
+// with MIG also the send side of update_cells_mpi (src/interfaces/particles.cpp:118-181)
+template <bool MOVE, bool WRAP, bool MIG>
+__global__ void __launch_bounds__(kBlock) k_move_bin(GridDev g, SortDev s, int64_t n, double step, Migr mg)
 {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= n) return; // whole trailing lanes drop out together: ballots below only see live lanes
   double x = s.r[0][p], y = s.r[1][p], z = s.r[2][p];
+  double vx = 0, vy = 0, vz = 0;
+  if (MOVE || MIG) { vx = s.v[0][p]; vy = s.v[1][p]; vz = s.v[2][p]; }
   if (MOVE) {
-    x += s.v[0][p] * step;
-    y += s.v[1][p] * step;
-    z += s.v[2][p] * step;
+    x += vx * step;
+    y += vy * step;
+    z += vz * step;
   }
   if (WRAP) {
     x = bound_periodic(x, g.Lx);
     y = bound_periodic(y, g.Ly);
     z = bound_periodic(z, g.Lz);
   }
-  const int c = cell_of(g, x, y, z);
+  int c = MIG ? dest_of(g, mg.rank, mg.nranks, x, y, z) : cell_of(g, x, y, z);
+  if (MIG && c <= -2) {
+    if (c == -4) { atomicOr(&mg.sendcount[2], 1); c = -1; }
+    else {
+      const int dir = c == -2 ? 0 : 1;
+      const int idx = atomicAdd(&mg.sendcount[dir], 1);
+      if (idx < mg.send_cap) {
+        double* o = mg.send[dir] + 6L * idx;
+        o[0] = x; o[1] = y; o[2] = z; o[3] = vx; o[4] = vy; o[5] = vz;
+      }
+      else atomicOr(&mg.sendcount[2], 2);
+      c = -1;
+    }
+  }
   s.cell[p] = c;
   // Arrival rank inside the new cell.  The input is (nearly) cell-sorted, so a wave sees a handful of distinct
   // cells: one returning atomic per distinct cell and wave instead of one per particle.
@@ -52,6 +89,32 @@ __global__ void __launch_bounds__(kBlock) k_move_bin(GridDev g, SortDev s, int64
     todo &= ~same;
   }
   s.rank[p] = rank;
+}
+
+// receive side of update_cells_mpi (:226-241): bin what the neighbours sent
+__global__ void __launch_bounds__(kBlock) k_bin_incoming(GridDev g, SortDev s, const double* inc, int n, int* inc_cell,
+  int* inc_rank, int* err)
+{
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int c = cell_of(g, inc[6L * i], inc[6L * i + 1], inc[6L * i + 2]);
+  inc_cell[i] = c;
+  if (c >= 0) inc_rank[i] = atomicAdd(&s.cell_count[c], 1);
+  else atomicOr(err, 4);
+}
+
+__global__ void __launch_bounds__(kBlock) k_scatter_incoming(SortDev s, const double* inc, int n, const int* inc_cell,
+  const int* inc_rank)
+{
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int c = inc_cell[i];
+  if (c < 0) return;
+  const int64_t d = (int64_t)s.cell_start[c] + inc_rank[i];
+  for (int a = 0; a < 3; ++a) {
+    s.r2[a][d] = inc[6L * i + a];
+    s.v2[a][d] = inc[6L * i + 3 + a];
+  }
 }
 
 // pass 2: recompute the moved + wrapped position (bitwise the same arithmetic) and scatter the record
@@ -326,6 +389,17 @@ int sort_alloc(xpic_ctx* c, Sort& s, int64_t cap)
   XPIC_HIP(hipMalloc(&s.d.cell_start, sizeof(int) * (c->ncell + 1)));
   XPIC_HIP(hipMemsetAsync(s.d.cell_count, 0, sizeof(int) * (c->ncell + 1), c->stream));
   XPIC_HIP(hipMemsetAsync(s.d.cell_start, 0, sizeof(int) * (c->ncell + 1), c->stream));
+  if (c->geom.nranks > 1) {
+    int64_t mc = cap / 8;
+    if (mc < 65536) mc = 65536;
+    s.mig_cap = (int)mc;
+    XPIC_HIP(hipMalloc(&s.mig_send[0], sizeof(double) * 6 * mc));
+    XPIC_HIP(hipMalloc(&s.mig_send[1], sizeof(double) * 6 * mc));
+    XPIC_HIP(hipMalloc(&s.mig_recv, sizeof(double) * 6 * mc));
+    XPIC_HIP(hipMalloc(&s.mig_cell, sizeof(int) * mc));
+    XPIC_HIP(hipMalloc(&s.mig_rank, sizeof(int) * mc));
+    XPIC_HIP(hipMalloc(&s.mig_count, sizeof(int) * 8));
+  }
   s.n = 0;
   return 0;
 }
@@ -337,31 +411,76 @@ void sort_free(Sort& s)
   }
   (void)hipFree(s.d.cell); (void)hipFree(s.d.rank); (void)hipFree(s.d.cell_count); (void)hipFree(s.d.cell_start);
   (void)hipFree(s.J); (void)hipFree(s.currI); (void)hipFree(s.currJe);
+  (void)hipFree(s.mig_send[0]); (void)hipFree(s.mig_send[1]); (void)hipFree(s.mig_recv);
+  (void)hipFree(s.mig_cell); (void)hipFree(s.mig_rank); (void)hipFree(s.mig_count);
   s = Sort{};
 }
 
 // (optional) r += step*v, periodic wrap, re-bin, drop what left the box: the whole of
-// first_push + update_cells_seq (src/impls/ecsim/particles.cpp:21-31, src/interfaces/particles.cpp:79-116)
+// first_push + update_cells_seq (src/impls/ecsim/particles.cpp:21-31, src/interfaces/particles.cpp:79-116);
+// with nranks > 1 also update_cells_mpi (:118-248): leavers go to the z-neighbours, arrivals are binned in.
 int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap)
 {
   XPIC_HIP(hipMemsetAsync(s.d.cell_count, 0, sizeof(int) * (c->ncell + 1), c->stream));
   const bool move = step != 0.0;
+  const bool mig = c->comm.kind != 0;
+  Migr mg{};
+  if (mig) {
+    mg.rank = c->comm.rank; mg.nranks = c->comm.nranks;
+    mg.send[0] = s.mig_send[0]; mg.send[1] = s.mig_send[1];
+    mg.sendcount = s.mig_count; mg.send_cap = s.mig_cap;
+    XPIC_HIP(hipMemsetAsync(s.mig_count, 0, sizeof(int) * 4, c->stream));
+  }
   if (s.n > 0) {
     Timed t(c, "move_bin");
     const unsigned nb = pgrid(s.n);
-#define LAUNCH(M, W) hipLaunchKernelGGL((k_move_bin<M, W>), dim3(nb), dim3(kBlock), 0, c->stream, c->g, s.d, s.n, step)
-    if (move && wrap) LAUNCH(true, true);
-    else if (move) LAUNCH(true, false);
-    else if (wrap) LAUNCH(false, true);
-    else LAUNCH(false, false);
+#define LAUNCH(M, W, G) hipLaunchKernelGGL((k_move_bin<M, W, G>), dim3(nb), dim3(kBlock), 0, c->stream, c->g, s.d, s.n, step, mg)
+    if (mig) {
+      if (move && wrap) LAUNCH(true, true, true);
+      else if (move) LAUNCH(true, false, true);
+      else if (wrap) LAUNCH(false, true, true);
+      else LAUNCH(false, false, true);
+    }
+    else {
+      if (move && wrap) LAUNCH(true, true, false);
+      else if (move) LAUNCH(true, false, false);
+      else if (wrap) LAUNCH(false, true, false);
+      else LAUNCH(false, false, false);
+    }
 #undef LAUNCH
     XPIC_HIP(hipGetLastError());
+  }
+  int n_in = 0;
+  if (mig) {
+    Timed t(c, "migrate");
+    // counts first (MPI_Isend/Irecv of o_num/i_num, particles.cpp:183-197), then the Point records (:199-208)
+    int hc[4];
+    XPIC_HIP(hipMemcpyAsync(hc, s.mig_count, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
+    XPIC_HIP(hipStreamSynchronize(c->stream));
+    XPIC_CHECK((hc[2] & 1) == 0, "a particle moved further than the neighbouring z-slab in one step");
+    XPIC_CHECK((hc[2] & 2) == 0, "particle migration buffer overflow");
+    int* cnt = s.mig_count + 4; // [4],[5] = my down/up counts (copy), [6],[7] = from up / from down
+    XPIC_HIP(hipMemcpyAsync(cnt, s.mig_count, sizeof(int) * 2, hipMemcpyDeviceToDevice, c->stream));
+    XPIC_CALL(comm_ring(c, cnt, sizeof(int), cnt + 1, sizeof(int), cnt + 2, sizeof(int), cnt + 3, sizeof(int)));
+    int hin[2];
+    XPIC_HIP(hipMemcpyAsync(hin, cnt + 2, sizeof(int) * 2, hipMemcpyDeviceToHost, c->stream));
+    XPIC_HIP(hipStreamSynchronize(c->stream));
+    n_in = hin[0] + hin[1];
+    XPIC_CHECK(n_in <= s.mig_cap, "particle migration receive buffer overflow");
+    XPIC_CALL(comm_ring(c, s.mig_send[0], sizeof(double) * 6 * hc[0], s.mig_send[1], sizeof(double) * 6 * hc[1], s.mig_recv,
+      sizeof(double) * 6 * hin[0], s.mig_recv + 6L * hin[0], sizeof(double) * 6 * hin[1]));
+    if (n_in > 0) {
+      hipLaunchKernelGGL(k_bin_incoming, dim3(pgrid(n_in)), dim3(kBlock), 0, c->stream, c->g, s.d, s.mig_recv, n_in,
+        s.mig_cell, s.mig_rank, s.mig_count + 2);
+      XPIC_HIP(hipGetLastError());
+    }
   }
   int total = 0;
   {
     Timed t(c, "scan");
     XPIC_CALL(exclusive_scan(c, s.d.cell_count, c->ncell, s.d.cell_start, &total));
   }
+  XPIC_CHECK(total <= s.cap, "sort capacity exceeded by incoming particles");
   if (s.n > 0) {
     Timed t(c, "scatter");
     const unsigned nb = pgrid(s.n);
@@ -371,6 +490,10 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap)
     else if (wrap) LAUNCH(false, true);
     else LAUNCH(false, false);
 #undef LAUNCH
+    XPIC_HIP(hipGetLastError());
+  }
+  if (n_in > 0) {
+    hipLaunchKernelGGL(k_scatter_incoming, dim3(pgrid(n_in)), dim3(kBlock), 0, c->stream, s.d, s.mig_recv, n_in, s.mig_cell, s.mig_rank);
     XPIC_HIP(hipGetLastError());
   }
   for (int a = 0; a < 3; ++a) {
@@ -453,6 +576,13 @@ int kinetic_sums_host(xpic_ctx* c, Sort& s, double* out5)
   XPIC_HIP(hipStreamSynchronize(c->stream));
   for (int i = 0; i < 4; ++i) out5[i] = c->red_host[i];
   return 0;
+}
+
+// the MPI_Allreduce of Energy::calculate_kinetic / calculate_energy (energy.cpp:92-93, ecsimcorr/particles.cpp:148)
+int kinetic_sums_global(xpic_ctx* c, Sort& s, double* out5)
+{
+  XPIC_CALL(kinetic_sums_host(c, s, out5));
+  return comm_allreduce_sum_host(c, out5, 5);
 }
 
 int sort_move(xpic_ctx* c, Sort& s, double step)

@@ -1,0 +1,86 @@
+"""One process per GPU: z-slab bookkeeping and the two ways a context gets its communicator.
+
+* `init_rccl(ctx)`  -- production: RCCL over xGMI.  torch.distributed is only the bootstrap channel that carries
+  rank 0's 128-byte ncclUniqueId to the other ranks; all data-path traffic is issued by libxpic_hip.so itself.
+* `GlooRing`        -- tests: a host-staged ring send/receive + all-reduce over torch.distributed (gloo), plugged in
+  through xpic_comm_init_callbacks.  Lets two ranks that share one GPU (or none, for the transport's own tests)
+  exercise the slab code path.
+"""
+import numpy as np
+
+
+def slab(nz, rank, nranks):
+    """(first plane, number of planes) of z-slab `rank`: DMDA with da_processors_z = nranks, equal slabs."""
+    if nz % nranks:
+        raise ValueError("nz must be divisible by the number of z-slabs")
+    nzl = nz // nranks
+    return rank * nzl, nzl
+
+
+def neighbours(rank, nranks):
+    """(lower, upper) z-neighbour in the periodic ring."""
+    return (rank - 1 + nranks) % nranks, (rank + 1) % nranks
+
+
+def init_rccl(ctx, device=None):
+    import torch
+    import torch.distributed as dist
+    import xpic_amd
+
+    rank = dist.get_rank()
+    if dist.get_backend() == "nccl":
+        t = torch.zeros(128, dtype=torch.uint8, device=device or torch.device("cuda", torch.cuda.current_device()))
+    else:
+        t = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        t.copy_(torch.frombuffer(bytearray(xpic_amd.rccl_unique_id()), dtype=torch.uint8))
+    dist.broadcast(t, src=0)
+    ctx.comm_init_rccl(bytes(t.cpu().numpy().tobytes()))
+
+
+class GlooRing:
+    """Ring exchange with the semantics xpic_comm_callbacks asks for, over torch.distributed point-to-point ops.
+    Messages to the same peer (2 ranks: both neighbours are one process) are told apart by tag: 0 = sent downwards,
+    1 = sent upwards."""
+
+    def __init__(self):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.rank = dist.get_rank()
+        self.n = dist.get_world_size()
+        self.lo, self.hi = neighbours(self.rank, self.n)
+
+    def sendrecv(self, down, up, n_from_up, n_from_down):
+        import torch
+
+        dist = self.dist
+        reqs = []
+        keep = []
+        if len(down):
+            t = torch.frombuffer(bytearray(down), dtype=torch.uint8)
+            keep.append(t)
+            reqs.append(dist.isend(t, self.lo, tag=0))
+        if len(up):
+            t = torch.frombuffer(bytearray(up), dtype=torch.uint8)
+            keep.append(t)
+            reqs.append(dist.isend(t, self.hi, tag=1))
+        fu = torch.empty(n_from_up, dtype=torch.uint8)
+        fd = torch.empty(n_from_down, dtype=torch.uint8)
+        if n_from_up:
+            reqs.append(dist.irecv(fu, self.hi, tag=0))  # the upper neighbour's "down" message
+        if n_from_down:
+            reqs.append(dist.irecv(fd, self.lo, tag=1))  # the lower neighbour's "up" message
+        for r in reqs:
+            r.wait()
+        return fu.numpy().tobytes(), fd.numpy().tobytes()
+
+    def allreduce_sum(self, arr):
+        import torch
+
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        self.dist.all_reduce(t)
+        arr[:] = t.numpy()
+
+    def attach(self, ctx):
+        ctx.comm_init_callbacks(self.sendrecv, self.allreduce_sum)
