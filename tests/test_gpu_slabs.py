@@ -19,3 +19,49 @@ def test_slabs_reproduce_single_slab(scheme, world):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
     assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-4000:]
     assert out.stdout.count(" ok") == world
+
+
+def test_rccl_transport_on_a_self_ring():
+    """The RCCL backend itself (ncclSend/ncclRecv ring, ncclAllReduce on the context's stream) on the one GPU we
+    have: a single slab that keeps its ghost planes and is its own lower and upper neighbour (XPIC_FORCE_HALO=1)
+    must reproduce the ghost-free single-slab run."""
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import xpic_amd as X
+
+def build(force):
+    if force: os.environ["XPIC_FORCE_HALO"] = "1"
+    else: os.environ.pop("XPIC_FORCE_HALO", None)
+    rng = np.random.default_rng(3)
+    n, d = (12, 10, 8), (0.5, 0.4, 0.25)
+    ctx = X.Context("ecsimcorr", n, d, 0.2)
+    if force: ctx.comm_init_rccl(X.rccl_unique_id())
+    N = n[0] * n[1] * n[2]
+    s = ctx.add_sort(8, 1.0, -1.0, 1.0, capacity=4 * 8 * N)
+    pts = np.empty((8 * N, 6))
+    pts[:, :3] = rng.random((8 * N, 3)) * (np.array(n) * np.array(d))
+    pts[:, 3:] = rng.normal(0, 0.1, (8 * N, 3))
+    ctx.add_particles(s, pts)
+    B = rng.normal(0, 0.02, ctx.fshape()) + np.array([0.0, 0.1, 0.3])
+    ctx.set_field(X.B, B); ctx.set_field(X.B0, np.zeros(ctx.fshape()) + np.array([0.0, 0.1, 0.3]))
+    ctx.set_field(X.E, rng.normal(0, 0.02, ctx.fshape()))
+    ctx.set_tolerances(1e-12, 1e-50, 400)
+    return ctx
+
+a, b = build(True), build(False)
+for t in range(3):
+    ia, ib = a.step(), b.step()
+    assert abs(ia - ib) <= 2, (ia, ib)
+for f in (X.E, X.B):
+    fa, fb = a.get_field(f), b.get_field(f)
+    assert np.abs(fa - fb).max() <= 1e-8 * np.abs(fb).max()
+assert a.count(0) == b.count(0)
+assert np.allclose(a.energy(), b.energy(), rtol=1e-9)
+print("self-ring ok")
+''' % ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "self-ring ok" in out.stdout

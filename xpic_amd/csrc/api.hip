@@ -1,6 +1,7 @@
 // api.hip -- the C ABI of include/xpic_hip.h: context life cycle, boundary copies, per-phase entry points
 // and the timestep drivers that mirror timestep_implementation() of the reference's schemes.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -249,7 +250,11 @@ int xpic_create(const xpic_geometry* geom, int scheme, xpic_ctx** out)
   g.nx = geom->n[0]; g.ny = geom->n[1]; g.nzg = geom->n[2];
   g.nzl = g.nzg / geom->nranks;
   g.z0 = geom->rank * g.nzl;
-  g.G = geom->nranks > 1 ? 3 : 0; // ceil(shape_radius) + 1 planes: c-2 .. c+3 of the 2nd-order shape pair
+  // ceil(shape_radius) + 1 ghost planes (c-2 .. c+3 of the 2nd-order shape pair) when there are z-neighbours.
+  // XPIC_FORCE_HALO=1 keeps the ghost planes and the exchange layer on a single slab (its own neighbour): the
+  // way to exercise the RCCL transport on a one-GPU box.
+  const bool force_halo = getenv("XPIC_FORCE_HALO") && atoi(getenv("XPIC_FORCE_HALO")) != 0;
+  g.G = (geom->nranks > 1 || force_halo) ? 3 : 0;
   g.nzs = g.nzl + 2 * g.G;
   g.dx = geom->d[0]; g.dy = geom->d[1]; g.dz = geom->d[2]; g.dt = geom->dt;
   g.Lx = g.nx * g.dx; g.Ly = g.ny * g.dy; g.Lz = g.nzg * g.dz;

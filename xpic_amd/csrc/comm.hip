@@ -121,7 +121,7 @@ int xpic_comm_rccl_unique_id(void* id128)
 int xpic_comm_init_rccl(xpic_ctx* ctx, const void* id128)
 {
   XPIC_CHECK(ctx && id128, "null argument");
-  XPIC_CHECK(ctx->geom.nranks > 1, "context was created with nranks == 1");
+  XPIC_CHECK(ctx->g.G > 0, "context was created without ghost planes (nranks == 1)");
   ncclUniqueId id;
   memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
   ncclComm_t nc;
@@ -137,7 +137,7 @@ int xpic_comm_init_rccl(xpic_ctx* ctx, const void* id128)
 int xpic_comm_init_callbacks(xpic_ctx* ctx, const xpic_comm_callbacks* cb)
 {
   XPIC_CHECK(ctx && cb && cb->sendrecv && cb->allreduce_sum, "null argument");
-  XPIC_CHECK(ctx->geom.nranks > 1, "context was created with nranks == 1");
+  XPIC_CHECK(ctx->g.G > 0, "context was created without ghost planes (nranks == 1)");
   ctx->comm.kind = 2;
   ctx->comm.cb = *cb;
   ctx->comm.rank = ctx->geom.rank;
