@@ -1,0 +1,600 @@
+// xpic_host.cpp -- see xpic_host.h.  Host logic only; every grid/particle operation goes through the C ABI.
+#include "xpic_host.h"
+
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <iostream>
+#include <random>
+#include <sstream>
+#include <stdexcept>
+
+PetscReal dx = 0, dy = 0, dz = 0, dt = 0;
+PetscReal geom_x = 0, geom_y = 0, geom_z = 0, geom_t = 0;
+PetscInt geom_nx = 0, geom_ny = 0, geom_nz = 0, geom_nt = 0;
+PetscInt diagnose_period = 0;
+
+#define LOG(msg) (std::cout << msg << "\n")
+#define ROUND_STEP(s, ds) static_cast<PetscInt>(std::round((s) / (ds))) /* src/utils/utils.h:77 */
+#define FLOOR_STEP(s, ds) static_cast<PetscInt>(std::floor((s) / (ds))) /* :78 */
+
+static int check(interfaces::Simulation* sim, int rc, const char* what)
+{
+  (void)sim;
+  if (rc != 0) std::cerr << "xpic_hip error in " << what << ": " << xpic_last_error() << std::endl;
+  return rc;
+}
+#define HIPCALL(expr) XCALL(check(nullptr, (expr), #expr))
+
+static void make_dirs(const std::string& path)
+{
+  std::string cur;
+  for (size_t i = 0; i <= path.size(); ++i) {
+    if (i == path.size() || path[i] == '/') {
+      if (!cur.empty()) mkdir(cur.c_str(), 0777);
+    }
+    if (i < path.size()) cur += path[i];
+  }
+}
+
+// ---- Configuration (src/utils/configuration.cpp:7-24)
+Configuration Configuration::config;
+const Configuration& Configuration::get() { return config; }
+void Configuration::overwrite(json_t&& json)
+{
+  config.json = std::move(json);
+  config.out_dir = config.json.at("OutputDirectory").as_string();
+}
+void Configuration::init(const std::string& config_path)
+{
+  std::ifstream file(config_path);
+  if (!file) throw std::runtime_error("Cannot open configuration file " + config_path);
+  std::stringstream ss;
+  ss << file.rdbuf();
+  overwrite(xjson::parse(ss.str()));
+}
+void Configuration::set_out_dir(const std::string& dir) { config.out_dir = dir; }
+
+// ---- World (src/utils/world.cpp:11-112)
+/* static */ void World::set_geometry(PetscReal gx, PetscReal gy, PetscReal gz, PetscReal gt, PetscReal dx_,
+  PetscReal dy_, PetscReal dz_, PetscReal dt_, PetscReal dtp)
+{
+  dx = dx_; dy = dy_; dz = dz_; dt = dt_;
+  geom_x = gx; geom_y = gy; geom_z = gz; geom_t = gt;
+  geom_nx = ROUND_STEP(geom_x, dx);
+  geom_ny = ROUND_STEP(geom_y, dy);
+  geom_nz = ROUND_STEP(geom_z, dz);
+  geom_nt = ROUND_STEP(geom_t, dt);
+  diagnose_period = ROUND_STEP(dtp, dt);
+}
+
+PetscErrorCode World::initialize()
+{
+  const Configuration::json_t& geometry = CONFIG().json.at("Geometry");
+  // cell sizes first, parse_value() needs them (world.cpp:17-21)
+  dx = geometry.at("dx").as_double();
+  dy = geometry.at("dy").as_double();
+  dz = geometry.at("dz").as_double();
+  dt = geometry.at("dt").as_double();
+  using interfaces::Builder;
+  set_geometry(Builder::parse_value(geometry.at("x")), Builder::parse_value(geometry.at("y")),
+    Builder::parse_value(geometry.at("z")), Builder::parse_value(geometry.at("t")), dx, dy, dz, dt,
+    Builder::parse_value(geometry.at("diagnose_period")));
+  for (const char* b : {"da_boundary_x", "da_boundary_y", "da_boundary_z"})
+    if (geometry.at(b).as_string() != "DM_BOUNDARY_PERIODIC")
+      throw std::runtime_error("the HIP backends support DM_BOUNDARY_PERIODIC only");
+  geom.n[0] = geom_nx; geom.n[1] = geom_ny; geom.n[2] = geom_nz;
+  geom.d[0] = dx; geom.d[1] = dy; geom.d[2] = dz;
+  geom.dt = dt;
+  geom.periodic[0] = geom.periodic[1] = geom.periodic[2] = 1;
+  geom.rank = 0; geom.nranks = 1; geom.device = 0;
+  return 0;
+}
+
+namespace interfaces {
+
+// ---- Builder (src/interfaces/builder.cpp:22-81)
+static bool ends_with(const std::string& s, const std::string& suf)
+{
+  return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
+}
+
+/* static */ PetscReal Builder::parse_value(const Configuration::json_t& value)
+{
+  if (!value.is_string()) return value.as_double();
+  const std::string& str = value.as_string();
+  if (str == "geom_x" || str == "geom_nx") return geom_x;
+  if (str == "geom_y" || str == "geom_ny") return geom_y;
+  if (str == "geom_z" || str == "geom_nz") return geom_z;
+  if (ends_with(str, " [dx]")) return std::stod(str.substr(0, str.size() - 5)) * dx;
+  if (ends_with(str, " [dy]")) return std::stod(str.substr(0, str.size() - 5)) * dy;
+  if (ends_with(str, " [dz]")) return std::stod(str.substr(0, str.size() - 5)) * dz;
+  if (ends_with(str, " [dt]")) return std::stod(str.substr(0, str.size() - 5)) * dt;
+  if (ends_with(str, " [c/w_pe]") || ends_with(str, " [1/w_pe]")) return std::stod(str.substr(0, str.size() - 9));
+  throw std::runtime_error("Unknown string format to convert: " + str);
+}
+
+/* static */ Vector3R Builder::parse_vector(const Configuration::json_t& info, const std::string& name)
+{
+  const Configuration::json_t& value = info.at(name);
+  Vector3R result;
+  if (value.is_array()) {
+    if (value.arr.size() != 3) throw std::runtime_error(name + " vector should be of size 3.");
+    for (int i = 0; i < 3; ++i) result[i] = parse_value(value.arr[i]);
+    return result;
+  }
+  if (value.is_string()) {
+    const std::string& str = value.as_string();
+    if (str == "Geom") { result[0] = geom_x; result[1] = geom_y; result[2] = geom_z; }
+    else if (str == "Geom / 2") { result[0] = geom_x / 2; result[1] = geom_y / 2; result[2] = geom_z / 2; }
+    return result;
+  }
+  const PetscReal v = parse_value(value);
+  result[0] = result[1] = result[2] = v;
+  return result;
+}
+
+// ---- Particles
+Particles::Particles(Simulation& simulation, const SortParameters& parameters)
+  : parameters(parameters), simulation_(simulation)
+{
+}
+
+PetscErrorCode Particles::add_particle(const Point& point, bool* is_added)
+{
+  // the same FLOOR_STEP bounds test the device applies (src/interfaces/particles.cpp:50-56)
+  const PetscInt vx = FLOOR_STEP(point.r[0], dx), vy = FLOOR_STEP(point.r[1], dy), vz = FLOOR_STEP(point.r[2], dz);
+  const bool inside = 0 <= vx && vx < geom_nx && 0 <= vy && vy < geom_ny && 0 <= vz && vz < geom_nz;
+  if (!inside) return 0;
+  for (int c = 0; c < 3; ++c) pending_.push_back(point.r[c]);
+  for (int c = 0; c < 3; ++c) pending_.push_back(point.p[c]);
+  if (is_added) *is_added = true;
+  return 0;
+}
+
+PetscErrorCode Particles::flush()
+{
+  if (pending_.empty()) return 0;
+  int64_t added = 0;
+  HIPCALL(xpic_sort_add_particles(simulation_.ctx, sort_id, (int64_t)(pending_.size() / 6), pending_.data(), &added));
+  pending_.clear();
+  pending_.shrink_to_fit();
+  return 0;
+}
+
+PetscErrorCode Particles::update_cells()
+{
+  int64_t n;
+  HIPCALL(xpic_update_cells(simulation_.ctx, sort_id, &n));
+  return 0;
+}
+
+PetscInt Particles::count()
+{
+  int64_t n = 0;
+  xpic_sort_count(simulation_.ctx, sort_id, &n);
+  return (PetscInt)n;
+}
+
+PetscErrorCode Particles::storage(std::vector<Point>& points, std::vector<int>& cell_of)
+{
+  const PetscInt n = count();
+  std::vector<double> raw((size_t)n * 6);
+  cell_of.resize(n);
+  HIPCALL(xpic_sort_get_particles(simulation_.ctx, sort_id, raw.data(), cell_of.data()));
+  points.resize(n);
+  for (PetscInt i = 0; i < n; ++i)
+    for (int c = 0; c < 3; ++c) { points[i].r[c] = raw[6 * i + c]; points[i].p[c] = raw[6 * i + 3 + c]; }
+  return 0;
+}
+
+// ---- Simulation (src/interfaces/simulation.cpp:16-155)
+Simulation::~Simulation()
+{
+  if (ctx) xpic_destroy(ctx);
+}
+
+PetscErrorCode Simulation::initialize()
+{
+  XCALL(world.initialize());
+  LOG("Geometric constants for the current setup:");
+  LOG("  Nx = " << geom_nx << ", Ny = " << geom_ny << ", Nz = " << geom_nz << ", Nt = " << geom_nt << ", dt = " << dt);
+  LOG("Running initialize implementation");
+  XCALL(initialize_implementation());
+
+  // the always-on conservation diagnostic (simulation.cpp:39-50)
+  diagnostics_.emplace_back(std::make_unique<Energy>(*this));
+
+  std::vector<std::unique_ptr<Command>> presets;
+  XCALL(build_commands(*this, "Presets", presets));
+  XCALL(build_commands(*this, "StepPresets", step_presets_));
+
+  LOG("Executing presets");
+  for (auto&& preset : presets) XCALL(preset->execute(start));
+  for (auto& diagnostic : diagnostics_) XCALL(diagnostic->diagnose(start));
+  return 0;
+}
+
+PetscErrorCode Simulation::calculate()
+{
+  LOG("Running the main simulation cycle");
+  for (PetscInt t = start + 1; t <= geom_nt; ++t) {
+    for (auto& command : step_presets_) XCALL(command->execute(t));
+    XCALL(timestep_implementation(t));
+    for (auto& diagnostic : diagnostics_) XCALL(diagnostic->diagnose(t));
+  }
+  return 0;
+}
+
+PetscErrorCode Simulation::finalize()
+{
+  for (auto& command : step_presets_) XCALL(command->finalize());
+  for (auto& diagnostic : diagnostics_) XCALL(diagnostic->finalize());
+  if (ctx) {
+    HIPCALL(xpic_destroy(ctx));
+    ctx = nullptr;
+  }
+  return 0;
+}
+
+int Simulation::get_named_vector(const std::string& name) const
+{
+  if (name == "E") return XPIC_E;
+  if (name == "B") return XPIC_B;
+  if (name == "B0") return XPIC_B0;
+  throw std::out_of_range("no vector named " + name);
+}
+
+Particles& Simulation::get_named_particles(const std::string& name)
+{
+  for (auto& sort : particles_)
+    if (sort->parameters.sort_name == name) return *sort;
+  throw std::runtime_error("No particles with name " + name);
+}
+
+PetscErrorCode Simulation::initialize_implementation()
+{
+  HIPCALL(xpic_create(&world.geom, scheme(), &ctx));
+  return init_particles();
+}
+
+PetscErrorCode Simulation::init_particles()
+{
+  const Configuration::json_t& json = CONFIG().json;
+  const Configuration::json_t* it = json.find("Particles");
+  if (!it || it->arr.empty()) return 0;
+  // capacity: the SetParticles presets tell how many points each sort will get; leave head-room for migration
+  for (auto&& info : it->arr) {
+    if (!info.contains("sort_name")) continue;
+    SortParameters p;
+    p.sort_name = info.at("sort_name").as_string();
+    p.Np = info.at("Np").as_int();
+    p.n = info.at("n").as_double();
+    p.q = info.at("q").as_double();
+    p.m = info.at("m").as_double();
+    if (info.contains("T")) p.Tx = p.Ty = p.Tz = info.at("T").as_double();
+    else {
+      p.Tx = info.at("Tx").as_double();
+      p.Ty = info.at("Ty").as_double();
+      p.Tz = info.at("Tz").as_double();
+    }
+    auto sort = std::make_shared<Particles>(*this, p);
+    xpic_sort_params sp{p.Np, p.n, p.q, p.m};
+    const int64_t cells = (int64_t)geom_nx * geom_ny * geom_nz;
+    const int64_t capacity = std::max<int64_t>(cells * p.Np * 5 / 4 + 4096, 1 << 16);
+    HIPCALL(xpic_add_sort(ctx, &sp, capacity, &sort->sort_id));
+    particles_.emplace_back(sort);
+    LOG("  " << p.sort_name << " are added");
+  }
+  return 0;
+}
+
+PetscErrorCode Simulation::timestep_implementation(PetscInt /* t */)
+{
+  int its = 0;
+  HIPCALL(xpic_step(ctx, &its));
+  return 0;
+}
+
+}  // namespace interfaces
+
+PetscErrorCode ecsim::Simulation::timestep_implementation(PetscInt /* t */)
+{
+  int its = 0;
+  HIPCALL(xpic_step(ctx, &its));
+  last_ksp_iterations = its;
+  LOG("  KSPSolve() has finished, iterations: " << its);
+  return 0;
+}
+
+std::unique_ptr<interfaces::Simulation> build_simulation()
+{
+  const std::string simulation_str = CONFIG().json.at("Simulation").as_string();
+  std::unique_ptr<interfaces::Simulation> simulation;
+  if (simulation_str == "basic") simulation = std::make_unique<basic::Simulation>();
+  else if (simulation_str == "ecsim") simulation = std::make_unique<ecsim::Simulation>();
+  else if (simulation_str == "ecsimcorr") simulation = std::make_unique<ecsimcorr::Simulation>();
+  else throw std::runtime_error("Unkown simulation is used: " + simulation_str);
+  LOG("Simulation is built, scheme " << simulation_str);
+  return simulation;
+}
+
+// ---- particle loaders (src/utils/random_generator.h:8-35, src/utils/particles_load.cpp:11-76)
+static std::mt19937& generator()
+{
+  static std::mt19937 gen; // RANDOM_SEED false (src/constants.h:5): default seed
+  return gen;
+}
+static PetscReal random_01()
+{
+  static std::uniform_real_distribution<double> distribution(0.0, 1.0);
+  return distribution(generator());
+}
+static PetscReal temperature_momentum(PetscReal temperature, PetscReal mass)
+{
+  return std::sqrt(-2.0 * (temperature * mass / mec2) * std::log(random_01()));
+}
+
+SetParticles::SetParticles(interfaces::Particles& particles, PetscInt number_of_particles, CoordinateGenerator gc,
+  MomentumGenerator gm)
+  : particles_(particles), number_of_particles_(number_of_particles), generate_coordinate_(std::move(gc)),
+    generate_momentum_(std::move(gm))
+{
+}
+
+PetscErrorCode SetParticles::execute(PetscInt /* t */) // src/commands/set_particles.cpp:19-43
+{
+  added_energy = 0.0;
+  added_particles = 0;
+  const PetscReal m = particles_.parameters.m;
+  const PetscReal mpw = particles_.parameters.n / particles_.parameters.Np;
+  for (PetscInt p = 0; p < number_of_particles_; ++p) {
+    Vector3R coordinate = generate_coordinate_();
+    Vector3R momentum = generate_momentum_(coordinate);
+    bool is_added = false;
+    Point point;
+    point.r = coordinate;
+    point.p = momentum;
+    XCALL(particles_.add_particle(point, &is_added));
+    if (is_added) {
+      added_energy += 0.5 * (m * momentum.squared()) * mpw; // Energy::get_kinetic
+      added_particles++;
+    }
+  }
+  XCALL(particles_.flush());
+  LOG("  Particles have been added into \"" << particles_.parameters.sort_name << "\": " << added_particles);
+  return 0;
+}
+
+SetMagneticField::SetMagneticField(interfaces::Simulation& sim, int field, int field_axpy, const Vector3R& v)
+  : sim_(sim), field_(field), field_axpy_(field_axpy), value_(v)
+{
+}
+
+PetscErrorCode SetMagneticField::execute(PetscInt /* t */) // src/commands/set_magnetic_field.cpp:12-19, 27-35
+{
+  const size_t n = (size_t)geom_nx * geom_ny * geom_nz;
+  std::vector<double> v(3 * n);
+  for (size_t i = 0; i < n; ++i)
+    for (int c = 0; c < 3; ++c) v[3 * i + c] = value_[c]; // VecStrideSet
+  HIPCALL(xpic_field_set(sim_.ctx, field_, v.data()));
+  if (field_axpy_ >= 0) HIPCALL(xpic_vec_axpy(sim_.ctx, field_axpy_, 1.0, field_));
+  return 0;
+}
+
+// build_commands (src/commands/builders/command_builder.cpp:16-62) with ParticlesBuilder::load_coordinate /
+// load_momentum (particles_builder.cpp:9-68) and SetMagneticFieldBuilder (set_magnetic_field_builder.cpp:11-63)
+PetscErrorCode build_commands(interfaces::Simulation& simulation, const std::string& name,
+  std::vector<std::unique_ptr<interfaces::Command>>& result)
+{
+  using interfaces::Builder;
+  const Configuration::json_t* it = CONFIG().json.find(name);
+  if (!it || it->arr.empty()) return 0;
+  for (auto&& info : it->arr) {
+    if (!info.contains("command")) continue;
+    const std::string command = info.at("command").as_string();
+    if (command == "SetParticles") {
+      auto& particles = simulation.get_named_particles(info.at("particles").as_string());
+      const PetscInt Np = particles.parameters.Np;
+      const PetscReal frac = Np / (dx * dy * dz);
+      PetscInt number_of_particles = 0;
+      CoordinateGenerator gc;
+      const auto& ci = info.at("coordinate");
+      const std::string cname = ci.at("name").as_string();
+      if (cname == "PreciseCoordinate") {
+        number_of_particles = Np;
+        Vector3R dot = Builder::parse_vector(ci, "value");
+        gc = [dot]() { return dot; };
+      }
+      else if (cname == "CoordinateInBox") {
+        Vector3R mn, mx;
+        mx[0] = geom_x; mx[1] = geom_y; mx[2] = geom_z; // Builder::load_geometry defaults (builder.cpp:83-94)
+        if (ci.contains("min")) mn = Builder::parse_vector(ci, "min");
+        if (ci.contains("max")) mx = Builder::parse_vector(ci, "max");
+        number_of_particles = ((mx[0] - mn[0]) * (mx[1] - mn[1]) * (mx[2] - mn[2])) * frac; // truncation, :26
+        gc = [mn, mx]() {
+          Vector3R r;
+          r[0] = mn[0] + random_01() * (mx[0] - mn[0]);
+          r[1] = mn[1] + random_01() * (mx[1] - mn[1]);
+          r[2] = mn[2] + random_01() * (mx[2] - mn[2]);
+          return r;
+        };
+      }
+      else throw std::runtime_error("Unknown coordinate generator name " + cname);
+      MomentumGenerator gm;
+      const auto& mi = info.at("momentum");
+      const std::string mname = mi.at("name").as_string();
+      if (mname == "PreciseMomentum") {
+        Vector3R value = Builder::parse_vector(mi, "value");
+        gm = [value](const Vector3R&) { return value; };
+      }
+      else if (mname == "MaxwellianMomentum") {
+        bool tov = mi.contains("tov") ? mi.at("tov").as_bool() : false;
+        SortParameters params = particles.parameters;
+        gm = [params, tov](const Vector3R&) { // particles_load.cpp:57-76; sin(2 pi u) is drawn before sqrt(-2..ln u)
+          Vector3R result;
+          const PetscReal sx = std::sin(2.0 * M_PI * random_01());
+          result[0] = params.px + sx * temperature_momentum(params.Tx, params.m);
+          const PetscReal sy = std::sin(2.0 * M_PI * random_01());
+          result[1] = params.py + sy * temperature_momentum(params.Ty, params.m);
+          const PetscReal sz = std::sin(2.0 * M_PI * random_01());
+          result[2] = params.pz + sz * temperature_momentum(params.Tz, params.m);
+          if (tov) {
+            const PetscReal g = std::sqrt(params.m * params.m + result.squared());
+            for (int c = 0; c < 3; ++c) result[c] /= g;
+          }
+          return result;
+        };
+      }
+      else throw std::runtime_error("Unknown coordinate generator name " + mname);
+      result.emplace_back(std::make_unique<SetParticles>(particles, number_of_particles, gc, gm));
+      LOG("  SetParticles command is added for \"" << particles.parameters.sort_name << "\"");
+    }
+    else if (command == "SetMagneticField") {
+      const int field = simulation.get_named_vector(info.at("field").as_string());
+      int axpy = -1;
+      if (info.contains("field_axpy")) axpy = simulation.get_named_vector(info.at("field_axpy").as_string());
+      const auto& setter = info.at("setter");
+      const std::string sname = setter.at("name").as_string();
+      if (sname != "SetUniformField") throw std::runtime_error("Unknown setter name " + sname);
+      result.emplace_back(std::make_unique<SetMagneticField>(simulation, field, axpy, Builder::parse_vector(setter, "value")));
+    }
+    else throw std::runtime_error("Unknown command name " + command);
+  }
+  return 0;
+}
+
+// ---- TableDiagnostic (src/diagnostics/utils/table_diagnostic.cpp:8-59, table_diagnostic.h:19-38)
+static std::string pad_left(const std::string& s, int w) // std::format("{:<{}.{}s}")
+{
+  std::string t = s.substr(0, w);
+  t.append(w - t.size(), ' ');
+  return t;
+}
+static std::string pad_center(const std::string& s, int w) // std::format("{:^{}.{}s}")
+{
+  std::string t = s.substr(0, w);
+  const int pad = w - (int)t.size();
+  const int left = pad / 2;
+  return std::string(left, ' ') + t + std::string(pad - left, ' ');
+}
+
+TableDiagnostic::TableDiagnostic(const std::string& filename) : filename_(filename) {}
+
+void TableDiagnostic::add(PetscInt w, std::string title, const char* printf_fmt, double value, PetscInt pos)
+{
+  char buf[64];
+  std::snprintf(buf, sizeof(buf), printf_fmt, value);
+  title = pad_left(title, w);
+  std::string fvalue = pad_center(buf, w);
+  if (pos >= 0) {
+    titles_.insert(titles_.begin() + pos, title);
+    values_.insert(values_.begin() + pos, fvalue);
+  }
+  else {
+    titles_.push_back(title);
+    values_.push_back(fvalue);
+  }
+}
+
+void TableDiagnostic::add_int(PetscInt w, std::string title, long value)
+{
+  titles_.push_back(pad_left(title, w));
+  values_.push_back(pad_center(std::to_string(value), w));
+}
+
+void TableDiagnostic::write_formatted(const std::vector<std::string>& container)
+{
+  for (size_t i = 0; i + 1 < container.size(); ++i) file_ << container[i] << "  ";
+  std::string last = container.back();
+  while (!last.empty() && last.back() == ' ') last.pop_back();
+  file_ << last << "\n";
+}
+
+PetscErrorCode TableDiagnostic::diagnose(PetscInt t)
+{
+  if (t == 0) {
+    const size_t slash = filename_.rfind('/');
+    if (slash != std::string::npos) make_dirs(filename_.substr(0, slash));
+    file_.open(filename_);
+    if (!file_) throw std::runtime_error("Cannot open " + filename_);
+  }
+  XCALL(add_columns(t));
+  if (!values_.empty()) {
+    if (t == 0) write_formatted(titles_);
+    write_formatted(values_);
+    titles_.clear();
+    values_.clear();
+  }
+  if (diagnose_period > 0 && t % diagnose_period == 0) file_.flush();
+  return 0;
+}
+
+// ---- Energy (src/diagnostics/energy.cpp:9-185; ecsimcorr::Energy src/impls/ecsimcorr/simulation.cpp:157-197)
+Energy::Energy(interfaces::Simulation& simulation)
+  : simulation(simulation), energy(CONFIG().out_dir + "/temporal/energy.txt"),
+    energy_cons(CONFIG().out_dir + "/temporal/energy_conservation.txt")
+{
+  const size_t n = simulation.particles_.size();
+  K.assign(n, 0);
+  K0.assign(n, 0);
+  std_K.assign(n, 0);
+}
+
+PetscErrorCode Energy::calculate()
+{
+  std::vector<double> out(4 + 2 * K.size());
+  HIPCALL(xpic_energy(simulation.ctx, out.data()));
+  E = out[0]; B = out[1]; std_E = out[2]; std_B = out[3];
+  for (size_t i = 0; i < K.size(); ++i) { K[i] = out[4 + 2 * i]; std_K[i] = out[5 + 2 * i]; }
+  return 0;
+}
+
+PetscErrorCode Energy::diagnose(PetscInt t)
+{
+  if (t == 0) XCALL(calculate());
+  E0 = E; B0 = B; K0 = K;
+  XCALL(calculate());
+
+  auto& particles = simulation.particles_;
+  // fill_energy :111-135
+  energy.add_int(6, "Time", t);
+  energy.add(13, "wE", "% .6e", E);
+  energy.add(13, "wB", "% .6e", B);
+  for (size_t i = 0; i < K.size(); ++i) energy.add(13, "wK_" + particles[i]->parameters.sort_name, "% .6e", K[i]);
+  energy.add(13, "sE", "% .6e", std_E);
+  energy.add(13, "sB", "% .6e", std_B);
+  for (size_t i = 0; i < K.size(); ++i) energy.add(13, "sK_" + particles[i]->parameters.sort_name, "% .6e", std_K[i]);
+
+  // fill_energy_cons :137-185
+  energy_cons.add_int(6, "Time", t);
+  const PetscReal dE = E - E0, dB = B - B0;
+  PetscReal dF = dE + dB, dK = 0;
+  energy_cons.add(13, "dE", "% .6e", dE);
+  energy_cons.add(13, "dB", "% .6e", dB);
+  for (size_t i = 0; i < K.size(); ++i) {
+    energy_cons.add(13, "dK_" + particles[i]->parameters.sort_name, "% .6e", K[i] - K0[i]);
+    dK += K[i] - K0[i];
+  }
+  energy_cons.add(13, "dE+dB+dK", "% .6e", dF + dK);
+  if (simulation.scheme() == XPIC_ECSIMCORR) {
+    PetscInt off = 3;
+    PetscReal corr_w = 0.0;
+    for (size_t i = 0; i < K.size(); ++i) {
+      double s[6];
+      HIPCALL(xpic_ecsimcorr_scalars(simulation.ctx, particles[i]->sort_id, s));
+      const std::string& name = particles[i]->parameters.sort_name;
+      energy_cons.add(13, "CWD_" + name, "% .6e", s[2], ++off);            // lambda_dK
+      energy_cons.add(13, "PWD_" + name, "% .6e", s[3] - dt * s[0], ++off); // pred_dK - dt pred_w
+      energy_cons.add(13, "LdK_" + name, "% .6e", s[4] - dt * s[1], ++off); // corr_dK - dt corr_w
+      ++off;
+      corr_w += s[1];
+    }
+    energy_cons.add(13, "WD", "% .6e", dK - dt * corr_w);
+  }
+  XCALL(energy.diagnose(t));
+  XCALL(energy_cons.diagnose(t));
+  return 0;
+}
