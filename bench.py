@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--cpu-grid", type=int, default=40)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--probe", action="store_true", help="also run the device copy probes (PMC calibration)")
     args = ap.parse_args()
 
     import torch
@@ -117,6 +118,7 @@ def main():
         if world > 1:
             dist.barrier()
 
+    copy_rate = ctx.probe_copy_bandwidth(1 << 30, 5) if args.probe else None
     for _ in range(args.warmup):
         ctx.step()
     ctx.profile_enable(True)
@@ -176,6 +178,7 @@ def main():
         "ksp_iters_per_s": its_total / world / (ms_solve * 1e-3) if ms_solve else None,  # iterations are global
         "ksp_iterations_per_step": its_total / world / args.steps,
         "phase_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},
+        "device_copy_GBps": copy_rate / 1e9 if copy_rate else None,
         "roofline": {
             "kernel": "k_matA (matL+matM SpMV)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,

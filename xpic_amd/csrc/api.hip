@@ -661,6 +661,12 @@ __global__ void __launch_bounds__(256) k_copy16(const double2* __restrict__ in, 
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = in[i];
 }
 
+__global__ void __launch_bounds__(256) k_copy8(const double* __restrict__ in, double* __restrict__ out, long n)
+{
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = in[i];
+}
+
 int xpic_probe_copy_bandwidth(xpic_ctx* ctx, int64_t bytes, int reps, double* bytes_per_s)
 {
   CTX_CHECK(ctx);
@@ -671,6 +677,9 @@ int xpic_probe_copy_bandwidth(xpic_ctx* ctx, int64_t bytes, int reps, double* by
   XPIC_HIP(hipMemsetAsync(a, 1, n * 16, ctx->stream));
   hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
   hipLaunchKernelGGL(k_copy16, dim3(2048), dim3(256), 0, ctx->stream, a, b, n);
+  // one 8-byte-per-lane copy of the same buffers: the access width of the SpMV's loads, launched so that the
+  // FETCH_SIZE / WRITE_SIZE counters can be calibrated on a known byte count (MI355X_MICROARCH.md, HBM section)
+  hipLaunchKernelGGL(k_copy8, dim3(2048), dim3(256), 0, ctx->stream, (const double*)a, (double*)b, 2 * n);
   XPIC_HIP(hipEventRecord(e0, ctx->stream));
   for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_copy16, dim3(2048), dim3(256), 0, ctx->stream, a, b, n);
   XPIC_HIP(hipEventRecord(e1, ctx->stream));

@@ -320,18 +320,32 @@ __device__ __forceinline__ double matM_comp(const GridDev& g, const double* __re
 }
 
 constexpr int kRowX = 64, kRowY = 4;
+constexpr int kBandY = 4; // y-chunks per band: 16 rows
 
 template <bool WITH_L, bool WITH_M>
 __global__ void __launch_bounds__(kRowX* kRowY, 4) k_matA(GridDev g, const double* __restrict__ L,
   const double* __restrict__ X, double* __restrict__ Y, int add)
 {
-  // grid.x = 3 * x-chunks (component fastest: the three rows of a node share their operand footprint),
-  // grid.y = y-chunks, grid.z = z
-  const int c1 = blockIdx.x % 3;
-  const int x = (blockIdx.x / 3) * kRowX + threadIdx.x;
+  // 1-D grid.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  XCD r sweeps its own
+  // run of z-planes, and inside the run a band of 16 y-rows at a time along z: the operand footprint of a band
+  // (20 rows x 5 planes x 3 components) stays in that XCD's 4 MiB L2 while the coefficient streams pass through.
+  // Order inside a band position: component fastest (the three rows of a node share their operand footprint), x, y.
+  const int nxc = (g.nx + kRowX - 1) / kRowX, nyc = (g.ny + kRowY - 1) / kRowY;
+  const int nyt = (nyc + kBandY - 1) / kBandY;         // y-bands
+  const int P = (g.nzl + 7) / 8;                       // planes per XCD run
+  const int per_z = kBandY * nxc * 3, per_band = P * per_z;
+  const int xcd = blockIdx.x % 8;
+  const long q = blockIdx.x / 8;
+  const int yt = (int)(q / per_band);
+  const int rem = (int)(q % per_band);
+  const int z = xcd * P + rem / per_z;
+  const int rem2 = rem % per_z;
+  const int c1 = rem2 % 3;
+  const int x = ((rem2 / 3) % nxc) * kRowX + threadIdx.x;
   // y is the same for the 64 lanes of a wave (blockDim.x == 64): tell the compiler, so that every row base
   // below is scalar arithmetic
-  const int y = blockIdx.y * kRowY + __builtin_amdgcn_readfirstlane(threadIdx.y), z = blockIdx.z;
+  const int y = (yt * kBandY + rem2 / (3 * nxc)) * kRowY + __builtin_amdgcn_readfirstlane(threadIdx.y);
+  if (yt >= nyt || z >= g.nzl) return;
   if (x >= g.nx || y >= g.ny) return;
   using Seq = std::make_integer_sequence<int, kLStencil>;
   double r = 0.0;
@@ -476,7 +490,12 @@ int matM_apply(xpic_ctx* c, const double* x, double* y, bool add)
   return 0;
 }
 
-static dim3 row_grid(const GridDev& g) { return dim3(3 * ((g.nx + kRowX - 1) / kRowX), (g.ny + kRowY - 1) / kRowY, g.nzl); }
+static dim3 row_grid(const GridDev& g)
+{
+  const long nxc = (g.nx + kRowX - 1) / kRowX, nyc = (g.ny + kRowY - 1) / kRowY;
+  const long nyt = (nyc + kBandY - 1) / kBandY, P = (g.nzl + 7) / 8;
+  return dim3((unsigned)(8 * nyt * P * kBandY * nxc * 3));
+}
 
 int matL_apply(xpic_ctx* c, const double* x, double* y, bool add)
 {
