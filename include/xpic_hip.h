@@ -144,6 +144,12 @@ int xpic_solve(xpic_ctx* ctx, int op, int rhs, int x, double rtol, double atol, 
 /* KSPSetTolerances used by the step drivers (src/impls/ecsim/simulation.h:15-18: 1e-7,1e-7,100) */
 int xpic_set_tolerances(xpic_ctx* ctx, double rtol, double atol, int maxit);
 
+/* PCSetType for the "predict" KSP.  The reference runs PETSc's default ILU(0) (not part of its tree, not a GPU
+ * algorithm); here: kind 0 = none, kind 1 (default) = a fixed Chebyshev polynomial in matM applied from the right
+ * (matM = 2 I + 0.5 dt^2 rotB rotE dominates matA and its spectral interval is known in closed form).
+ * degree <= 0 keeps the automatic choice.  The stopping rule of xpic_solve is unchanged: true residual norm. */
+int xpic_set_preconditioner(xpic_ctx* ctx, int kind, int degree);
+
 /* timestep_implementation of the context's scheme (basic/simulation.cpp:30-43, ecsim/simulation.cpp:145-155,
  * ecsimcorr/simulation.cpp:21-32); *ksp_iterations = Krylov iterations spent in this step */
 int xpic_step(xpic_ctx* ctx, int* ksp_iterations);

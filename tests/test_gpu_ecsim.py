@@ -28,6 +28,8 @@ def make_pair(oracle, scheme, n, d, dt, sorts, seed=0, ppc=6, vth=0.05, B0=(0.0,
     rng = np.random.default_rng(seed)
     o = oracle.OracleSim(scheme, n, d, dt)
     g = xpic_amd.Context(scheme, n, d, dt)
+    if scheme != "basic":
+        g.set_preconditioner(0)  # same (unpreconditioned) Krylov method as the oracle: iteration counts comparable
     N = n[0] * n[1] * n[2]
     for (Np, dens, q, m) in sorts:
         so = o.add_sort(Np, dens, q, m)
@@ -193,6 +195,48 @@ def test_solve_matches_oracle(oracle, op):
     assert np.linalg.norm(Ax - rhs) <= 1e-8 * np.linalg.norm(rhs)
 
 
+def test_preconditioned_solve(oracle):
+    """The default "predict" solver: GMRES(30) right-preconditioned with a Chebyshev polynomial in matM.  Same
+    stopping rule (true residual), same solution within 10 x rtol, several times fewer iterations."""
+    import xpic_amd as X
+
+    n, d, dt = GRID
+    o, g = make_pair(oracle, "ecsim", n, d, 1.5, [(8, 1.0, -1.0, 1.0)], B0=(0.0, 0.0, 0.5))
+    oracle.lib().orc_ecsim_fill_current(o.h)
+    g.ecsim_fill_current()
+    rhs = o.get_field("E")
+    xo, its_o, _ = o.solve(0, rhs, 1e-9, 1e-50, 300)
+    its_plain, _, _ = g.solve(0, X.E, X.W2, 1e-9, 1e-50, 300)
+    g.set_preconditioner(1)
+    its_pc, reason, rn = g.solve(0, X.E, X.W1, 1e-9, 1e-50, 300)
+    assert reason > 0 and its_pc * 3 <= its_plain
+    xg = g.get_field(X.W1)
+    assert np.abs(xo - xg).max() <= 1e-6 * np.abs(xo).max()
+    Ax = o.matM(xg) + o.matL_apply(xg)
+    assert np.linalg.norm(Ax - rhs) <= 1.5e-9 * np.linalg.norm(rhs)  # the reported norm IS the true residual
+    assert abs(np.linalg.norm(Ax - rhs) - rn) <= 0.2 * rn + 1e-14
+    # explicit degree
+    g.set_preconditioner(1, 12)
+    its12, _, _ = g.solve(0, X.E, X.W1, 1e-9, 1e-50, 300)
+    assert its12 <= its_pc
+
+
+def test_default_step_uses_preconditioner_and_matches_oracle(oracle):
+    import xpic_amd as X
+
+    n, d, dt = GRID
+    o, g = make_pair(oracle, "ecsim", n, d, 1.0, [(8, 1.0, -1.0, 1.0)], B0=(0.0, 0.0, 0.2), vth=0.03)
+    g.set_preconditioner(1)
+    for s in (o, g):
+        s.set_tolerances(1e-11, 1e-50, 300)
+    for t in range(3):
+        io, ig = o.step(), g.step()
+        assert 0 < ig < io / 2
+        for name, fid in (("E", X.E), ("B", X.B)):
+            a, b = o.get_field(name), g.get_field(fid)
+            assert np.abs(a - b).max() <= 1e-7 * np.abs(a).max()
+
+
 def test_solve_reports_non_convergence(oracle):
     """KSPSetErrorIfNotConverged(TRUE) (ecsim/simulation.cpp:562): hitting maxit is an error."""
     import xpic_amd as X
@@ -257,6 +301,7 @@ def test_reference_golden_ecsim_ex1(oracle):
     o.load_maxwell_box(so, True)
     pts, _ = o.particles(so)
     g = X.Context("ecsim", (10, 10, 10), (0.5, 0.5, 0.5), 1.5)
+    g.set_preconditioner(0)
     sg = g.add_sort(100, 1.0, -1.0, 1.0, capacity=200000)
     assert g.add_particles(sg, pts) == 100000
     _, gold = oracle.read_table(os.path.join(GOLD, "ecsim_ex1", "energy.txt"))

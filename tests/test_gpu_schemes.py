@@ -177,6 +177,7 @@ def test_reference_golden_ecsimcorr_ex1(oracle):
     o.load_maxwell_box(so, True)
     pts, _ = o.particles(so)
     g = X.Context("ecsimcorr", (10, 10, 10), (0.5, 0.5, 0.5), 1.5)
+    g.set_preconditioner(0)
     sg = g.add_sort(100, 1.0, -1.0, 1.0, capacity=200000)
     assert g.add_particles(sg, pts) == 100000
     _, gold = oracle.read_table(os.path.join(GOLD, "ecsimcorr_ex1", "energy.txt"))

@@ -27,7 +27,7 @@ SYMBOLS = [
     "xpic_matL_apply", "xpic_matA_apply", "xpic_matL_get", "xpic_lstencil_decode", "xpic_ecsim_first_push",
     "xpic_update_cells", "xpic_ecsim_fill_current", "xpic_ecsim_second_push", "xpic_basic_push",
     "xpic_ecsimcorr_first_push", "xpic_ecsimcorr_second_push", "xpic_ecsimcorr_final_update",
-    "xpic_calculate_energy", "xpic_ecsimcorr_scalars", "xpic_solve", "xpic_set_tolerances", "xpic_step",
+    "xpic_calculate_energy", "xpic_ecsimcorr_scalars", "xpic_solve", "xpic_set_tolerances", "xpic_set_preconditioner", "xpic_step",
     "xpic_energy", "xpic_comm_rccl_unique_id", "xpic_comm_init_rccl", "xpic_comm_init_callbacks",
     "xpic_profile_enable", "xpic_profile_reset", "xpic_profile_get", "xpic_probe_copy_bandwidth",
 ]
@@ -279,6 +279,9 @@ class Context:
 
     def set_tolerances(self, rtol, atol, maxit):
         self._ck(self.L.xpic_set_tolerances(self.h, C.c_double(rtol), C.c_double(atol), maxit))
+
+    def set_preconditioner(self, kind, degree=0):
+        self._ck(self.L.xpic_set_preconditioner(self.h, int(kind), int(degree)))
 
     def step(self):
         its = C.c_int()

@@ -280,6 +280,19 @@ int xpic_create(const xpic_geometry* geom, int scheme, xpic_ctx** out)
     XPIC_HIP(hipMalloc(&c->kry_w, sizeof(double) * c->nvec));
     XPIC_HIP(hipMemsetAsync(c->kry_V, 0, sizeof(double) * c->nvec * 31, c->stream));
     XPIC_HIP(hipMemsetAsync(c->kry_w, 0, sizeof(double) * c->nvec, c->stream));
+    XPIC_HIP(hipMalloc(&c->kry_t, sizeof(double) * c->nvec));
+    XPIC_HIP(hipMemsetAsync(c->kry_t, 0, sizeof(double) * c->nvec, c->stream));
+    for (int i = 0; i < 3; ++i) {
+      XPIC_HIP(hipMalloc(&c->kry_p[i], sizeof(double) * c->nvec));
+      XPIC_HIP(hipMemsetAsync(c->kry_p[i], 0, sizeof(double) * c->nvec, c->stream));
+    }
+    {
+      // Chebyshev degree: error bound 2 rho^k / (1 + rho^2k) <= 5 % on the spectral interval of matM
+      const double kappa = 1.0 + g.dt * g.dt * (1.0 / (g.dx * g.dx) + 1.0 / (g.dy * g.dy) + 1.0 / (g.dz * g.dz));
+      const double rho = (std::sqrt(kappa) - 1.0) / (std::sqrt(kappa) + 1.0);
+      int k = rho > 0 ? (int)std::ceil(std::log(0.025) / std::log(rho)) : 2;
+      c->cheb_degree = k < 2 ? 2 : (k > 32 ? 32 : k);
+    }
     XPIC_CALL(build_ltab(c));
   }
   XPIC_HIP(hipStreamSynchronize(c->stream));
@@ -294,6 +307,7 @@ int xpic_destroy(xpic_ctx* ctx)
   for (auto& s : ctx->sorts) sort_free(s);
   for (int f = 0; f < XPIC_NFIELDS; ++f) (void)hipFree(ctx->field[f]);
   (void)hipFree(ctx->matL); (void)hipFree(ctx->ltab); (void)hipFree(ctx->kry_V); (void)hipFree(ctx->kry_w);
+  (void)hipFree(ctx->kry_t); (void)hipFree(ctx->kry_p[0]); (void)hipFree(ctx->kry_p[1]); (void)hipFree(ctx->kry_p[2]);
   (void)hipFree(ctx->red_partial); (void)hipFree(ctx->red_out); (void)hipHostFree(ctx->red_host);
   (void)hipFree(ctx->scan_tmp);
   for (int i = 0; i < 4; ++i) (void)hipFree(ctx->halo_buf[i]);
@@ -581,6 +595,15 @@ int xpic_solve(xpic_ctx* ctx, int op, int rhs, int x, double rtol, double atol, 
   if (reason) *reason = rs;
   if (rnorm) *rnorm = rn;
   return rc;
+}
+
+int xpic_set_preconditioner(xpic_ctx* ctx, int kind, int degree)
+{
+  CTX_CHECK(ctx);
+  XPIC_CHECK(kind == 0 || kind == 1, "unknown preconditioner kind");
+  ctx->precond = kind;
+  if (degree > 0) ctx->cheb_degree = degree > 64 ? 64 : degree;
+  return 0;
 }
 
 int xpic_set_tolerances(xpic_ctx* ctx, double rtol, double atol, int maxit)

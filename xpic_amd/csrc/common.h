@@ -129,6 +129,10 @@ struct xpic_ctx {
   // Krylov workspace
   double* kry_V = nullptr; // (m+1) vectors
   double* kry_w = nullptr;
+  double* kry_t = nullptr; // preconditioned vector
+  double* kry_p[3] = {nullptr, nullptr, nullptr}; // Chebyshev preconditioner work vectors
+  int precond = 1;     // 0 none, 1 Chebyshev polynomial in matM (right preconditioning)
+  int cheb_degree = 0; // steps of the Chebyshev iteration (set at create from the spectral interval)
   double* red_partial = nullptr; // reduction partials
   double* red_out = nullptr;     // device results (pinned mirror below)
   double* red_host = nullptr;
@@ -175,6 +179,7 @@ int rot_apply(xpic_ctx* c, int sign, double alpha, const double* x, double* y, b
 int matM_apply(xpic_ctx* c, const double* x, double* y, bool add);
 int matL_apply(xpic_ctx* c, const double* x, double* y, bool add);
 int matA_apply(xpic_ctx* c, const double* x, double* y);
+int cheb_matM_inverse(xpic_ctx* c, const double* r, double* out);
 int field_import(xpic_ctx* c, double* dst_soa, const double* src_aos_host);
 int field_export(xpic_ctx* c, const double* src_soa, double* dst_aos_host);
 int field_stats_host(xpic_ctx* c, const double* f, double* sumsq, double* mean3);

@@ -246,6 +246,30 @@ __global__ void __launch_bounds__(kBlock) k_matM(GridDev g, const double* F, dou
   }
 }
 
+// ---- Chebyshev step on matM: res = r - matM z_in ; d = cd d + cr res ; z_out = z_in + d (first = 0: d, z from r)
+__global__ void __launch_bounds__(kBlock) k_cheb(GridDev g, const double* __restrict__ r, const double* __restrict__ zin,
+  double* __restrict__ d, double* __restrict__ zout, double cd, double cr)
+{
+  const long n = g.nown;
+  const long stride = (long)gridDim.x * kBlock;
+  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    int x = (int)(i % g.nx), y = (int)((i / g.nx) % g.ny), z = (int)(i / g.plane);
+    double m[3];
+    matM_at(g, zin, x, y, z, m[0], m[1], m[2]);
+    const long o = g.node(x, y, g.wz(z));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const long oc = o + c * g.cstride;
+      const double dn = cd * d[oc] + cr * (r[oc] - m[c]);
+      d[oc] = dn;
+      zout[oc] = zin[oc] + dn;
+    }
+  }
+}
+
+struct FChebInit { double* d; double* z; double it; const double* r;
+  __device__ void operator()(long i) const { const double v = r[i] * it; d[i] = v; z[i] = v; } };
+
 // ---- matL / matA SpMV ---------------------------------------------------------------------------
 // matL[c1][z][y][k][x]: one thread per row (c1, node), lane = x, so each of the 123 coefficient streams of a
 // wave is one contiguous 512-byte line; the operand vector comes out of L1/L2 (every element is used by 123
@@ -511,6 +535,34 @@ int matA_apply(xpic_ctx* c, const double* x, double* y)
   hipLaunchKernelGGL((k_matA<true, true>), row_grid(c->g), dim3(kRowX, kRowY), 0, c->stream, c->g, c->matL, x, y, 0);
   XPIC_HIP(hipGetLastError());
   return 0;
+}
+
+// z = p_k(matM) r ~ matM^-1 r: k steps of the Chebyshev iteration on [a, b] = [2, 2 + 2 dt^2 sum 1/h^2], the exact
+// spectral interval of matM = 2 I + 0.5 dt^2 rot- rot+ on the periodic Yee grid.  A fixed polynomial: a linear
+// operator, no inner products (no all-reduce), one 1-plane halo per step.  `z` ends in out; uses c->kry_p[0..2].
+int cheb_matM_inverse(xpic_ctx* c, const double* r, double* out)
+{
+  Timed t(c, "precond");
+  const GridDev& g = c->g;
+  const double a = 2.0, b = 2.0 + 2.0 * g.dt * g.dt * (1.0 / (g.dx * g.dx) + 1.0 / (g.dy * g.dy) + 1.0 / (g.dz * g.dz));
+  const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma1 = theta / delta;
+  double* d = c->kry_p[0];
+  double* z0 = c->kry_p[1];
+  double* z1 = c->kry_p[2];
+  XPIC_CALL(launch_ew(c, FChebInit{d, z0, 1.0 / theta, r}));
+  double rho = 1.0 / sigma1;
+  long blocks = (g.nown + kBlock - 1) / kBlock;
+  if (blocks > 65536) blocks = 65536;
+  for (int i = 1; i < c->cheb_degree; ++i) {
+    const double rho_new = 1.0 / (2.0 * sigma1 - rho);
+    XPIC_CALL(halo_fill(c, z0, 1));
+    hipLaunchKernelGGL(k_cheb, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, g, r, z0, d, z1, rho_new * rho,
+      2.0 * rho_new / delta);
+    XPIC_HIP(hipGetLastError());
+    rho = rho_new;
+    std::swap(z0, z1);
+  }
+  return vec_copy(c, out, z0);
 }
 
 int field_import(xpic_ctx* c, double* dst, const double* src_host)

@@ -20,10 +20,14 @@ int apply_op(xpic_ctx* c, int op, double* x, double* y)
   return matM_apply(c, x, y, false);
 }
 
+// Right-preconditioned restarted GMRES: A P y = b, x = P y.  The recurrence residual is the TRUE residual
+// |b - A x|, so the stopping rule is the same with and without P.
 int gmres(xpic_ctx* c, int op, const double* b, double* x, double rtol, double atol, int maxit, int* its_out,
   int* reason, double* rnorm_out)
 {
   const int m = kRestart;
+  const bool pc = op == XPIC_OP_MATA_GMRES && c->precond == 1;
+  double* tmp = c->kry_t;
   double* V = c->kry_V;
   double* w = c->kry_w;
   std::vector<double> H((m + 1) * m, 0.0), cs(m), sn(m), gg(m + 1), h(m + 2), yv(m);
@@ -48,7 +52,11 @@ int gmres(xpic_ctx* c, int op, const double* b, double* x, double rtol, double a
     int j = 0;
     for (; j < m && its < maxit; ++j) {
       double* Vj = V + (long)j * c->nvec;
-      XPIC_CALL(apply_op(c, op, Vj, w));
+      if (pc) {
+        XPIC_CALL(cheb_matM_inverse(c, Vj, tmp));
+        XPIC_CALL(apply_op(c, op, tmp, w));
+      }
+      else XPIC_CALL(apply_op(c, op, Vj, w));
       XPIC_CALL(vec_mdot_host(c, w, V, j + 1, h.data()));           // VecMDot
       double nrm2;
       XPIC_CALL(vec_maxpy_norm_host(c, w, V, j + 1, h.data(), &nrm2)); // VecMAXPY + VecNorm
@@ -75,7 +83,13 @@ int gmres(xpic_ctx* c, int op, const double* b, double* x, double rtol, double a
       for (int k = i + 1; k < j; ++k) t -= H[i * m + k] * yv[k];
       yv[i] = t / H[i * m + i];
     }
-    XPIC_CALL(vec_maxpy(c, x, V, j, yv.data())); // x += V y
+    if (pc) { // x += P (V y)
+      XPIC_CALL(vec_set(c, w, 0.0));
+      XPIC_CALL(vec_maxpy(c, w, V, j, yv.data()));
+      XPIC_CALL(cheb_matM_inverse(c, w, tmp));
+      XPIC_CALL(vec_axpy(c, x, 1.0, tmp));
+    }
+    else XPIC_CALL(vec_maxpy(c, x, V, j, yv.data())); // x += V y
     if (rnorm <= tol) break;
     if (its >= maxit) break;
     // restart: r = b - A x, kept in w
