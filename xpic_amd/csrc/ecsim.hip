@@ -291,6 +291,21 @@ __global__ void __launch_bounds__(kThreads) k_ecsim_fill(GridDev g, SortDev s, c
     // next chunk's cell: particle data and B neighbourhood travel while this chunk is merged and flushed
     prefetch_cell(i + kW, pf);
 
+    // ---- the finished columns of this chunk leave by read-modify-write: request their current values NOW, so
+    // that the HBM latency runs under the merge below (addresses depend only on the chunk, not on the data)
+    const int ndone = min(kW, g.nx - j * kW);
+    constexpr int kItems = (kLines * kW + kThreads - 1) / kThreads;
+    const int fslot = threadIdx.x % kW, fline0 = threadIdx.x / kW;
+    double old[kItems];
+    double* ptr[kItems];
+#pragma unroll
+    for (int mm = 0; mm < kItems; ++mm) {
+      const int line = fline0 + mm * (kThreads / kW);
+      const bool ok = line < kLines && fslot < ndone;
+      ptr[mm] = ok ? lbase[line] + (j * kW + fslot) : nullptr;
+      old[mm] = ok ? *ptr[mm] : 0.0;
+    }
+
     // ---- merge the chunk's cell blocks in the window (aliased over the now dead stages)
     lds_barrier();
     double* win = sh; // [kLines][kSlots]
@@ -311,27 +326,14 @@ __global__ void __launch_bounds__(kThreads) k_ecsim_fill(GridDev g, SortDev s, c
       if (cdesc >= 0) unsafeAtomicAdd(&win[(cdesc >> 2) * kSlots + wave + (cdesc & 3)], accI);
     }
     lds_barrier();
-    // ---- stream out the finished columns (plain RMW, kW consecutive doubles per line), keep 2 in carry.
-    // All loads of a thread's items are issued before the first store, so one HBM latency is exposed per
-    // chunk instead of one per item.
-    const int ndone = min(kW, g.nx - j * kW);
-    {
-      constexpr int kItems = (kLines * kW + kThreads - 1) / kThreads;
-      const int slot = threadIdx.x % kW, line0 = threadIdx.x / kW;
-      double val[kItems], old[kItems];
-      double* ptr[kItems];
+    // ---- stream out the finished columns (plain RMW, kW consecutive doubles per line), keep 2 in carry
 #pragma unroll
-      for (int mm = 0; mm < kItems; ++mm) {
-        const int line = line0 + mm * (kThreads / kW);
-        const bool ok = line < kLines && slot < ndone;
-        val[mm] = ok ? win[line * kSlots + slot] : 0.0;
-        ptr[mm] = ok ? lbase[line] + (j * kW + slot) : nullptr;
+    for (int mm = 0; mm < kItems; ++mm) {
+      const int line = fline0 + mm * (kThreads / kW);
+      if (ptr[mm]) {
+        const double val = win[line * kSlots + fslot];
+        if (val != 0.0) *ptr[mm] = old[mm] + val;
       }
-#pragma unroll
-      for (int mm = 0; mm < kItems; ++mm) old[mm] = val[mm] != 0.0 ? *ptr[mm] : 0.0;
-#pragma unroll
-      for (int mm = 0; mm < kItems; ++mm)
-        if (val[mm] != 0.0) *ptr[mm] = old[mm] + val[mm];
     }
     for (int t = threadIdx.x; t < kLines * 2; t += kThreads) carry[t] = win[(t >> 1) * kSlots + ndone + (t & 1)];
     lds_barrier();

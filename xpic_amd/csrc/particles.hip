@@ -215,18 +215,72 @@ __global__ void __launch_bounds__(kBlock) k_scan_apply(const int* in, long n, co
   }
 }
 
-// ecsim::Particles::second_push (src/impls/ecsim/particles.cpp:175-192)
-__global__ void __launch_bounds__(kBlock) k_second_push(GridDev g, SortDev s, int64_t n, const double* __restrict__ E,
-  const double* __restrict__ B, double qm)
+// ecsim::Particles::second_push (src/impls/ecsim/particles.cpp:175-192).
+// One wave per cell, lane = particle.  Every particle of the cell gathers from the same 36 E and 54 B values
+// (interpolate_E_s1 / interpolate_B_s1, ecsim/simulation.cpp:8-118): they are fetched once per cell into LDS, the
+// 48 gathers per particle then hit LDS instead of L1/L2, and the particle streams are read and written fully
+// coalesced (the cell's particles are contiguous).
+constexpr int kSPW = 4; // cells (waves) per workgroup
+
+__global__ void __launch_bounds__(kSPW * 64) k_second_push(GridDev g, SortDev s, const double* __restrict__ E,
+  const double* __restrict__ B, double qm, long ncell, long chunk)
 {
-  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (p >= n) return;
-  const W1 w(g, s.r[0][p], s.r[1][p], s.r[2][p]);
-  double Ep[3], Bp[3];
-  gather_s1(g, E, B, w, Ep, Bp);
-  double v[3] = {s.v[0][p], s.v[1][p], s.v[2][p]};
-  update_vEB(g.dt, qm, Ep, Bp, v);
-  s.v[0][p] = v[0]; s.v[1][p] = v[1]; s.v[2][p] = v[2];
+  // workgroup -> 4 consecutive cells; XCD r sweeps its own contiguous run of cells (see k_matA)
+  const long q = (long)(blockIdx.x % 8) * chunk + blockIdx.x / 8;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long cell = q * kSPW + wave;
+  if (blockIdx.x / 8 >= chunk || cell >= ncell) return;
+  const int start = s.cell_start[cell];
+  const int cnt = s.cell_start[cell + 1] - start;
+  if (cnt == 0) return;
+  const int cx = (int)(cell % g.nx), cy = (int)((cell / g.nx) % g.ny), cz = (int)(cell / g.plane);
+
+  __shared__ double nbE[kSPW][36], nbB[kSPW][54];
+  if (lane < 36) {
+    const int c = lane / 12;
+    int o[3];
+    // node numbering of the cell's 3 x 12 E nodes: X (k*2+j)*3+l, Y (k*3+l)*2+i, Z (l*2+j)*2+i
+    const int l = lane % 12;
+    if (c == 0) { o[0] = l % 3 - 1; o[1] = (l / 3) % 2; o[2] = l / 6; }
+    else if (c == 1) { o[0] = l % 2; o[1] = (l / 2) % 3 - 1; o[2] = l / 6; }
+    else { o[0] = l % 2; o[1] = (l / 2) % 2; o[2] = l / 4 - 1; }
+    nbE[wave][lane] = E[c * g.cstride + g.nodew(cx + o[0], cy + o[1], cz + o[2])];
+  }
+  if (lane < 54) {
+    int c, ox, oy, oz;
+    if (lane < 18) { c = 0; ox = lane % 2; oy = (lane / 2) % 3 - 1; oz = lane / 6 - 1; }
+    else if (lane < 36) { const int l = lane - 18; c = 1; ox = l % 3 - 1; oy = (l / 3) % 2; oz = l / 6 - 1; }
+    else { const int l = lane - 36; c = 2; ox = l % 3 - 1; oy = (l / 3) % 3 - 1; oz = l / 9; }
+    nbB[wave][lane] = B[c * g.cstride + g.nodew(cx + ox, cy + oy, cz + oz)];
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  const double* eE = nbE[wave];
+  const double* eB = nbB[wave];
+
+  for (int base = 0; base < cnt; base += 64) {
+    if (base + lane >= cnt) break;
+    const long p = (long)start + base + lane;
+    const W1 w(g, s.r[0][p], s.r[1][p], s.r[2][p]);
+    const int ox = w.is[0] - w.in[0] + 1, oy = w.is[1] - w.in[1] + 1, oz = w.is[2] - w.in[2] + 1;
+    double Ep[3] = {0, 0, 0}, Bp[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          Ep[0] += eE[(k * 2 + j) * 3 + (ox + i)] * (w.wn[2][k] * w.wn[1][j] * w.ws[0][i]);
+          Ep[1] += eE[12 + (k * 3 + (oy + j)) * 2 + i] * (w.wn[2][k] * w.ws[1][j] * w.wn[0][i]);
+          Ep[2] += eE[24 + ((oz + k) * 2 + j) * 2 + i] * (w.ws[2][k] * w.wn[1][j] * w.wn[0][i]);
+          Bp[0] += eB[((oz + k) * 3 + (oy + j)) * 2 + i] * (w.ws[2][k] * w.ws[1][j] * w.wn[0][i]);
+          Bp[1] += eB[18 + ((oz + k) * 2 + j) * 3 + (ox + i)] * (w.ws[2][k] * w.wn[1][j] * w.ws[0][i]);
+          Bp[2] += eB[36 + (k * 3 + (oy + j)) * 3 + (ox + i)] * (w.wn[2][k] * w.ws[1][j] * w.ws[0][i]);
+        }
+    double v[3] = {s.v[0][p], s.v[1][p], s.v[2][p]};
+    update_vEB(g.dt, qm, Ep, Bp, v);
+    s.v[0][p] = v[0]; s.v[1][p] = v[1]; s.v[2][p] = v[2];
+  }
 }
 
 __device__ inline double wave_sum(double v)
@@ -557,7 +611,10 @@ int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B)
 {
   if (s.n == 0) return 0;
   Timed t(c, "second_push");
-  hipLaunchKernelGGL(k_second_push, dim3(pgrid(s.n)), dim3(kBlock), 0, c->stream, c->g, s.d, s.n, E, B, s.par.q / s.par.m);
+  const long ngroups = (c->ncell + kSPW - 1) / kSPW;
+  const long chunk = (ngroups + 7) / 8;
+  hipLaunchKernelGGL(k_second_push, dim3((unsigned)(8 * chunk)), dim3(kSPW * 64), 0, c->stream, c->g, s.d, E, B,
+    s.par.q / s.par.m, (long)c->ncell, chunk);
   XPIC_HIP(hipGetLastError());
   return 0;
 }
