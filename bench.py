@@ -60,6 +60,18 @@ def cpu_baseline(args):
     }
 
 
+def pmc_traffic(grid):
+    """HBM bytes per k_matA launch from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    passes, KiB units, FETCH_SIZE x 2 on gfx950 -- tools/pmc_summary.py); only valid for the grid it was taken on."""
+    path = os.path.join(ROOT, "profiles", "r01_v4_pmc_traffic_256.txt")
+    if grid != 256 or not os.path.exists(path):
+        return None
+    for line in open(path):
+        if line.startswith("k_matA<true, true>"):
+            return float(line.split()[-2]) * 1e9
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +87,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--probe", action="store_true", help="also run the device copy probes (PMC calibration)")
+    ap.add_argument("--plain-gmres", action="store_true", help="unpreconditioned GMRES(30), as the CPU oracle runs")
     args = ap.parse_args()
 
     import torch
@@ -85,10 +98,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the xpic HIP path has no CPU fallback")
+    # XPIC_BENCH_COMM=gloo: rehearse the N > 1 path on a one-GPU box (all ranks share GPU 0, host-staged exchange)
+    rehearsal = os.environ.get("XPIC_BENCH_COMM", "rccl") == "gloo"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import xpic_amd as X
 
@@ -96,9 +116,12 @@ def main():
     # N > 1: the SAME global grid, cut into z-slabs (BASELINE.json configs[3]); one slab, one process, one GPU
     ctx = X.Context("ecsim", (n, n, n), (args.dx,) * 3, args.dt, device=local_rank, rank=rank, nranks=world)
     if world > 1:
-        from xpic_amd.parallel import init_rccl
+        from xpic_amd.parallel import GlooRing, init_rccl
 
-        init_rccl(ctx)
+        if rehearsal:
+            GlooRing().attach(ctx)
+        else:
+            init_rccl(ctx)
     N = ctx.N  # local cells
     npart = args.ppc * N
     s = ctx.add_sort(args.ppc, 1.0, -1.0, 1.0, capacity=int(npart * 1.02) + 1024)
@@ -118,6 +141,8 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if args.plain_gmres:
+        ctx.set_preconditioner(0)
     copy_rate = ctx.probe_copy_bandwidth(1 << 30, 5) if args.probe else None
     for _ in range(args.warmup):
         ctx.step()
@@ -131,10 +156,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dev = "cpu" if rehearsal else "cuda"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        it_t = torch.tensor([its], dtype=torch.float64, device="cuda")
+        it_t = torch.tensor([its], dtype=torch.float64, device=dev)
         dist.all_reduce(it_t, op=dist.ReduceOp.SUM)
         its_total = float(it_t.item())
     else:
@@ -150,7 +176,7 @@ def main():
     achieved = bytes_apply / (ms_apply / max(n_apply, 1) * 1e-3) / 1e9 if n_apply else 0.0
     count = ctx.count(s)
     if world > 1:
-        ct = torch.tensor([count], dtype=torch.float64, device="cuda")
+        ct = torch.tensor([count], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(ct)
         count = int(ct.item())
     assert count == world * npart, "particles were lost in a periodic box"
@@ -176,12 +202,15 @@ def main():
                            f"{world} z-slabs of {n // world} planes, RCCL halo / migration / dot all-reduce over xGMI",
         },
         "ksp_iters_per_s": its_total / world / (ms_solve * 1e-3) if ms_solve else None,  # iterations are global
+        "ksp_method": "GMRES(30), right-preconditioned by a Chebyshev polynomial in matM" if not args.plain_gmres
+                      else "GMRES(30), no preconditioner",
         "ksp_iterations_per_step": its_total / world / args.steps,
         "phase_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},
         "device_copy_GBps": copy_rate / 1e9 if copy_rate else None,
         "roofline": {
             "kernel": "k_matA (matL+matM SpMV)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": pmc_traffic(n) if world == 1 else None,
             "bytes_per_launch": bytes_apply, "launches": n_apply, "avg_ms": ms_apply / max(n_apply, 1),
         },
     }

@@ -284,7 +284,11 @@ __global__ void __launch_bounds__(kThreadsB) k_esirkepov_push(GridDev g, SortDev
 int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double* B, double* J, double* pred_w_host)
 {
   if (pred_w_host) *pred_w_host = 0.0;
-  if (s.n == 0) return 0;
+  if (s.n == 0) {
+    // an empty slab still takes part in the collective
+    if (pred_w_host) XPIC_CALL(comm_allreduce_sum_host(c, pred_w_host, 1));
+    return 0;
+  }
   const GridDev& g = c->g;
   XPIC_CHECK(g.nx >= 6 && g.ny >= 6 && g.nzl >= 6, "the Esirkepov tile needs every grid extent >= 6");
   const double qm = s.par.q / s.par.m;
