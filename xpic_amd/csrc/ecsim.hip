@@ -403,12 +403,15 @@ int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, d
   if (s.n == 0) return 0;
   Timed t(c, "fill_current");
   const GridDev& g = c->g;
-  const int ncol_y = 3 + g.ny % 3, ncol_z = 3 + g.nzl % 3;
+  // y is periodic inside the slab; z is periodic only when the slab is the whole box: with z-neighbours the rows
+  // below plane 0 / above plane nzl-1 are ghost rows of this rank alone, so plain residues mod 3 suffice
+  const int ncol_y = 3 + g.ny % 3, ncol_z = g.G == 0 ? 3 + g.nzl % 3 : 3;
   for (int b = 0; b < ncol_z; ++b)
     for (int a = 0; a < ncol_y; ++a) {
       int cy0, cys, ncy, cz0, czs, ncz;
       colour_class(g.ny, a, &cy0, &cys, &ncy);
-      colour_class(g.nzl, b, &cz0, &czs, &ncz);
+      if (g.G == 0) colour_class(g.nzl, b, &cz0, &czs, &ncz);
+      else { cz0 = b; czs = 3; ncz = (g.nzl - b + 2) / 3; }
       if (ncy == 0 || ncz == 0) continue;
       hipLaunchKernelGGL(k_ecsim_fill, dim3((unsigned)(ncy * ncz)), dim3(kThreads), 0, c->stream, g, s.d, B,
         currI_sort, matL, c->ltab, c->ltab + 36 * 36, s.par.q, s.par.m, s.par.n / (double)s.par.Np, cy0, cys, ncy,
