@@ -90,15 +90,23 @@ static int advance_fields(xpic_ctx* c, int op, const double* curr, double* out, 
 static int ecsim_fill_current(xpic_ctx* c)
 {
   const GridDev& g = c->g;
-  {
+  // MatZeroEntries (:164).  On a single slab every matL entry has a local writer, so the first species' assembly
+  // stores instead of adding (first touch) and no clearing pass is needed.  With z-neighbours some rows of the
+  // top / bottom planes are written only by the neighbour's ghost-row exchange: clear everything, add everywhere.
+  bool any = false;
+  for (auto& s : c->sorts) any = any || s.n > 0;
+  const bool first_touch = any && g.G == 0;
+  if (!first_touch) {
     Timed t(c, "matL_zero");
-    XPIC_HIP(hipMemsetAsync(c->matL, 0, sizeof(double) * matL_doubles(g), c->stream)); // MatZeroEntries :164
+    XPIC_HIP(hipMemsetAsync(c->matL, 0, sizeof(double) * matL_doubles(g), c->stream));
   }
   XPIC_CALL(vec_set(c, c->field[XPIC_CURRI], 0.0));
+  bool first_sort = first_touch;
   XPIC_CALL(halo_fill(c, c->field[XPIC_B], 1)); // DMGlobalToLocal(B) :474
   for (auto& s : c->sorts) {
     XPIC_HIP(hipMemsetAsync(s.currI, 0, sizeof(double) * c->nvec, c->stream));
-    XPIC_CALL(ecsim_fill_sort(c, s, c->field[XPIC_B], s.currI, c->matL));
+    XPIC_CALL(ecsim_fill_sort(c, s, c->field[XPIC_B], s.currI, c->matL, first_sort && s.n > 0));
+    if (s.n > 0) first_sort = false;
     XPIC_CALL(halo_add(c, s.currI, 1));                          // DMLocalToGlobal(ADD) particles.cpp:56
     XPIC_CALL(vec_axpy(c, c->field[XPIC_CURRI], 1.0, s.currI)); // particles.cpp:57
   }

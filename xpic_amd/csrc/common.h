@@ -201,7 +201,7 @@ int kinetic_sums_global(xpic_ctx* c, Sort& s, double* out5); // summed over the 
 int scale_velocities(xpic_ctx* c, Sort& s, double lambda);
 
 // ecsim.hip
-int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, double* matL);
+int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, double* matL, bool first_sort);
 int build_ltab(xpic_ctx* c);
 
 // esirkepov.hip: mode 0 basic::push, 1 ecsimcorr first_push, 2 ecsimcorr second_push

@@ -19,6 +19,8 @@
 //     the result is bitwise reproducible.  MatSetValuesCOO's duplicate summation (simulation.cpp:366) thus
 //     happens in LDS (x) and in launch order (y, z).
 // v1 flushed every cell block with ~1200 scattered fp64 atomics: 85 % of the kernel time at 256^3.
+#include <cstdint>
+
 #include "common.h"
 #include "device_common.h"
 #include "lstencil.h"
@@ -78,8 +80,8 @@ __device__ inline double load_bnb(const GridDev& g, const double* __restrict__ B
 }
 
 __global__ void __launch_bounds__(kThreads) k_ecsim_fill(GridDev g, SortDev s, const double* __restrict__ B,
-  double* currI, double* matL, const int* __restrict__ etab, const int* __restrict__ linetab, double q, double m,
-  double mpw, int cy0, int cystep, int ncy, int cz0, int czstep)
+  double* currI, double* matL, const int* __restrict__ etab, const int* __restrict__ linetab, const int* __restrict__ cowr, double q, double m,
+  double mpw, int cy0, int cystep, int ncy, int cz0, int czstep, int my_order, int ncol_y, int first_sort)
 {
   const int cy = cy0 + (int)(blockIdx.x % ncy) * cystep;
   const int cz = cz0 + (int)(blockIdx.x / ncy) * czstep;
@@ -122,9 +124,29 @@ __global__ void __launch_bounds__(kThreads) k_ecsim_fill(GridDev g, SortDev s, c
     // single slab: periodic fold; with z-neighbours matL carries one ghost row plane on each side
     const int rzw = g.G == 0 ? (rz < 0 ? rz + g.nzl : (rz >= g.nzl ? rz - g.nzl : rz)) : rz + 1;
     const int nzp = g.nzl + (g.G ? 2 : 0);
-    lbase[line] = line < kMatLines
+    double* base = line < kMatLines
       ? matL + ((((long)(ld & 3) * nzp + rzw) * g.ny + ry) * kLStencil + (ld >> 6)) * g.nx
       : currI + (ld & 3) * g.cstride + g.node(0, ry, g.wz(rz));
+    // First touch: if no other pencil that also writes this matL line runs in an EARLIER launch, this workgroup
+    // is the first writer of the step and stores instead of read-modify-write (no memset of matL, half the reads).
+    // Co-writers sit at pencil offsets (-dy', -dz') listed in cowr[line]; launch order = cz colour * ncol_y + cy colour.
+    bool first = first_sort && line < kMatLines;
+    if (first) {
+      const int bodyy = g.ny - g.ny % 3, bodyz = g.nzl - g.nzl % 3;
+      for (int e = 0; e < 8 && first; ++e) {
+        const int w = cowr[line * 8 + e];
+        if (w == 0x7fffffff) break;
+        const int oy = (w & 0xff) - 8, oz = ((w >> 8) & 0xff) - 8;
+        int py = cy + oy, pz = cz + oz;
+        py = py < 0 ? py + g.ny : (py >= g.ny ? py - g.ny : py);
+        if (g.G == 0) pz = pz < 0 ? pz + g.nzl : (pz >= g.nzl ? pz - g.nzl : pz);
+        else if (pz < 0 || pz >= g.nzl) continue; // no such local pencil: the neighbour rank's rows are its own
+        const int ca = py < bodyy ? py % 3 : 3 + (py - bodyy);
+        const int cb = g.G == 0 ? (pz < bodyz ? pz % 3 : 3 + (pz - bodyz)) : pz % 3;
+        if (cb * ncol_y + ca < my_order) first = false;
+      }
+    }
+    lbase[line] = (double*)((uintptr_t)base | (first ? 1u : 0u));
   }
 
   // cells are visited in the order 1, 2, ..., nx-1, 0 so that finished columns start 64-byte aligned
@@ -298,12 +320,15 @@ __global__ void __launch_bounds__(kThreads) k_ecsim_fill(GridDev g, SortDev s, c
     const int fslot = threadIdx.x % kW, fline0 = threadIdx.x / kW;
     double old[kItems];
     double* ptr[kItems];
+    bool fst[kItems];
 #pragma unroll
     for (int mm = 0; mm < kItems; ++mm) {
       const int line = fline0 + mm * (kThreads / kW);
       const bool ok = line < kLines && fslot < ndone;
-      ptr[mm] = ok ? lbase[line] + (j * kW + fslot) : nullptr;
-      old[mm] = ok ? *ptr[mm] : 0.0;
+      const uintptr_t lb = ok ? (uintptr_t)lbase[line] : 0;
+      fst[mm] = lb & 1;
+      ptr[mm] = ok ? (double*)(lb & ~(uintptr_t)1) + (j * kW + fslot) : nullptr;
+      old[mm] = (ok && !fst[mm]) ? *ptr[mm] : 0.0;
     }
 
     // ---- merge the chunk's cell blocks in the window (aliased over the now dead stages)
@@ -332,7 +357,7 @@ __global__ void __launch_bounds__(kThreads) k_ecsim_fill(GridDev g, SortDev s, c
       const int line = fline0 + mm * (kThreads / kW);
       if (ptr[mm]) {
         const double val = win[line * kSlots + fslot];
-        if (val != 0.0) *ptr[mm] = old[mm] + val;
+        if (val != 0.0 || fst[mm]) *ptr[mm] = old[mm] + val;
       }
     }
     for (int t = threadIdx.x; t < kLines * 2; t += kThreads) carry[t] = win[(t >> 1) * kSlots + ndone + (t & 1)];
@@ -344,7 +369,7 @@ __global__ void __launch_bounds__(kThreads) k_ecsim_fill(GridDev g, SortDev s, c
   __syncthreads();
   for (int t = threadIdx.x; t < kLines * 2; t += kThreads) {
     const double val = carry[t];
-    if (val != 0.0) unsafeAtomicAdd(lbase[t >> 1] + g.wx(t & 1), val);
+    if (val != 0.0) unsafeAtomicAdd((double*)((uintptr_t)lbase[t >> 1] & ~(uintptr_t)1) + g.wx(t & 1), val);
   }
 }
 
@@ -383,9 +408,25 @@ int build_ltab(xpic_ctx* c)
       int id = cidx == 0 ? o[2] * 2 + o[1] : (cidx == 1 ? 4 + o[2] * 3 + (o[1] + 1) : 10 + (o[2] + 1) * 2 + o[1]);
       linetab[kMatLines + id] = cidx | ((o[1] + 1) << 2) | ((o[2] + 1) << 4);
     }
-  XPIC_HIP(hipMalloc(&c->ltab, sizeof(int) * (etab.size() + linetab.size())));
+  // co-writers of a matL line (c1, dy, dz, k): the pencils at offset (dy - dy', dz - dz') for every other line
+  // (c1, dy', dz', k) of the table -- they add into the same matL row stream
+  std::vector<int> cowr(kLines * 8, 0x7fffffff);
+  for (int l = 0; l < kMatLines; ++l) {
+    int n = 0;
+    for (int l2 = 0; l2 < kMatLines; ++l2) {
+      if (l2 == l) continue;
+      const int a = linetab[l], b = linetab[l2];
+      if ((a & 3) != (b & 3) || (a >> 6) != (b >> 6)) continue;
+      const int oy = ((a >> 2) & 3) - ((b >> 2) & 3), oz = ((a >> 4) & 3) - ((b >> 4) & 3);
+      XPIC_CHECK(n < 8, "too many co-writers of a matL line");
+      cowr[l * 8 + n++] = (oy + 8) | ((oz + 8) << 8);
+    }
+  }
+  const size_t total = etab.size() + linetab.size() + cowr.size();
+  XPIC_HIP(hipMalloc(&c->ltab, sizeof(int) * total));
   XPIC_HIP(hipMemcpy(c->ltab, etab.data(), sizeof(int) * etab.size(), hipMemcpyHostToDevice));
   XPIC_HIP(hipMemcpy(c->ltab + etab.size(), linetab.data(), sizeof(int) * linetab.size(), hipMemcpyHostToDevice));
+  XPIC_HIP(hipMemcpy(c->ltab + etab.size() + linetab.size(), cowr.data(), sizeof(int) * cowr.size(), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -398,7 +439,7 @@ static void colour_class(int n, int colour, int* first, int* step, int* count)
   else { *first = body + (colour - 3); *step = 1; *count = 1; }
 }
 
-int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, double* matL)
+int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, double* matL, bool first_sort)
 {
   if (s.n == 0) return 0;
   Timed t(c, "fill_current");
@@ -414,8 +455,8 @@ int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, d
       else { cz0 = b; czs = 3; ncz = (g.nzl - b + 2) / 3; }
       if (ncy == 0 || ncz == 0) continue;
       hipLaunchKernelGGL(k_ecsim_fill, dim3((unsigned)(ncy * ncz)), dim3(kThreads), 0, c->stream, g, s.d, B,
-        currI_sort, matL, c->ltab, c->ltab + 36 * 36, s.par.q, s.par.m, s.par.n / (double)s.par.Np, cy0, cys, ncy,
-        cz0, czs);
+        currI_sort, matL, c->ltab, c->ltab + 36 * 36, c->ltab + 36 * 36 + kLines, s.par.q, s.par.m,
+        s.par.n / (double)s.par.Np, cy0, cys, ncy, cz0, czs, b * ncol_y + a, ncol_y, first_sort ? 1 : 0);
     }
   XPIC_HIP(hipGetLastError());
   return 0;
