@@ -1,0 +1,120 @@
+"""Edge cases through the C ABI, against the CPU oracle: empty and ragged species, cells holding far more particles
+than one staging pass, grid extents that are not multiples of any tile size, a single particle."""
+import numpy as np
+import pytest
+
+from test_gpu_ecsim import canon
+
+pytestmark = pytest.mark.gpu
+
+
+def pair(oracle, scheme, n, d, dt):
+    import xpic_amd as X
+
+    o = oracle.OracleSim(scheme, n, d, dt)
+    g = X.Context(scheme, n, d, dt)
+    if scheme != "basic":
+        g.set_preconditioner(0)
+    return o, g
+
+
+def same_fields(o, g, names, tol=1e-9):
+    import xpic_amd as X
+
+    ids = {"E": X.E, "B": X.B, "J": X.J, "currI": X.CURRI}
+    for name in names:
+        a, b = o.get_field(name), g.get_field(ids[name])
+        scale = max(np.abs(a).max(), 1e-300)
+        assert np.abs(a - b).max() <= tol * scale, name
+
+
+@pytest.mark.parametrize("scheme", ["ecsim", "ecsimcorr", "basic"])
+def test_empty_species(oracle, scheme):
+    """No particles at all: the step is a vacuum Maxwell update, nothing may fault or hang."""
+    import xpic_amd as X
+
+    n, d = (8, 7, 6), (0.5, 0.5, 0.5)
+    o, g = pair(oracle, scheme, n, d, 0.3)
+    o.add_sort(4, 1.0, -1.0, 1.0)
+    g.add_sort(4, 1.0, -1.0, 1.0, capacity=1000)
+    rng = np.random.default_rng(1)
+    E, B = rng.normal(0, 0.1, o.fshape()), rng.normal(0, 0.1, o.fshape())
+    for name, fid, F in (("E", X.E, E), ("B", X.B, B)):
+        o.set_field(name, F)
+        g.set_field(fid, F)
+    for _ in range(2):
+        o.step()
+        g.step()
+    same_fields(o, g, ["E", "B"], 1e-7)
+    assert g.count(0) == 0
+    assert g.update_cells(0) == 0
+
+
+def test_ragged_cells_and_long_cells(oracle):
+    """Vacuum almost everywhere, one cell with 300 particles (10 staging passes), one with 33, one with 1."""
+    import xpic_amd as X
+
+    n, d = (13, 9, 7), (0.5, 0.4, 0.3)
+    o, g = pair(oracle, "ecsim", n, d, 0.5)
+    o.add_sort(10, 1.0, -1.0, 1.0)
+    g.add_sort(10, 1.0, -1.0, 1.0, capacity=5000)
+    rng = np.random.default_rng(2)
+    pts = []
+    for cell, cnt in (((12, 8, 6), 300), ((0, 0, 0), 33), ((5, 3, 2), 1), ((6, 3, 2), 64), ((12, 0, 6), 65)):
+        r = (np.array(cell) + rng.random((cnt, 3))) * np.array(d)
+        pts.append(np.hstack([r, rng.normal(0, 0.2, (cnt, 3))]))
+    pts = np.vstack(pts)
+    assert o.add_particles(0, pts) == g.add_particles(0, pts) == len(pts)
+    B = np.zeros(o.fshape()) + np.array([0.1, -0.2, 0.4])
+    for name, fid in (("B", X.B), ("B0", X.B0)):
+        o.set_field(name, B)
+        g.set_field(fid, B)
+    oracle.lib().orc_ecsim_fill_current(o.h)
+    g.ecsim_fill_current()
+    Lo, Lg = o.matL(), g.matL()
+    assert np.abs(Lo - Lg).max() <= 1e-12 * np.abs(Lo).max()
+    assert np.count_nonzero(Lg) == np.count_nonzero(Lo)  # untouched rows are exactly zero
+    same_fields(o, g, ["currI"], 1e-12)
+    for s in (o, g):
+        s.set_tolerances(1e-11, 1e-50, 300)
+    for _ in range(3):
+        assert o.step() >= 0
+        g.step()
+    same_fields(o, g, ["E", "B"], 1e-6)
+    po, co = canon(*o.particles(0))
+    pg, cg = canon(*g.particles(0))
+    assert np.array_equal(co, cg) and np.abs(po - pg).max() < 1e-9
+
+
+def test_single_particle_basic(oracle):
+    import xpic_amd as X
+
+    n, d = (7, 6, 9), (0.5, 0.5, 0.5)
+    o, g = pair(oracle, "basic", n, d, 0.1)
+    o.add_sort(1, 1.0, -1.0, 1.0)
+    g.add_sort(1, 1.0, -1.0, 1.0, capacity=16)
+    p = np.array([[3.49999, 0.0, 4.25, 0.3, -0.8, 0.9]])  # sits on a cell face in y, about to cross in x
+    assert o.add_particles(0, p) == g.add_particles(0, p) == 1
+    for _ in range(12):
+        assert o.step() == 0
+        g.step()
+    same_fields(o, g, ["E", "B", "J"], 1e-10)
+    assert np.abs(o.particles(0)[0] - g.particles(0)[0]).max() < 1e-12
+    assert o.particles(0)[1][0] == g.particles(0)[1][0]
+
+
+def test_capacity_and_argument_errors():
+    import xpic_amd as X
+
+    g = X.Context("ecsim", (8, 8, 8), (0.5, 0.5, 0.5), 1.0)
+    s = g.add_sort(1, 1.0, -1.0, 1.0, capacity=10)
+    with pytest.raises(X.XpicError, match="capacity"):
+        g.add_particles(s, np.zeros((11, 6)) + 1.0)
+    with pytest.raises(X.XpicError):
+        g.set_field(99, np.zeros(g.fshape()))
+    with pytest.raises(X.XpicError, match="in place"):
+        g.rot_apply(+1, 1.0, X.E, X.E)
+    with pytest.raises(X.XpicError):
+        X.Context("ecsim", (3, 8, 8), (0.5, 0.5, 0.5), 1.0)  # extent below the stencil width
+    with pytest.raises(X.XpicError, match="basic scheme"):
+        X.Context("basic", (8, 8, 8), (0.5, 0.5, 0.5), 1.0).ecsim_fill_current()

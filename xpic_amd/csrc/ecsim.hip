@@ -149,6 +149,9 @@ __global__ void __launch_bounds__(kThreads) k_ecsim_fill(GridDev g, SortDev s, c
     lbase[line] = (double*)((uintptr_t)base | (first ? 1u : 0u));
   }
 
+  // lbase / carry are read by other threads from the first chunk on (the RMW prefetch comes before any barrier)
+  __syncthreads();
+
   // cells are visited in the order 1, 2, ..., nx-1, 0 so that finished columns start 64-byte aligned
   auto cell_x = [&](int i) { return (i + 1 == g.nx) ? 0 : i + 1; };
   auto prefetch_cell = [&](int i, Prefetch& pf) {
