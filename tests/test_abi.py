@@ -53,3 +53,33 @@ def test_product_does_not_reference_the_oracle():
                     continue
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in txt.lower(), os.path.join(dirpath, f)
+
+
+def test_host_mirror_selftest():
+    """Host logic of the C++ mirror (JSON reader, Builder::parse_value units, TableDiagnostic text format against
+    literal lines of the reference's golden tables) -- runs without a GPU."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "xpic_amd", "host", "xpic_hip.out")
+    if not os.path.exists(exe):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    out = subprocess.run([exe, "--selftest"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "selftest ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_host_mirror_fails_loudly_without_gpu(tmp_path):
+    import json
+    import subprocess
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    exe = os.path.join(ROOT, "xpic_amd", "host", "xpic_hip.out")
+    cfg = json.load(open(os.path.join(ROOT, "tests", "golden", "ecsim_ex1", "config.json")))
+    cfg["OutputDirectory"] = str(tmp_path)
+    (tmp_path / "c.json").write_text(json.dumps(cfg))
+    out = subprocess.run([exe, str(tmp_path / "c.json")], capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "no ROCm-capable device" in (out.stdout + out.stderr)

@@ -223,6 +223,7 @@ class TableDiagnostic : public interfaces::Diagnostic {
 public:
   explicit TableDiagnostic(const std::string& filename);
   PetscErrorCode diagnose(PetscInt t) override;
+  PetscErrorCode finalize() override { file_.close(); return 0; }
   virtual PetscErrorCode add_columns(PetscInt /* t */) { return 0; }
   void add(PetscInt w, std::string title, const char* printf_fmt, double value, PetscInt pos = -1);
   void add_int(PetscInt w, std::string title, long value);
