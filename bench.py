@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--probe", action="store_true", help="also run the device copy probes (PMC calibration)")
     ap.add_argument("--plain-gmres", action="store_true", help="unpreconditioned GMRES(30), as the CPU oracle runs")
+    ap.add_argument("--scheme", default="ecsim", choices=["ecsim", "ecsimcorr", "basic"],
+                    help="ecsim is the headline workload; the others are side measurements (no cpu_baseline)")
     args = ap.parse_args()
 
     import torch
@@ -114,7 +116,7 @@ def main():
 
     n = args.grid
     # N > 1: the SAME global grid, cut into z-slabs (BASELINE.json configs[3]); one slab, one process, one GPU
-    ctx = X.Context("ecsim", (n, n, n), (args.dx,) * 3, args.dt, device=local_rank, rank=rank, nranks=world)
+    ctx = X.Context(args.scheme, (n, n, n), (args.dx,) * 3, args.dt, device=local_rank, rank=rank, nranks=world)
     if world > 1:
         from xpic_amd.parallel import GlooRing, init_rccl
 
@@ -141,7 +143,7 @@ def main():
         if world > 1:
             dist.barrier()
 
-    if args.plain_gmres:
+    if args.plain_gmres and args.scheme != "basic":
         ctx.set_preconditioner(0)
     copy_rate = ctx.probe_copy_bandwidth(1 << 30, 5) if args.probe else None
     for _ in range(args.warmup):
@@ -168,7 +170,8 @@ def main():
 
     prof = {k: ctx.profile_get(k) for k in ("matA_apply", "solve_matA", "fill_current", "move_bin", "scatter",
                                             "second_push", "mdot", "maxpy", "matL_zero", "scan", "rot_apply",
-                                            "halo", "migrate", "matL_ghost_rows")}
+                                            "halo", "migrate", "matL_ghost_rows", "basic_push", "corr_first_push",
+                                            "corr_second_push", "solve_matM", "precond", "matL_apply")}
     n_apply, ms_apply = prof["matA_apply"]
     n_solve, ms_solve = prof["solve_matA"]
     # algorithmic bytes of one matA apply: 123 fp64 coefficients per row, 3N rows, + read x + write y
@@ -195,8 +198,9 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"3D ECSIM electromagnetic, {n}^3 cells, {args.ppc} ppc, 1 electron species, "
-                        f"GMRES(30) on matL+matM rtol=atol=1e-7 (BASELINE.json configs[2])",
+            "workload": (f"3D ECSIM electromagnetic, {n}^3 cells, {args.ppc} ppc, 1 electron species, "
+                         f"GMRES(30) on matL+matM rtol=atol=1e-7 (BASELINE.json configs[2])") if args.scheme == "ecsim"
+                        else f"scheme {args.scheme}, {n}^3 cells, {args.ppc} ppc (side measurement)",
             "grid": [n, n, n], "ppc": args.ppc, "particles_per_gpu": npart, "dx": args.dx, "dt": args.dt,
             "parallelism": "1 GPU" if world == 1 else
                            f"{world} z-slabs of {n // world} planes, RCCL halo / migration / dot all-reduce over xGMI",
@@ -215,7 +219,7 @@ def main():
         },
     }
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.scheme == "ecsim":
             line["cpu_baseline"] = cpu_baseline(args)
         else:
             line["cpu_baseline"] = None

@@ -342,3 +342,30 @@ def test_config2_size_properties():
     tot0, tot1 = e0[0] + e0[1] + e0[4], e1[0] + e1[1] + e1[4]
     assert abs(tot1 - tot0) <= 1e-7 * tot0
     assert e1[0] > 0 and e1[1] > 0
+
+
+def test_headline_size_properties():
+    """BASELINE config 3 at full size (256^3 cells, 64 ppc = 1.07e9 particles, ~180 GB of HBM), size-independent
+    properties only: every particle survives the periodic re-binning, the default (preconditioned) solve converges
+    within the reference's maxit, the scheme conserves energy to the accuracy of the field solve, the fields grow
+    from the thermal noise, and an extra re-bin of already binned particles is the identity."""
+    import xpic_amd as X
+
+    n = (256, 256, 256)
+    g = X.Context("ecsim", n, (0.5, 0.5, 0.5), 1.0)
+    N = n[0] * n[1] * n[2]
+    s = g.add_sort(64, 1.0, -1.0, 1.0, capacity=int(64 * N * 1.02))
+    g.fill_synthetic(s, 64, 0.014, seed=11)
+    assert g.count(s) == 64 * N
+    e0 = g.energy()
+    its = [g.step() for _ in range(2)]
+    assert all(0 < i <= 100 for i in its)
+    e1 = g.energy()
+    assert g.count(s) == 64 * N
+    tot0, tot1 = e0[0] + e0[1] + e0[4], e1[0] + e1[1] + e1[4]
+    assert abs(tot1 - tot0) <= 1e-7 * tot0
+    assert e1[0] > 0 and e1[1] > 0
+    assert g.update_cells(s) == 64 * N
+    e2 = g.energy()
+    assert e2[4] == e1[4] or abs(e2[4] - e1[4]) <= 1e-13 * e1[4]  # same particles, maybe another summation order
+    g.close()
