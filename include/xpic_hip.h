@@ -158,6 +158,14 @@ int xpic_step(xpic_ctx* ctx, int* ksp_iterations);
  * out = {wE, wB, sE, sB, wK_0, sK_0, wK_1, sK_1, ...} */
 int xpic_energy(xpic_ctx* ctx, double* out);
 
+/* ParticlesChargeDensity::collect of one sort (src/diagnostics/charge_conservation.cpp:67-97) -> rho[z][y][x] */
+int xpic_charge_density(xpic_ctx* ctx, int sort, double* rho_zyx);
+/* ChargeConservation (charge_conservation.cpp:117-171): xpic_charge_collect() = initialize(); then once per step
+ * xpic_charge_columns(): out = {N1dQ_0, N2dQ_0, ..., N1dQ_tot, N2dQ_tot} of (rho_new - rho_old)/dt + div(-) J.
+ * Uses the scratch vectors XPIC_W0..W2. */
+int xpic_charge_collect(xpic_ctx* ctx);
+int xpic_charge_columns(xpic_ctx* ctx, double* out);
+
 /* ---- z-slab decomposition (DMDA da_processors_z = nranks; src/utils/world.cpp:36-38).  A context created with
  * nranks > 1 owns planes [rank*nz/nranks, (rank+1)*nz/nranks) and must be given a communicator before any
  * call that moves data between slabs (steps, solves, operator applies, re-binning, energy): those calls are

@@ -60,6 +60,30 @@ def test_esirkepov_continuity_on_device(oracle):
     assert np.abs(res).max() <= 1e-11 * max(np.abs(div).max(), 1e-30)
 
 
+@pytest.mark.parametrize("scheme", ["basic", "ecsim", "ecsimcorr"])
+def test_charge_conservation_diagnostic_on_device(oracle, scheme):
+    """xpic_charge_density / xpic_charge_columns (ChargeConservation, charge_conservation.cpp:67-171): the density
+    equals the oracle's; the continuity residual columns are round-off for the Esirkepov schemes and equal the
+    oracle's (finite) residual for plain ecsim, whose currI is not charge conserving."""
+    n, d, dt = GRID
+    o, g = make_pair(oracle, scheme, n, d, dt, [(6, 1.0, -1.0, 1.0), (3, 1.0, 1.0, 50.0)], B0=(0.0, 0.0, 0.5), vth=0.1)
+    for k in range(2):
+        a, b = o.charge_density(k), g.charge_density(k)
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
+    o.charge_collect()
+    g.charge_collect()
+    for t in range(3):
+        assert o.step() >= 0
+        g.step()
+        qo, qg = o.charge_columns(), g.charge_columns()
+        assert qo.shape == qg.shape == (6,)
+        if scheme == "ecsim":
+            assert np.abs(qo - qg).max() <= 1e-6 * qo.max(), (t, qo, qg)
+        else:
+            scale = np.abs(o.charge_density(0)).sum() / dt
+            assert qg.max() <= 1e-11 * scale and qo.max() <= 1e-11 * scale, (t, qo, qg, scale)
+
+
 def test_basic_steps_match_oracle(oracle):
     import xpic_amd as X
 

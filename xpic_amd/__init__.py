@@ -28,7 +28,7 @@ SYMBOLS = [
     "xpic_update_cells", "xpic_ecsim_fill_current", "xpic_ecsim_second_push", "xpic_basic_push",
     "xpic_ecsimcorr_first_push", "xpic_ecsimcorr_second_push", "xpic_ecsimcorr_final_update",
     "xpic_calculate_energy", "xpic_ecsimcorr_scalars", "xpic_solve", "xpic_set_tolerances", "xpic_set_preconditioner", "xpic_step",
-    "xpic_energy", "xpic_comm_rccl_unique_id", "xpic_comm_init_rccl", "xpic_comm_init_callbacks",
+    "xpic_energy", "xpic_charge_density", "xpic_charge_collect", "xpic_charge_columns", "xpic_comm_rccl_unique_id", "xpic_comm_init_rccl", "xpic_comm_init_callbacks",
     "xpic_profile_enable", "xpic_profile_reset", "xpic_profile_get", "xpic_probe_copy_bandwidth",
 ]
 
@@ -291,6 +291,19 @@ class Context:
     def energy(self):
         out = np.zeros(4 + 2 * self.nsorts)
         self._ck(self.L.xpic_energy(self.h, _dp(out)))
+        return out
+
+    def charge_density(self, sort):
+        rho = np.zeros((self.nzl, self.n[1], self.n[0]))
+        self._ck(self.L.xpic_charge_density(self.h, sort, _dp(rho)))
+        return rho
+
+    def charge_collect(self):
+        self._ck(self.L.xpic_charge_collect(self.h))
+
+    def charge_columns(self):
+        out = np.zeros(2 * self.nsorts + 2)
+        self._ck(self.L.xpic_charge_columns(self.h, _dp(out)))
         return out
 
     def synchronize(self):

@@ -665,6 +665,56 @@ int xpic_energy(xpic_ctx* ctx, double* out)
   return 0;
 }
 
+static double* sort_current(xpic_ctx* ctx, Sort& s)
+{
+  return ctx->scheme == XPIC_BASIC ? s.J : (ctx->scheme == XPIC_ECSIM ? s.currI : s.currJe);
+}
+
+int xpic_charge_density(xpic_ctx* ctx, int sort, double* rho_zyx)
+{
+  CTX_CHECK(ctx); SORT_CHECK(sort);
+  double* tmp = ctx->field[XPIC_W2];
+  XPIC_CALL(charge_density(ctx, ctx->sorts[sort], tmp));
+  std::vector<double> v3((size_t)ctx->g.nown * 3);
+  XPIC_CALL(field_export(ctx, tmp, v3.data()));
+  for (long i = 0; i < ctx->g.nown; ++i) rho_zyx[i] = v3[3 * i];
+  return 0;
+}
+
+int xpic_charge_collect(xpic_ctx* ctx) // ChargeConservation::initialize, charge_conservation.cpp:117-123
+{
+  CTX_CHECK(ctx);
+  for (auto& s : ctx->sorts) {
+    if (!s.rho) XPIC_HIP(hipMalloc(&s.rho, sizeof(double) * ctx->nvec));
+    XPIC_CALL(charge_density(ctx, s, s.rho));
+  }
+  return 0;
+}
+
+int xpic_charge_columns(xpic_ctx* ctx, double* out) // ChargeConservation::add_columns, :125-171
+{
+  CTX_CHECK(ctx);
+  double* sum = ctx->field[XPIC_W0];
+  double* diff = ctx->field[XPIC_W1];
+  double* fresh = ctx->field[XPIC_W2];
+  XPIC_CALL(vec_set(ctx, sum, 0.0));
+  size_t i = 0;
+  for (; i < ctx->sorts.size(); ++i) {
+    Sort& s = ctx->sorts[i];
+    XPIC_CHECK(s.rho, "xpic_charge_collect must run first");
+    XPIC_CALL(charge_density(ctx, s, fresh));
+    XPIC_CALL(vec_waxpby(ctx, diff, 1.0 / ctx->g.dt, fresh, -1.0 / ctx->g.dt, s.rho)); // (rho_new - rho_old) / dt
+    XPIC_CALL(vec_copy(ctx, s.rho, fresh));
+    XPIC_CALL(vec_axpy(ctx, sum, 1.0, diff));
+    XPIC_CALL(div_neg_add(ctx, sort_current(ctx, s), diff));
+    XPIC_CALL(scalar_norm12_host(ctx, diff, out + 2 * i));
+  }
+  double* total = ctx->scheme == XPIC_BASIC ? ctx->field[XPIC_J] : (ctx->scheme == XPIC_ECSIM ? ctx->field[XPIC_CURRI] : ctx->field[XPIC_CURRJE]);
+  XPIC_CALL(div_neg_add(ctx, total, sum));
+  XPIC_CALL(scalar_norm12_host(ctx, sum, out + 2 * i));
+  return 0;
+}
+
 int xpic_profile_enable(xpic_ctx* ctx, int on) { CTX_CHECK(ctx); ctx->profiling = on != 0; return 0; }
 
 int xpic_profile_reset(xpic_ctx* ctx)

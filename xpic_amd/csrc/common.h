@@ -90,6 +90,7 @@ struct Sort {
   double* J = nullptr;      // basic: J
   double* currI = nullptr;  // ecsim: currI
   double* currJe = nullptr; // ecsimcorr: currJe
+  double* rho = nullptr;    // ChargeConservation: last collected charge density (component 0 of a vector)
   // particle migration between z-slabs (nranks > 1)
   double* mig_send[2] = {nullptr, nullptr};
   double* mig_recv = nullptr;
@@ -180,6 +181,8 @@ int matM_apply(xpic_ctx* c, const double* x, double* y, bool add);
 int matL_apply(xpic_ctx* c, const double* x, double* y, bool add);
 int matA_apply(xpic_ctx* c, const double* x, double* y);
 int cheb_matM_inverse(xpic_ctx* c, const double* r, double* out);
+int div_neg_add(xpic_ctx* c, double* v3, double* out_scalar);
+int scalar_norm12_host(xpic_ctx* c, const double* f, double* out2);
 int field_import(xpic_ctx* c, double* dst_soa, const double* src_aos_host);
 int field_export(xpic_ctx* c, const double* src_soa, double* dst_aos_host);
 int field_stats_host(xpic_ctx* c, const double* f, double* sumsq, double* mean3);
@@ -196,6 +199,7 @@ int sort_append_host(xpic_ctx* c, Sort& s, int64_t n, const double* pts6, int64_
 int sort_download(xpic_ctx* c, Sort& s, double* pts6, int32_t* cell_of);
 int sort_fill_synthetic(xpic_ctx* c, Sort& s, int ppc, double vth, uint64_t seed);
 int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B);
+int charge_density(xpic_ctx* c, Sort& s, double* rho_vec);
 int kinetic_sums_host(xpic_ctx* c, Sort& s, double* out5);   // local sums of vx, vy, vz, v^2 and the count
 int kinetic_sums_global(xpic_ctx* c, Sort& s, double* out5); // summed over the slabs
 int scale_velocities(xpic_ctx* c, Sort& s, double lambda);

@@ -1,6 +1,7 @@
 // fields.hip -- grid-side kernels: BLAS-1 (K14), curl (K11), matM (K12), matL / matA SpMV (K13),
 // layout conversion at the boundary, two-stage reductions.  All HBM-bound; see DESIGN.md for the
 // algorithmic byte counts each kernel is measured against.
+#include <cmath>
 #include <utility>
 
 #include "common.h"
@@ -390,6 +391,34 @@ __global__ void __launch_bounds__(kRowX* kRowY, 4) k_matA(GridDev g, const doubl
   else Y[o] = r;
 }
 
+// Divergence, negative Yee shift (src/utils/operators.cpp:275-333), added into component 0 of `out`;
+// then |.|_1 and |.|_2^2 partials of that scalar
+__global__ void __launch_bounds__(kBlock) k_div_neg_add(GridDev g, const double* __restrict__ v, double* out)
+{
+  const double ix = 1.0 / g.dx, iy = 1.0 / g.dy, iz = 1.0 / g.dz;
+  const long stride = (long)gridDim.x * kBlock;
+  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < g.nown; i += stride) {
+    int x = (int)(i % g.nx), y = (int)((i / g.nx) % g.ny), z = (int)(i / g.plane);
+    const long c0 = g.nodew(x, y, z);
+    const double dv = +ix * v[c0] - ix * v[g.nodew(x - 1, y, z)] + iy * v[g.cstride + c0] -
+      iy * v[g.cstride + g.nodew(x, y - 1, z)] + iz * v[2 * g.cstride + c0] - iz * v[2 * g.cstride + g.nodew(x, y, z - 1)];
+    out[c0] += dv;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_norm12(GridDev g, const double* f, double* partial)
+{
+  double acc[2] = {0.0, 0.0};
+  const long off = (long)g.G * g.plane; // component 0
+  const long stride = (long)gridDim.x * kBlock;
+  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < g.nown; i += stride) {
+    const double v = f[off + i];
+    acc[0] += fabs(v);
+    acc[1] += v * v;
+  }
+  block_reduce_store<2>(acc, partial, gridDim.x, blockIdx.x);
+}
+
 // ---- boundary layout conversion: [z][y][x][3] (reference DMDA order) <-> SoA with ghost planes ----
 __global__ void __launch_bounds__(kBlock) k_import(GridDev g, const double* aos, double* soa)
 {
@@ -563,6 +592,28 @@ int cheb_matM_inverse(xpic_ctx* c, const double* r, double* out)
     std::swap(z0, z1);
   }
   return vec_copy(c, out, z0);
+}
+
+int div_neg_add(xpic_ctx* c, double* v3, double* out_scalar)
+{
+  XPIC_CALL(halo_fill(c, v3, 1));
+  long blocks = (c->g.nown + kBlock - 1) / kBlock;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(k_div_neg_add, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, c->g, v3, out_scalar);
+  XPIC_HIP(hipGetLastError());
+  return 0;
+}
+
+int scalar_norm12_host(xpic_ctx* c, const double* f, double* out2) // VecNorm(NORM_1_AND_2) of component 0
+{
+  long blocks = (c->g.nown + kBlock * 4 - 1) / (kBlock * 4);
+  if (blocks > kRedBlocks) blocks = kRedBlocks;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_norm12, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, c->g, f, c->red_partial);
+  XPIC_HIP(hipGetLastError());
+  XPIC_CALL(finish_reduce(c, 2, (int)blocks, 1, out2));
+  out2[1] = std::sqrt(out2[1]);
+  return 0;
 }
 
 int field_import(xpic_ctx* c, double* dst, const double* src_host)

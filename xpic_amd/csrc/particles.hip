@@ -344,6 +344,43 @@ __global__ void __launch_bounds__(kBlock) k_scale_v(SortDev s, int64_t n, double
   s.v[0][p] *= lambda; s.v[1][p] *= lambda; s.v[2][p] *= lambda;
 }
 
+// ParticlesChargeDensity::collect (src/diagnostics/charge_conservation.cpp:34-97): 3 x 3 x 3 nodes from
+// ceil(r/dx - 1.5), weight spline2 x spline2 x spline2, value q * n/Np.  Diagnostic, off the hot path: plain atomics.
+__device__ inline double spline2_d(double s)
+{
+  s = fabs(s);
+  if (s <= 0.5) return (0.75 - s * s);
+  if (0.5 < s && s < 1.5) return 0.5 * (1.5 - s) * (1.5 - s);
+  return 0.0;
+}
+
+__global__ void __launch_bounds__(kBlock) k_charge_density(GridDev g, SortDev s, int64_t n, double qn, double* rho)
+{
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n) return;
+  const double pr[3] = {s.r[0][p] / g.dx, s.r[1][p] / g.dy, s.r[2][p] / g.dz};
+  int st[3];
+  double w[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    st[a] = (int)ceil(pr[a] - 1.5);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) w[a][t] = spline2_d(pr[a] - (double)(st[a] + t));
+  }
+  st[2] -= g.z0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        // cache[i] = sfunc(x) * sfunc(y) * sfunc(z); arr += q * cache * n_Np   (:57, :90)
+        const int x = ((st[0] + i) % g.nx + g.nx) % g.nx, y = ((st[1] + j) % g.ny + g.ny) % g.ny;
+        const double v = w[0][i] * w[1][j] * w[2][k];
+        if (v != 0.0) unsafeAtomicAdd(&rho[g.node(x, y, g.wz(st[2] + k))], qn * v);
+      }
+}
+
 // AoS Point records (host staging buffer on device) -> SoA tail of the sort
 __global__ void __launch_bounds__(kBlock) k_unpack(SortDev s, int64_t at, int64_t n, const double* pts6)
 {
@@ -464,7 +501,7 @@ void sort_free(Sort& s)
     (void)hipFree(s.d.r[a]); (void)hipFree(s.d.v[a]); (void)hipFree(s.d.r2[a]); (void)hipFree(s.d.v2[a]);
   }
   (void)hipFree(s.d.cell); (void)hipFree(s.d.rank); (void)hipFree(s.d.cell_count); (void)hipFree(s.d.cell_start);
-  (void)hipFree(s.J); (void)hipFree(s.currI); (void)hipFree(s.currJe);
+  (void)hipFree(s.J); (void)hipFree(s.currI); (void)hipFree(s.currJe); (void)hipFree(s.rho);
   (void)hipFree(s.mig_send[0]); (void)hipFree(s.mig_send[1]); (void)hipFree(s.mig_recv);
   (void)hipFree(s.mig_cell); (void)hipFree(s.mig_rank); (void)hipFree(s.mig_count);
   s = Sort{};
@@ -617,6 +654,17 @@ int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B)
     s.par.q / s.par.m, (long)c->ncell, chunk);
   XPIC_HIP(hipGetLastError());
   return 0;
+}
+
+int charge_density(xpic_ctx* c, Sort& s, double* rho_vec)
+{
+  XPIC_HIP(hipMemsetAsync(rho_vec, 0, sizeof(double) * c->nvec, c->stream));
+  if (s.n > 0) {
+    hipLaunchKernelGGL(k_charge_density, dim3(pgrid(s.n)), dim3(kBlock), 0, c->stream, c->g, s.d, s.n,
+      s.par.q * (s.par.n / s.par.Np), rho_vec);
+    XPIC_HIP(hipGetLastError());
+  }
+  return halo_add(c, rho_vec, 3); // DMLocalToGlobal(ADD) :95
 }
 
 int kinetic_sums_host(xpic_ctx* c, Sort& s, double* out5)

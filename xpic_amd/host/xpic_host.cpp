@@ -206,6 +206,7 @@ PetscErrorCode Simulation::initialize()
 
   // the always-on conservation diagnostic (simulation.cpp:39-50)
   diagnostics_.emplace_back(std::make_unique<Energy>(*this));
+  diagnostics_.emplace_back(std::make_unique<ChargeConservation>(*this)); // simulation.cpp:52-53
 
   std::vector<std::unique_ptr<Command>> presets;
   XCALL(build_commands(*this, "Presets", presets));
@@ -521,6 +522,7 @@ PetscErrorCode TableDiagnostic::diagnose(PetscInt t)
     file_.open(filename_);
     if (!file_) throw std::runtime_error("Cannot open " + filename_);
   }
+  if (t == 0) XCALL(initialize());
   XCALL(add_columns(t));
   if (!values_.empty()) {
     if (t == 0) write_formatted(titles_);
@@ -529,6 +531,33 @@ PetscErrorCode TableDiagnostic::diagnose(PetscInt t)
     values_.clear();
   }
   if (diagnose_period > 0 && t % diagnose_period == 0) file_.flush();
+  return 0;
+}
+
+// ---- ChargeConservation: the densities, the divergence and both norms stay on the device
+ChargeConservation::ChargeConservation(interfaces::Simulation& simulation)
+  : TableDiagnostic(CONFIG().out_dir + "/temporal/charge_conservation.txt"), simulation(simulation)
+{
+}
+
+PetscErrorCode ChargeConservation::initialize()
+{
+  HIPCALL(xpic_charge_collect(simulation.ctx));
+  return 0;
+}
+
+PetscErrorCode ChargeConservation::add_columns(PetscInt t)
+{
+  auto& particles = simulation.particles_;
+  std::vector<double> norm(2 * particles.size() + 2);
+  HIPCALL(xpic_charge_columns(simulation.ctx, norm.data()));
+  add_int(6, "Time", t);
+  for (size_t i = 0; i < particles.size(); ++i) {
+    add(13, "N1dQ_" + particles[i]->parameters.sort_name, "% .6e", norm[2 * i]);
+    add(13, "N2dQ_" + particles[i]->parameters.sort_name, "% .6e", norm[2 * i + 1]);
+  }
+  add(13, "N1dQ_tot", "% .6e", norm[2 * particles.size()]);
+  add(13, "N2dQ_tot", "% .6e", norm[2 * particles.size() + 1]);
   return 0;
 }
 

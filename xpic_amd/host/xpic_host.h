@@ -224,6 +224,7 @@ public:
   explicit TableDiagnostic(const std::string& filename);
   PetscErrorCode diagnose(PetscInt t) override;
   PetscErrorCode finalize() override { file_.close(); return 0; }
+  virtual PetscErrorCode initialize() { return 0; }
   virtual PetscErrorCode add_columns(PetscInt /* t */) { return 0; }
   void add(PetscInt w, std::string title, const char* printf_fmt, double value, PetscInt pos = -1);
   void add_int(PetscInt w, std::string title, long value);
@@ -246,4 +247,14 @@ protected:
   TableDiagnostic energy, energy_cons;
   PetscReal E = 0, E0 = 0, B = 0, B0 = 0, std_E = 0, std_B = 0;
   std::vector<PetscReal> K, K0, std_K;
+};
+
+class ChargeConservation : public TableDiagnostic { // src/diagnostics/charge_conservation.cpp:100-171
+public:
+  explicit ChargeConservation(interfaces::Simulation& simulation);
+  PetscErrorCode initialize() override;
+  PetscErrorCode add_columns(PetscInt t) override;
+
+private:
+  interfaces::Simulation& simulation;
 };
