@@ -31,7 +31,8 @@ namespace {
 
 constexpr int kW = 4;             // waves per workgroup = cells per chunk
 constexpr int kCP = 32;           // particles staged per pass and wave
-constexpr int kPadP = kCP + 1;    // LDS row pitch (conflict-free for lane = particle and lane = entry)
+constexpr int kPadP = kCP + 2;    // LDS row pitch: even, so that particle pairs are 16-byte aligned (ds_read_b128), and
+                                  // 34 keeps the 4-row / 6-column tile loads within 1.5 LDS cycles of conflict-free
 constexpr int kRows = 48;         // 36 weights + 9 A_p*matB + 3 I_p
 constexpr int kStage = kRows * kPadP;
 constexpr int kTileR = 4, kTileC = 6;
@@ -79,14 +80,14 @@ __device__ inline double load_bnb(const GridDev& g, const double* __restrict__ B
   return B[c * g.cstride + g.nodew(cx + ox, cy + oy, cz + oz)];
 }
 
-__global__ void __launch_bounds__(kThreads) k_ecsim_fill(GridDev g, SortDev s, const double* __restrict__ B,
+__global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s, const double* __restrict__ B,
   double* currI, double* matL, const int* __restrict__ etab, const int* __restrict__ linetab, const int* __restrict__ cowr, double q, double m,
   double mpw, int cy0, int cystep, int ncy, int cz0, int czstep, int my_order, int ncol_y, int first_sort)
 {
   const int cy = cy0 + (int)(blockIdx.x % ncy) * cystep;
   const int cz = cz0 + (int)(blockIdx.x / ncy) * czstep;
 
-  __shared__ double sh[kW * kStage];
+  __shared__ __attribute__((aligned(16))) double sh[kW * kStage];
   __shared__ double carry[kLines * 2];
   __shared__ double* lbase[kLines];
   __shared__ double bnb[kW][54];
@@ -98,12 +99,16 @@ __global__ void __launch_bounds__(kThreads) k_ecsim_fill(GridDev g, SortDev s, c
   const double dt = g.dt;
 
   // per-lane flush descriptors: (line, row x offset) of the 24 tile entries, constant over the march
-  int edesc[kTileR][kTileC];
+  // (two 16-bit descriptors per register; 0xffff = structural zero)
+  unsigned edesc[kTileR][kTileC / 2];
 #pragma unroll
   for (int a = 0; a < kTileR; ++a)
 #pragma unroll
-    for (int bb = 0; bb < kTileC; ++bb)
-      edesc[a][bb] = has_tile ? etab[(kTileR * rt + a) * 36 + kTileC * ct + bb] : -1;
+    for (int bb = 0; bb < kTileC; bb += 2) {
+      const int e0 = has_tile ? etab[(kTileR * rt + a) * 36 + kTileC * ct + bb] : -1;
+      const int e1 = has_tile ? etab[(kTileR * rt + a) * 36 + kTileC * ct + bb + 1] : -1;
+      edesc[a][bb / 2] = ((unsigned)e0 & 0xffffu) | ((unsigned)e1 << 16);
+    }
   int cdesc = -1; // currI: lanes < 36
   if (lane < 36) {
     const int c = lane / 12;
@@ -192,17 +197,14 @@ __global__ void __launch_bounds__(kThreads) k_ecsim_fill(GridDev g, SortDev s, c
       for (int a = 0; a < 6; ++a) cur[a] = pf.p[a];
       for (int base = 0; base < cnt; base += kCP) {
         const int mcnt = min(kCP, cnt - base);
-        // next pass of this cell: loads in flight during this pass's phase 1 and 2
-        double nxt[6] = {0, 0, 0, 0, 0, 0};
-        if (base + kCP + lane < cnt) {
-          const long p = (long)start + base + kCP + lane;
-#pragma unroll
-          for (int a = 0; a < 3; ++a) { nxt[a] = s.r[a][p]; nxt[3 + a] = s.v[a][p]; }
-        }
         wave_sync();
-        if (lane < mcnt) {
-          const double v[3] = {cur[3], cur[4], cur[5]};
-          const W1 w(g, cur[0], cur[1], cur[2]);
+        if (lane < ((mcnt + 1) & ~1)) {
+          // the partner of an odd count's last particle: a particle of zero weight at the origin (all its A_p*matB
+          // and I_p rows are exact zeros, so the rank-1 update over the pair needs no tail)
+          const bool real = lane < mcnt;
+          const double mpw_p = real ? mpw : 0.0;
+          const double v[3] = {real ? cur[3] : 0.0, real ? cur[4] : 0.0, real ? cur[5] : 0.0};
+          const W1 w(g, real ? cur[0] : 0.0, real ? cur[1] : 0.0, real ? cur[2] : 0.0);
           // interpolate_B_s1 (ecsim/simulation.cpp:64-118) out of the cell's LDS neighbourhood, same loop
           // and product order as the global-memory gather
           const int ox = w.is[0] - w.in[0] + 1, oy = w.is[1] - w.in[1] + 1, oz = w.is[2] - w.in[2] + 1;
@@ -224,9 +226,9 @@ __global__ void __launch_bounds__(kThreads) k_ecsim_fill(GridDev g, SortDev s, c
           const double b2 = bx * bx + by * by + bz * bz;
           const double vb = v[0] * bx + v[1] * by + v[2] * bz;
           const double cxv = +(v[1] * bz - v[2] * by), cyv = -(v[0] * bz - v[2] * bx), czv = +(v[0] * by - v[1] * bx);
-          const double iq = q * mpw / (1. + b2);
+          const double iq = q * mpw_p / (1. + b2);
           const double Ip[3] = {iq * (v[0] + cxv + vb * bx), iq * (v[1] + cyv + vb * by), iq * (v[2] + czv + vb * bz)};
-          const double A_p = 0.5 * dt * dt * mpw * q * q / m / (1 + b2);
+          const double A_p = 0.5 * dt * dt * mpw_p * q * q / m / (1 + b2);
           const double AB[9] = {
             A_p * (1.0 + bx * bx), A_p * (+bz + bx * by), A_p * (-by + bx * bz),
             A_p * (-bz + by * bx), A_p * (1.0 + by * by), A_p * (+bx + by * bz),
@@ -267,49 +269,74 @@ __global__ void __launch_bounds__(kThreads) k_ecsim_fill(GridDev g, SortDev s, c
 #pragma unroll
           for (int e = 0; e < 3; ++e) col[(45 + e) * kPadP] = Ip[e];
         }
+        // next pass of this cell: loads in flight during this pass's phase 2
+        if (base + kCP + lane < cnt) {
+          const long p = (long)start + base + kCP + lane;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) { cur[a] = s.r[a][p]; cur[3 + a] = s.v[a][p]; }
+        }
         wave_sync();
 
         if (has_tile) {
-          // rank-1 updates, software pipelined by hand: the 13 LDS operands of particle p+1 are requested
-          // before the 28 FMAs of particle p (column mcnt <= 32 is the pad column: harmless to read)
-          const double* rp = st + (kTileR * rt) * kPadP;
-          const double* cp = st + (kTileC * ct) * kPadP;
-          const double* ap = st + (36 + c1 * 3 + c2) * kPadP;
-          const double* sp = st + irow * kPadP;
-          const double* ip = st + icol * kPadP;
-          double r[kTileR], cc[kTileC], ab, si, ii_;
-          ab = ap[0];
+          // rank-1 updates, two particles per operand (ds_read_b128 of an aligned pair) and software pipelined by
+          // hand over two register sets: the 13 operand pairs of particles p+2, p+3 are requested before the
+          // 2 x 29 FMAs of particles p, p+1, and nothing waits on them until the next half-iteration.
+          const double2* rp = (const double2*)(st + (kTileR * rt) * kPadP);
+          const double2* cp = (const double2*)(st + (kTileC * ct) * kPadP);
+          const double2* ap = (const double2*)(st + (36 + c1 * 3 + c2) * kPadP);
+          const double2* sp = (const double2*)(st + irow * kPadP);
+          const double2* ip = (const double2*)(st + icol * kPadP);
+          constexpr int kP2 = kPadP / 2;
+          struct Operands { double2 r[kTileR], c[kTileC], ab, si, ii; };
+          auto load = [&](Operands& o, int h) {
 #pragma unroll
-          for (int a = 0; a < kTileR; ++a) r[a] = rp[a * kPadP];
+            for (int a = 0; a < kTileR; ++a) o.r[a] = rp[a * kP2 + h];
 #pragma unroll
-          for (int bb = 0; bb < kTileC; ++bb) cc[bb] = cp[bb * kPadP];
-          si = sp[0];
-          ii_ = ip[0];
-#pragma unroll 2
-          for (int p = 0; p < mcnt; ++p) {
-            double rn[kTileR], cn[kTileC];
-            const double abn = ap[p + 1];
-#pragma unroll
-            for (int a = 0; a < kTileR; ++a) rn[a] = rp[a * kPadP + p + 1];
-#pragma unroll
-            for (int bb = 0; bb < kTileC; ++bb) cn[bb] = cp[bb * kPadP + p + 1];
-            const double sin_ = sp[p + 1], iin = ip[p + 1];
+            for (int bb = 0; bb < kTileC; ++bb) o.c[bb] = cp[bb * kP2 + h];
+            o.ab = ap[h]; o.si = sp[h]; o.ii = ip[h];
+          };
+          auto rank1 = [&](const Operands& o) {
 #pragma unroll
             for (int a = 0; a < kTileR; ++a) {
-              const double ra = r[a] * ab;
+              const double ra = o.r[a].x * o.ab.x;
 #pragma unroll
-              for (int bb = 0; bb < kTileC; ++bb) acc[a][bb] += ra * cc[bb];
+              for (int bb = 0; bb < kTileC; ++bb) acc[a][bb] += ra * o.c[bb].x;
             }
-            accI += si * ii_;
-            ab = abn; si = sin_; ii_ = iin;
+            accI += o.si.x * o.ii.x;
 #pragma unroll
-            for (int a = 0; a < kTileR; ++a) r[a] = rn[a];
+            for (int a = 0; a < kTileR; ++a) {
+              const double ra = o.r[a].y * o.ab.y;
 #pragma unroll
-            for (int bb = 0; bb < kTileC; ++bb) cc[bb] = cn[bb];
+              for (int bb = 0; bb < kTileC; ++bb) acc[a][bb] += ra * o.c[bb].y;
+            }
+            accI += o.si.y * o.ii.y;
+          };
+          const int nh = (mcnt + 1) >> 1; // particle pairs; an odd count's partner column holds zeros
+          // one operand request per four FMAs: at most 13 LDS reads of a wave are in flight (the counter holds 15)
+          auto interleave = [] {
+#pragma unroll
+            for (int i = 0; i < 13; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
+          };
+          Operands A, Bo;
+          load(A, 0);
+          int h = 0;
+          // no branch sits between a load group and the FMAs it overlaps with, so the LDS counter stays exact and the
+          // FMAs of one pair wait only for their own operands
+          for (; h + 1 < nh; h += 2) {
+            load(Bo, h + 1);
+            rank1(A);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            load(A, min(h + 2, nh - 1));
+            rank1(Bo);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
           }
+          if (h < nh) rank1(A);
         }
-#pragma unroll
-        for (int a = 0; a < 6; ++a) cur[a] = nxt[a];
       }
     }
 
@@ -348,8 +375,8 @@ __global__ void __launch_bounds__(kThreads) k_ecsim_fill(GridDev g, SortDev s, c
       for (int a = 0; a < kTileR; ++a)
 #pragma unroll
         for (int bb = 0; bb < kTileC; ++bb) {
-          const int d = edesc[a][bb];
-          if (d >= 0) unsafeAtomicAdd(&win[(d >> 2) * kSlots + wave + (d & 3)], acc[a][bb]);
+          const unsigned d = (edesc[a][bb / 2] >> (16 * (bb & 1))) & 0xffffu;
+          if (d != 0xffffu) unsafeAtomicAdd(&win[(d >> 2) * kSlots + wave + (d & 3)], acc[a][bb]);
         }
       if (cdesc >= 0) unsafeAtomicAdd(&win[(cdesc >> 2) * kSlots + wave + (cdesc & 3)], accI);
     }
