@@ -33,10 +33,10 @@ constexpr int kW = 4;             // waves per workgroup = cells per chunk
 constexpr int kCP = 32;           // particles staged per pass and wave
 constexpr int kPadP = kCP + 2;    // LDS row pitch: even, so that particle pairs are 16-byte aligned (ds_read_b128), and
                                   // 34 keeps the 4-row / 6-column tile loads within 1.5 LDS cycles of conflict-free
-constexpr int kRows = 48;         // 36 weights + 9 A_p*matB + 3 I_p
+constexpr int kRows = 50;         // 36 weights + 9 A_p*matB + 3 I_p + a row of ones + a row of zeros
 constexpr int kStage = kRows * kPadP;
-constexpr int kTileR = 4, kTileC = 6;
-constexpr int kTiles = (36 / kTileR) * (36 / kTileC); // 54 lanes carry a tile
+constexpr int kRowOne = 48, kRowZero = 49;
+typedef double mfma_acc __attribute__((ext_vector_type(4)));
 constexpr int kMatLines = 816;    // distinct (c1, row dy, row dz, k) streams one pencil can touch
 constexpr int kCurLines = 16;     // (c, dy, dz) streams of currI
 constexpr int kLines = kMatLines + kCurLines;
@@ -93,32 +93,48 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
   __shared__ double bnb[kW][54];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double* st = sh + wave * kStage;
-  const int rt = lane / 6, ct = lane % 6; // tile (rows 4rt.., cols 6ct..) for lane < 54
-  const int c1 = rt / 3, c2 = ct / 2;
-  const bool has_tile = lane < kTiles;
   const double dt = g.dt;
 
-  // per-lane flush descriptors: (line, row x offset) of the 24 tile entries, constant over the march
-  // (two 16-bit descriptors per register; 0xffff = structural zero)
-  unsigned edesc[kTileR][kTileC / 2];
+  // Phase 2 runs on the matrix cores.  For a row component c1 the cell block is the GEMM
+  //   D_c1[12 x 36] = S_c1^T [12 x P] * ( S [P x 36] o matB_c1 )        (P = particles of the cell)
+  // issued as v_mfma_f64_16x16x4_f64 over K = 4 particles: A = 12 (+4 unused) rows of component c1, B = three
+  // 16-column tiles.  The third tile holds block columns 32..35 and, in its 12 spare columns, the stage rows
+  // 36..47: column 45 + c1 is multiplied by one (every other spare column by zero), so D_c1[.][45 + c1] is the
+  // cell's currI = sum_p s_p I_p[c1] for free.
+  // MFMA lane roles: operand element (i or j = lane & 15, k = lane >> 4); result rows (lane >> 4) + 4 r, r < 3.
+  const int mj = lane & 15, mk = lane >> 4;
+  const double* a_ptr = st + min(mj, 11) * kPadP + mk;                 // + c1 * 12 rows
+  const double* b_ptr = st + mj * kPadP + mk;                          // + t * 16 rows
+  const double* m0_ptr = st + (36 + (mj < 12 ? 0 : 1)) * kPadP + mk;  // tile 0: columns 0..15   (+ c1 * 3 rows)
+  const double* m1_ptr = st + (36 + (mj < 8 ? 1 : 2)) * kPadP + mk;   // tile 1: columns 16..31
+  const double* m2_ptr[3];                                             // tile 2: columns 32..35 | spare
 #pragma unroll
-  for (int a = 0; a < kTileR; ++a)
+  for (int c = 0; c < 3; ++c)
+    m2_ptr[c] = st + (mj < 4 ? 36 + 3 * c + 2 : (mj == 13 + c ? kRowOne : kRowZero)) * kPadP + mk;
+
+  // per-lane flush descriptors (line << 2 | row x offset + 1) of the 27 results, constant over the march; two
+  // 16-bit descriptors per register, 0xffff = nothing to add (structural zero or spare column)
+  unsigned edesc[14];
 #pragma unroll
-    for (int bb = 0; bb < kTileC; bb += 2) {
-      const int e0 = has_tile ? etab[(kTileR * rt + a) * 36 + kTileC * ct + bb] : -1;
-      const int e1 = has_tile ? etab[(kTileR * rt + a) * 36 + kTileC * ct + bb + 1] : -1;
-      edesc[a][bb / 2] = ((unsigned)e0 & 0xffffu) | ((unsigned)e1 << 16);
-    }
-  int cdesc = -1; // currI: lanes < 36
-  if (lane < 36) {
-    const int c = lane / 12;
-    int o[3];
-    block_node_offset(c, lane % 12, o);
-    const int id = c == 0 ? o[2] * 2 + o[1] : (c == 1 ? 4 + o[2] * 3 + (o[1] + 1) : 10 + (o[2] + 1) * 2 + o[1]);
-    cdesc = ((kMatLines + id) << 2) | (o[0] + 1);
-  }
-  // the currI row of lanes < 36 rides in the tile loop: row `lane` times I_p[lane / 12]
-  const int irow = lane < 36 ? lane : 0, icol = 45 + (lane < 36 ? lane / 12 : 0);
+  for (int e = 0; e < 14; ++e) edesc[e] = 0xffffffffu;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int row = 12 * c + mk + 4 * r, col = 16 * t + mj;
+        int d = -1;
+        if (col < 36) d = etab[row * 36 + col];
+        else if (col == 45 + c) {
+          int o[3];
+          block_node_offset(c, row % 12, o);
+          const int id = c == 0 ? o[2] * 2 + o[1] : (c == 1 ? 4 + o[2] * 3 + (o[1] + 1) : 10 + (o[2] + 1) * 2 + o[1]);
+          d = ((kMatLines + id) << 2) | (o[0] + 1);
+        }
+        const int e = (c * 3 + t) * 3 + r;
+        edesc[e / 2] = (edesc[e / 2] & ~(0xffffu << (16 * (e & 1)))) | (((unsigned)d & 0xffffu) << (16 * (e & 1)));
+      }
 
   for (int i = threadIdx.x; i < kLines * 2; i += kThreads) carry[i] = 0.0;
   // address of column 0 of every line of this pencil
@@ -182,12 +198,11 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
     const int i = j * kW + wave;
     const bool active = i < g.nx;
 
-    double acc[kTileR][kTileC];
+    mfma_acc acc[3][3];
 #pragma unroll
-    for (int a = 0; a < kTileR; ++a)
+    for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int bb = 0; bb < kTileC; ++bb) acc[a][bb] = 0.0;
-    double accI = 0.0;
+      for (int t = 0; t < 3; ++t) acc[c][t] = mfma_acc{0.0, 0.0, 0.0, 0.0};
 
     if (active) {
       const int start = pf.start, cnt = pf.cnt;
@@ -198,9 +213,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
       for (int base = 0; base < cnt; base += kCP) {
         const int mcnt = min(kCP, cnt - base);
         wave_sync();
-        if (lane < ((mcnt + 1) & ~1)) {
-          // the partner of an odd count's last particle: a particle of zero weight at the origin (all its A_p*matB
-          // and I_p rows are exact zeros, so the rank-1 update over the pair needs no tail)
+        if (lane < ((mcnt + 3) & ~3)) {
+          // a pass is padded to whole K = 4 steps with particles of zero weight at the origin: all their A_p*matB
+          // and I_p rows are exact zeros
           const bool real = lane < mcnt;
           const double mpw_p = real ? mpw : 0.0;
           const double v[3] = {real ? cur[3] : 0.0, real ? cur[4] : 0.0, real ? cur[5] : 0.0};
@@ -268,6 +283,8 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
           for (int e = 0; e < 9; ++e) col[(36 + e) * kPadP] = AB[e];
 #pragma unroll
           for (int e = 0; e < 3; ++e) col[(45 + e) * kPadP] = Ip[e];
+          col[kRowOne * kPadP] = 1.0;
+          col[kRowZero * kPadP] = 0.0;
         }
         // next pass of this cell: loads in flight during this pass's phase 2
         if (base + kCP + lane < cnt) {
@@ -277,65 +294,40 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
         }
         wave_sync();
 
-        if (has_tile) {
-          // rank-1 updates, two particles per operand (ds_read_b128 of an aligned pair) and software pipelined by
-          // hand over two register sets: the 13 operand pairs of particles p+2, p+3 are requested before the
-          // 2 x 29 FMAs of particles p, p+1, and nothing waits on them until the next half-iteration.
-          const double2* rp = (const double2*)(st + (kTileR * rt) * kPadP);
-          const double2* cp = (const double2*)(st + (kTileC * ct) * kPadP);
-          const double2* ap = (const double2*)(st + (36 + c1 * 3 + c2) * kPadP);
-          const double2* sp = (const double2*)(st + irow * kPadP);
-          const double2* ip = (const double2*)(st + icol * kPadP);
-          constexpr int kP2 = kPadP / 2;
-          struct Operands { double2 r[kTileR], c[kTileC], ab, si, ii; };
-          auto load = [&](Operands& o, int h) {
+        {
+          // K = 4 particles per step: 15 operands (3 A, 3 B, 9 matB multipliers), 9 products, 9 MFMAs; the operands
+          // of step s+1 are requested before the MFMAs of step s
+          struct Operands { double a[3], b[3], m[9]; };
+          auto load = [&](Operands& o, int p0) {
 #pragma unroll
-            for (int a = 0; a < kTileR; ++a) o.r[a] = rp[a * kP2 + h];
+            for (int c = 0; c < 3; ++c) o.a[c] = a_ptr[c * 12 * kPadP + p0];
 #pragma unroll
-            for (int bb = 0; bb < kTileC; ++bb) o.c[bb] = cp[bb * kP2 + h];
-            o.ab = ap[h]; o.si = sp[h]; o.ii = ip[h];
-          };
-          auto rank1 = [&](const Operands& o) {
+            for (int t = 0; t < 3; ++t) o.b[t] = b_ptr[t * 16 * kPadP + p0];
 #pragma unroll
-            for (int a = 0; a < kTileR; ++a) {
-              const double ra = o.r[a].x * o.ab.x;
-#pragma unroll
-              for (int bb = 0; bb < kTileC; ++bb) acc[a][bb] += ra * o.c[bb].x;
-            }
-            accI += o.si.x * o.ii.x;
-#pragma unroll
-            for (int a = 0; a < kTileR; ++a) {
-              const double ra = o.r[a].y * o.ab.y;
-#pragma unroll
-              for (int bb = 0; bb < kTileC; ++bb) acc[a][bb] += ra * o.c[bb].y;
-            }
-            accI += o.si.y * o.ii.y;
-          };
-          const int nh = (mcnt + 1) >> 1; // particle pairs; an odd count's partner column holds zeros
-          // one operand request per four FMAs: at most 13 LDS reads of a wave are in flight (the counter holds 15)
-          auto interleave = [] {
-#pragma unroll
-            for (int i = 0; i < 13; ++i) {
-              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-              __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            for (int c = 0; c < 3; ++c) {
+              o.m[c * 3 + 0] = m0_ptr[c * 3 * kPadP + p0];
+              o.m[c * 3 + 1] = m1_ptr[c * 3 * kPadP + p0];
+              o.m[c * 3 + 2] = m2_ptr[c][p0];
             }
           };
+          auto gemm = [&](const Operands& o) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+              for (int t = 0; t < 3; ++t)
+                acc[c][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[c], o.b[t] * o.m[c * 3 + t], acc[c][t], 0, 0, 0);
+          };
+          const int nks = (mcnt + 3) >> 2;
           Operands A, Bo;
           load(A, 0);
-          int h = 0;
-          // no branch sits between a load group and the FMAs it overlaps with, so the LDS counter stays exact and the
-          // FMAs of one pair wait only for their own operands
-          for (; h + 1 < nh; h += 2) {
-            load(Bo, h + 1);
-            rank1(A);
-            interleave();
-            __builtin_amdgcn_sched_barrier(0);
-            load(A, min(h + 2, nh - 1));
-            rank1(Bo);
-            interleave();
-            __builtin_amdgcn_sched_barrier(0);
+          int ks = 0;
+          for (; ks + 1 < nks; ks += 2) {
+            load(Bo, 4 * (ks + 1));
+            gemm(A);
+            load(A, 4 * min(ks + 2, nks - 1));
+            gemm(Bo);
           }
-          if (h < nh) rank1(A);
+          if (ks < nks) gemm(A);
         }
       }
     }
@@ -372,13 +364,15 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
     if (active) {
       // row node x of cell (unwrapped) u = i+1 with offset o is column u+o; window column 0 is kW*j
 #pragma unroll
-      for (int a = 0; a < kTileR; ++a)
+      for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int bb = 0; bb < kTileC; ++bb) {
-          const unsigned d = (edesc[a][bb / 2] >> (16 * (bb & 1))) & 0xffffu;
-          if (d != 0xffffu) unsafeAtomicAdd(&win[(d >> 2) * kSlots + wave + (d & 3)], acc[a][bb]);
-        }
-      if (cdesc >= 0) unsafeAtomicAdd(&win[(cdesc >> 2) * kSlots + wave + (cdesc & 3)], accI);
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const int e = (c * 3 + t) * 3 + r;
+            const unsigned d = (edesc[e / 2] >> (16 * (e & 1))) & 0xffffu;
+            if (d != 0xffffu) unsafeAtomicAdd(&win[(d >> 2) * kSlots + wave + (d & 3)], acc[c][t][r]);
+          }
     }
     lds_barrier();
     // ---- stream out the finished columns (plain RMW, kW consecutive doubles per line), keep 2 in carry
