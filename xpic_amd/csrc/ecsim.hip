@@ -30,9 +30,8 @@ namespace xpic {
 namespace {
 
 constexpr int kW = 4;             // waves per workgroup = cells per chunk
-constexpr int kCP = 32;           // particles staged per pass and wave
-constexpr int kPadP = kCP + 2;    // LDS row pitch: even, so that particle pairs are 16-byte aligned (ds_read_b128), and
-                                  // 34 keeps the 4-row / 6-column tile loads within 1.5 LDS cycles of conflict-free
+constexpr int kCP = 40;           // particles staged per pass and wave (cells of 64 +- 8 fit two passes)
+constexpr int kPadP = kCP + 2;    // LDS row pitch; 2 * 42 mod 64 = 20: the 16 rows of an MFMA operand fall in 16 distinct bank quads
 constexpr int kRows = 50;         // 36 weights + 9 A_p*matB + 3 I_p + a row of ones + a row of zeros
 constexpr int kStage = kRows * kPadP;
 constexpr int kRowOne = 48, kRowZero = 49;
@@ -40,8 +39,10 @@ typedef double mfma_acc __attribute__((ext_vector_type(4)));
 constexpr int kMatLines = 816;    // distinct (c1, row dy, row dz, k) streams one pencil can touch
 constexpr int kCurLines = 16;     // (c, dy, dz) streams of currI
 constexpr int kLines = kMatLines + kCurLines;
-constexpr int kSlots = kW + 2;    // window columns: 8 finished + 2 carried
 constexpr int kThreads = kW * 64;
+constexpr int kSlots = kW + 2;    // window columns: kW finished + 2 carried
+constexpr int kOwn = (kLines + kThreads - 1) / kThreads; // window lines owned by a thread (init, flush, carry)
+constexpr int kMaxNxLds = 1024;   // pencils up to this length keep their cell_start row in LDS
 
 static_assert(kLines * kSlots <= kW * kStage, "the merge window must fit in the (dead) staging area");
 
@@ -82,13 +83,13 @@ __device__ inline double load_bnb(const GridDev& g, const double* __restrict__ B
 
 __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s, const double* __restrict__ B,
   double* currI, double* matL, const int* __restrict__ etab, const int* __restrict__ linetab, const int* __restrict__ cowr, double q, double m,
-  double mpw, int cy0, int cystep, int ncy, int cz0, int czstep, int my_order, int ncol_y, int first_sort)
+  double mpw, int cy0, int cystep, int ncy, int cz0, int czstep, int my_order, int ncol_y, int per_y, int per_z, int first_sort)
 {
   const int cy = cy0 + (int)(blockIdx.x % ncy) * cystep;
   const int cz = cz0 + (int)(blockIdx.x / ncy) * czstep;
 
   __shared__ __attribute__((aligned(16))) double sh[kW * kStage];
-  __shared__ double carry[kLines * 2];
+  __shared__ int cstart[kMaxNxLds + 2];
   __shared__ double* lbase[kLines];
   __shared__ double bnb[kW][54];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -136,7 +137,10 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
         edesc[e / 2] = (edesc[e / 2] & ~(0xffffu << (16 * (e & 1)))) | (((unsigned)d & 0xffffu) << (16 * (e & 1)));
       }
 
-  for (int i = threadIdx.x; i < kLines * 2; i += kThreads) carry[i] = 0.0;
+  const long pencil0 = ((long)cz * g.ny + cy) * g.nx;
+  const bool cs_lds = g.nx <= kMaxNxLds;
+  if (cs_lds)
+    for (int i = threadIdx.x; i <= g.nx; i += kThreads) cstart[i] = s.cell_start[pencil0 + i];
   // address of column 0 of every line of this pencil
   for (int line = threadIdx.x; line < kLines; line += kThreads) {
     const int ld = linetab[line];
@@ -153,7 +157,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
     // Co-writers sit at pencil offsets (-dy', -dz') listed in cowr[line]; launch order = cz colour * ncol_y + cy colour.
     bool first = first_sort && line < kMatLines;
     if (first) {
-      const int bodyy = g.ny - g.ny % 3, bodyz = g.nzl - g.nzl % 3;
+      const int bodyy = g.ny - g.ny % per_y, bodyz = g.nzl - g.nzl % per_z;
       for (int e = 0; e < 8 && first; ++e) {
         const int w = cowr[line * 8 + e];
         if (w == 0x7fffffff) break;
@@ -162,15 +166,15 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
         py = py < 0 ? py + g.ny : (py >= g.ny ? py - g.ny : py);
         if (g.G == 0) pz = pz < 0 ? pz + g.nzl : (pz >= g.nzl ? pz - g.nzl : pz);
         else if (pz < 0 || pz >= g.nzl) continue; // no such local pencil: the neighbour rank's rows are its own
-        const int ca = py < bodyy ? py % 3 : 3 + (py - bodyy);
-        const int cb = g.G == 0 ? (pz < bodyz ? pz % 3 : 3 + (pz - bodyz)) : pz % 3;
+        const int ca = py < bodyy ? py % per_y : per_y + (py - bodyy);
+        const int cb = g.G == 0 ? (pz < bodyz ? pz % per_z : per_z + (pz - bodyz)) : pz % 3;
         if (cb * ncol_y + ca < my_order) first = false;
       }
     }
     lbase[line] = (double*)((uintptr_t)base | (first ? 1u : 0u));
   }
 
-  // lbase / carry are read by other threads from the first chunk on (the RMW prefetch comes before any barrier)
+  // lbase / cstart are read by other threads from the first chunk on (the RMW prefetch comes before any barrier)
   __syncthreads();
 
   // cells are visited in the order 1, 2, ..., nx-1, 0 so that finished columns start 64-byte aligned
@@ -179,9 +183,14 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
     pf.start = 0; pf.cnt = 0; pf.b = 0.0;
     if (i >= g.nx) return;
     const int cx = cell_x(i);
-    const long cell = ((long)cz * g.ny + cy) * g.nx + cx;
-    pf.start = __builtin_amdgcn_readfirstlane(s.cell_start[cell]);
-    pf.cnt = __builtin_amdgcn_readfirstlane(s.cell_start[cell + 1]) - pf.start;
+    if (cs_lds) {
+      pf.start = __builtin_amdgcn_readfirstlane(cstart[cx]);
+      pf.cnt = __builtin_amdgcn_readfirstlane(cstart[cx + 1]) - pf.start;
+    }
+    else {
+      pf.start = __builtin_amdgcn_readfirstlane(s.cell_start[pencil0 + cx]);
+      pf.cnt = __builtin_amdgcn_readfirstlane(s.cell_start[pencil0 + cx + 1]) - pf.start;
+    }
     pf.b = load_bnb(g, B, lane, cx, cy, cz);
     if (lane < min(kCP, pf.cnt)) {
       const long p = (long)pf.start + lane;
@@ -192,6 +201,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
 
   Prefetch pf;
   prefetch_cell(wave, pf);
+  double carry[kOwn][2];
+#pragma unroll
+  for (int mm = 0; mm < kOwn; ++mm) carry[mm][0] = carry[mm][1] = 0.0;
 
   const int nch = (g.nx + kW - 1) / kW;
   for (int j = 0; j < nch; ++j) {
@@ -338,27 +350,48 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
     // ---- the finished columns of this chunk leave by read-modify-write: request their current values NOW, so
     // that the HBM latency runs under the merge below (addresses depend only on the chunk, not on the data)
     const int ndone = min(kW, g.nx - j * kW);
-    constexpr int kItems = (kLines * kW + kThreads - 1) / kThreads;
-    const int fslot = threadIdx.x % kW, fline0 = threadIdx.x / kW;
-    double old[kItems];
-    double* ptr[kItems];
-    bool fst[kItems];
+    const bool vec = ndone == kW && (g.nx & 1) == 0; // whole 16-byte aligned column groups
+    double old[kOwn][kW];
+    double* ptr[kOwn];
+    bool fst[kOwn];
 #pragma unroll
-    for (int mm = 0; mm < kItems; ++mm) {
-      const int line = fline0 + mm * (kThreads / kW);
-      const bool ok = line < kLines && fslot < ndone;
-      const uintptr_t lb = ok ? (uintptr_t)lbase[line] : 0;
+    for (int mm = 0; mm < kOwn; ++mm) {
+      const int line = threadIdx.x + mm * kThreads;
+      const uintptr_t lb = line < kLines ? (uintptr_t)lbase[line] : 0;
       fst[mm] = lb & 1;
-      ptr[mm] = ok ? (double*)(lb & ~(uintptr_t)1) + (j * kW + fslot) : nullptr;
-      old[mm] = (ok && !fst[mm]) ? *ptr[mm] : 0.0;
+      ptr[mm] = lb ? (double*)(lb & ~(uintptr_t)1) + j * kW : nullptr;
+#pragma unroll
+      for (int c = 0; c < kW; ++c) old[mm][c] = 0.0;
+      if (ptr[mm] && !fst[mm]) {
+        if (vec) {
+#pragma unroll
+          for (int c = 0; c < kW; c += 2) {
+            const double2 v = *(const double2*)(ptr[mm] + c);
+            old[mm][c] = v.x; old[mm][c + 1] = v.y;
+          }
+        }
+        else {
+#pragma unroll
+          for (int c = 0; c < kW; ++c)
+            if (c < ndone) old[mm][c] = ptr[mm][c];
+        }
+      }
     }
 
-    // ---- merge the chunk's cell blocks in the window (aliased over the now dead stages)
+    // ---- merge the chunk's cell blocks in the window (aliased over the now dead stages).  A thread owns kOwn
+    // lines of the window: it seeds them with the two columns it carried over, and after the merge it streams
+    // the finished columns out and keeps the last two in registers.
     lds_barrier();
     double* win = sh; // [kLines][kSlots]
-    for (int t = threadIdx.x; t < kLines * kSlots; t += kThreads) {
-      const int line = t / kSlots, slot = t % kSlots;
-      win[t] = slot < 2 ? carry[line * 2 + slot] : 0.0;
+#pragma unroll
+    for (int mm = 0; mm < kOwn; ++mm) {
+      const int line = threadIdx.x + mm * kThreads;
+      if (line < kLines) {
+        double2* w = (double2*)(win + line * kSlots);
+        w[0] = double2{carry[mm][0], carry[mm][1]};
+#pragma unroll
+        for (int c = 1; c < kSlots / 2; ++c) w[c] = double2{0.0, 0.0};
+      }
     }
     lds_barrier();
     if (active) {
@@ -375,25 +408,53 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
           }
     }
     lds_barrier();
-    // ---- stream out the finished columns (plain RMW, kW consecutive doubles per line), keep 2 in carry
+    // ---- stream out the finished columns (plain RMW, kW consecutive doubles per line), keep 2 in registers
 #pragma unroll
-    for (int mm = 0; mm < kItems; ++mm) {
-      const int line = fline0 + mm * (kThreads / kW);
-      if (ptr[mm]) {
-        const double val = win[line * kSlots + fslot];
-        if (val != 0.0 || fst[mm]) *ptr[mm] = old[mm] + val;
+    for (int mm = 0; mm < kOwn; ++mm) {
+      const int line = threadIdx.x + mm * kThreads;
+      if (line < kLines) {
+        double w[kSlots];
+        const double2* wp = (const double2*)(win + line * kSlots);
+#pragma unroll
+        for (int c = 0; c < kSlots / 2; ++c) { const double2 v = wp[c]; w[2 * c] = v.x; w[2 * c + 1] = v.y; }
+        bool any = fst[mm];
+#pragma unroll
+        for (int c = 0; c < kW; ++c) any = any || (c < ndone && w[c] != 0.0);
+        if (any) {
+          if (vec) {
+#pragma unroll
+            for (int c = 0; c < kW; c += 2)
+              *(double2*)(ptr[mm] + c) = double2{old[mm][c] + w[c], old[mm][c + 1] + w[c + 1]};
+          }
+          else {
+#pragma unroll
+            for (int c = 0; c < kW; ++c)
+              if (c < ndone) ptr[mm][c] = old[mm][c] + w[c];
+          }
+        }
+        if (ndone == kW) { carry[mm][0] = w[kW]; carry[mm][1] = w[kW + 1]; }
+        else {
+          carry[mm][0] = carry[mm][1] = 0.0;
+#pragma unroll
+          for (int c = 1; c < kW; ++c)
+            if (c == ndone) { carry[mm][0] = w[c]; carry[mm][1] = w[c + 1]; }
+        }
       }
     }
-    for (int t = threadIdx.x; t < kLines * 2; t += kThreads) carry[t] = win[(t >> 1) * kSlots + ndone + (t & 1)];
     lds_barrier();
   }
 
   // ---- the two columns still carried are x = nx, nx+1 = 0, 1 (periodic): columns this workgroup has
   // already written, so they are added with atomics (2 of nx columns)
-  __syncthreads();
-  for (int t = threadIdx.x; t < kLines * 2; t += kThreads) {
-    const double val = carry[t];
-    if (val != 0.0) unsafeAtomicAdd((double*)((uintptr_t)lbase[t >> 1] & ~(uintptr_t)1) + g.wx(t & 1), val);
+#pragma unroll
+  for (int mm = 0; mm < kOwn; ++mm) {
+    const int line = threadIdx.x + mm * kThreads;
+    if (line < kLines) {
+      double* base = (double*)((uintptr_t)lbase[line] & ~(uintptr_t)1);
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        if (carry[mm][c] != 0.0) unsafeAtomicAdd(base + g.wx(c), carry[mm][c]);
+    }
   }
 }
 
@@ -454,13 +515,21 @@ int build_ltab(xpic_ctx* c)
   return 0;
 }
 
-// colour classes of one periodic axis: 0,1,2 = residues mod 3 over the first 3*floor(n/3) indices,
-// 3.. = the n mod 3 trailing indices one by one.  Same-colour indices are >= 3 apart periodically.
-static void colour_class(int n, int colour, int* first, int* step, int* count)
+// Colour classes of one periodic axis of n indices.  Same-colour indices must be >= 3 apart (periodically).
+// If 3, 4 or 5 divides n the colours are the residues mod that period (all classes equal: no thin launches);
+// otherwise residues mod 3 over the first 3*floor(n/3) indices plus one class per trailing index.
+static int colour_period(int n)
 {
-  const int body = n - n % 3;
-  if (colour < 3) { *first = colour; *step = 3; *count = body / 3; }
-  else { *first = body + (colour - 3); *step = 1; *count = 1; }
+  for (int p = 3; p <= 5; ++p)
+    if (n % p == 0) return p;
+  return 3;
+}
+
+static void colour_class(int n, int period, int colour, int* first, int* step, int* count)
+{
+  const int body = n - n % period;
+  if (colour < period) { *first = colour; *step = period; *count = body / period; }
+  else { *first = body + (colour - period); *step = 1; *count = 1; }
 }
 
 int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, double* matL, bool first_sort)
@@ -470,17 +539,18 @@ int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, d
   const GridDev& g = c->g;
   // y is periodic inside the slab; z is periodic only when the slab is the whole box: with z-neighbours the rows
   // below plane 0 / above plane nzl-1 are ghost rows of this rank alone, so plain residues mod 3 suffice
-  const int ncol_y = 3 + g.ny % 3, ncol_z = g.G == 0 ? 3 + g.nzl % 3 : 3;
+  const int per_y = colour_period(g.ny), per_z = g.G == 0 ? colour_period(g.nzl) : 3;
+  const int ncol_y = per_y + g.ny % per_y, ncol_z = g.G == 0 ? per_z + g.nzl % per_z : 3;
   for (int b = 0; b < ncol_z; ++b)
     for (int a = 0; a < ncol_y; ++a) {
       int cy0, cys, ncy, cz0, czs, ncz;
-      colour_class(g.ny, a, &cy0, &cys, &ncy);
-      if (g.G == 0) colour_class(g.nzl, b, &cz0, &czs, &ncz);
+      colour_class(g.ny, per_y, a, &cy0, &cys, &ncy);
+      if (g.G == 0) colour_class(g.nzl, per_z, b, &cz0, &czs, &ncz);
       else { cz0 = b; czs = 3; ncz = (g.nzl - b + 2) / 3; }
       if (ncy == 0 || ncz == 0) continue;
       hipLaunchKernelGGL(k_ecsim_fill, dim3((unsigned)(ncy * ncz)), dim3(kThreads), 0, c->stream, g, s.d, B,
         currI_sort, matL, c->ltab, c->ltab + 36 * 36, c->ltab + 36 * 36 + kLines, s.par.q, s.par.m,
-        s.par.n / (double)s.par.Np, cy0, cys, ncy, cz0, czs, b * ncol_y + a, ncol_y, first_sort ? 1 : 0);
+        s.par.n / (double)s.par.Np, cy0, cys, ncy, cz0, czs, b * ncol_y + a, ncol_y, per_y, per_z, first_sort ? 1 : 0);
     }
   XPIC_HIP(hipGetLastError());
   return 0;
