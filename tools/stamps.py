@@ -4,7 +4,7 @@ ok = (a[..., 0] > 0).all(axis=(1, 2))
 a = a[ok]
 print("WGs with stamps:", a.shape[0])
 d = np.diff(a, axis=-1)
-names = ["passes(ph1+ph2)", "prefetch+rmw issue", "barrier1 wait", "win init+bar2", "merge+bar3", "flush", "carry+bar4"]
+names = ["passes(ph1+ph2)", "prefetch+rmw issue", "barrier1 wait", "win init+bar2", "merge+bar3", "flush", "bar4"]
 for k, nm in enumerate(names): print("%-22s mean %8.0f  median %8.0f  max %8.0f" % (nm, d[..., k].mean(), np.median(d[..., k]), d[..., k].max()))
 per = a[:, 1:, :, 0] - a[:, :-1, :, 0]
 print("chunk period: mean %.0f median %.0f" % (per.mean(), np.median(per)))

@@ -332,14 +332,17 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
           const int nks = (mcnt + 3) >> 2;
           Operands A, Bo;
           load(A, 0);
-          int ks = 0;
-          for (; ks + 1 < nks; ks += 2) {
-            load(Bo, 4 * (ks + 1));
+          // fully unrolled: every operand address is a base register plus an immediate.  Requests run one step
+          // ahead unconditionally (a step past the pass reads stale columns of the stage that nothing consumes).
+#pragma unroll
+          for (int ks = 0; ks < kCP / 4; ks += 2) {
+            if (ks >= nks) break;
+            if (ks + 1 < kCP / 4) load(Bo, 4 * (ks + 1));
             gemm(A);
-            load(A, 4 * min(ks + 2, nks - 1));
+            if (ks + 1 >= nks) break;
+            if (ks + 2 < kCP / 4) load(A, 4 * (ks + 2));
             gemm(Bo);
           }
-          if (ks < nks) gemm(A);
         }
       }
     }
