@@ -160,6 +160,9 @@ int xpic_energy(xpic_ctx* ctx, double* out);
 
 /* ParticlesChargeDensity::collect of one sort (src/diagnostics/charge_conservation.cpp:67-97) -> rho[z][y][x] */
 int xpic_charge_density(xpic_ctx* ctx, int sort, double* rho_zyx);
+/* DistributionMoment::collect with moment "density" (src/diagnostics/distribution_moment.cpp:125-216): cell-centred
+ * first-order deposit of n/Np -> out[z][y][x].  Uses the scratch vector XPIC_W2. */
+int xpic_moment_density(xpic_ctx* ctx, int sort, double* out_zyx);
 /* ChargeConservation (charge_conservation.cpp:117-171): xpic_charge_collect() = initialize(); then once per step
  * xpic_charge_columns(): out = {N1dQ_0, N2dQ_0, ..., N1dQ_tot, N2dQ_tot} of (rho_new - rho_old)/dt + div(-) J.
  * Uses the scratch vectors XPIC_W0..W2. */

@@ -1212,6 +1212,33 @@ void charge_collect(const orc_sim* s, const Sort& sort, std::vector<double>& fie
   local_to_global_add(gr, local, field, 1);
 }
 
+/* DistributionMoment::collect with the "density" moment (src/diagnostics/distribution_moment.cpp:125-205,212-216):
+ * cell-centred, 2 x 2 x 2 cells from round(r/dx - 1), spline_of_1st_order, value n/Np */
+void density_collect(const orc_sim* s, const Sort& sort, std::vector<double>& field)
+{
+  const Grid& gr = s->gr;
+  std::vector<double> local(gr.G, 0.0);
+  field.assign(gr.N, 0.0);
+  double* arr = local.data();
+  const long ncell = (long)sort.storage.size();
+#pragma omp parallel for schedule(dynamic, 16)
+  for (long g = 0; g < ncell; ++g)
+    for (auto& point : sort.storage[g]) {
+      const double p_r[3] = {point.r[X] / gr.d[X], point.r[Y] / gr.d[Y], point.r[Z] / gr.d[Z]};
+      int start[3];
+      for (int a = 0; a < 3; ++a) start[a] = (int)std::round(p_r[a] - 1.0);
+      for (int i = 0; i < 8; ++i) {
+        int g_x = start[X] + i % 2, g_y = start[Y] + (i / 2) % 2, g_z = start[Z] + (i / 2) / 2;
+        double c = spline1(p_r[X] - ((double)g_x + 0.5)) * spline1(p_r[Y] - ((double)g_y + 0.5)) *
+          spline1(p_r[Z] - ((double)g_z + 0.5));
+        double si = c * sort.n_Np();
+#pragma omp atomic update
+        arr[gr.sl(g_x, g_y, g_z)] += 1.0 * si;
+      }
+    }
+  local_to_global_add(gr, local, field, 1);
+}
+
 /* Divergence, negative Yee shift  (src/utils/operators.cpp:275-333) */
 void div_neg(const Grid& gr, const double* v, double* out, bool add)
 {
@@ -1696,6 +1723,13 @@ void orc_charge_density(orc_sim* s, int isort, double* rho)
   std::vector<double> f;
   charge_collect(s, s->sorts[isort], f);
   std::copy(f.begin(), f.end(), rho);
+}
+
+void orc_moment_density(orc_sim* s, int isort, double* out)
+{
+  std::vector<double> f;
+  density_collect(s, s->sorts[isort], f);
+  std::copy(f.begin(), f.end(), out);
 }
 
 void orc_charge_collect(orc_sim* s) /* ChargeConservation::initialize :117-123 */

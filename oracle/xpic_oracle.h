@@ -149,6 +149,8 @@ void orc_charge_collect(orc_sim*);
 void orc_charge_columns(orc_sim*, double* out);
 /* ParticlesChargeDensity::collect of one sort into rho[z][y][x] */
 void orc_charge_density(orc_sim*, int sort, double* rho);
+/* DistributionMoment "density" (src/diagnostics/distribution_moment.cpp:125-216) -> out[z][y][x] */
+void orc_moment_density(orc_sim*, int sort, double* out);
 
 #ifdef __cplusplus
 }

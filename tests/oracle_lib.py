@@ -96,6 +96,7 @@ def lib():
     L.orc_charge_collect.argtypes = [C.c_void_p]
     L.orc_charge_columns.argtypes = [C.c_void_p, c_dp]
     L.orc_charge_density.argtypes = [C.c_void_p, C.c_int, c_dp]
+    L.orc_moment_density.argtypes = [C.c_void_p, C.c_int, c_dp]
     L.orc_boris_test_trajectory.argtypes = [C.c_int, C.c_char_p, c_dp, C.c_int]
     L.orc_spline.restype = C.c_double
     L.orc_spline.argtypes = [C.c_int, C.c_double]
@@ -217,6 +218,11 @@ class OracleSim:
     def charge_columns(self):
         out = np.zeros(2 * self.nsorts + 2)
         self.L.orc_charge_columns(self.h, _dp(out))
+        return out
+
+    def moment_density(self, sort):
+        out = np.zeros(self.fshape()[:3])
+        self.L.orc_moment_density(self.h, sort, _dp(out))
         return out
 
     def charge_density(self, sort):

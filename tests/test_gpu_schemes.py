@@ -70,6 +70,8 @@ def test_charge_conservation_diagnostic_on_device(oracle, scheme):
     for k in range(2):
         a, b = o.charge_density(k), g.charge_density(k)
         assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
+        a, b = o.moment_density(k), g.moment_density(k)  # DistributionMoment "density"
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
     o.charge_collect()
     g.charge_collect()
     for t in range(3):

@@ -74,6 +74,8 @@ def test_basic_ex1_full_tables(oracle):
     s.charge_columns()
     prev = s.energy()
     assert np.abs(fmt(_energy_row(prev)) - gold[0, 1:]).max() < PETSC_SMALL
+    dump0 = np.fromfile(os.path.join(GOLD, "basic_ex1", "density_000.f32"), dtype=np.float32)
+    assert np.array_equal(s.moment_density(0).astype(np.float32).ravel(), dump0)  # initial load: bit-equal
     for t in range(1, 101):
         assert s.step() == 0
         en = s.energy()
@@ -90,6 +92,10 @@ def test_basic_ex1_full_tables(oracle):
                 dump = np.fromfile(os.path.join(GOLD, "basic_ex1", f"{name}_{t:03d}.f32"), dtype=np.float32)
                 mine = s.get_field(name).astype(np.float32).ravel()
                 assert np.abs(mine - dump).max() <= 2e-6 * np.abs(dump).max(), (name, t)
+            # electrons/density/<t>: DistributionMoment "density", float32 [z][y][x]
+            dump = np.fromfile(os.path.join(GOLD, "basic_ex1", f"density_{t:03d}.f32"), dtype=np.float32)
+            mine = s.moment_density(0).astype(np.float32).ravel()
+            assert np.abs(mine - dump).max() <= 2e-6 * np.abs(dump).max(), ("density", t)
 
 
 def test_ecsim_ex1_tables(oracle):

@@ -28,7 +28,7 @@ SYMBOLS = [
     "xpic_update_cells", "xpic_ecsim_fill_current", "xpic_ecsim_second_push", "xpic_basic_push",
     "xpic_ecsimcorr_first_push", "xpic_ecsimcorr_second_push", "xpic_ecsimcorr_final_update",
     "xpic_calculate_energy", "xpic_ecsimcorr_scalars", "xpic_solve", "xpic_set_tolerances", "xpic_set_preconditioner", "xpic_step",
-    "xpic_energy", "xpic_charge_density", "xpic_charge_collect", "xpic_charge_columns", "xpic_comm_rccl_unique_id", "xpic_comm_init_rccl", "xpic_comm_init_callbacks",
+    "xpic_energy", "xpic_charge_density", "xpic_moment_density", "xpic_charge_collect", "xpic_charge_columns", "xpic_comm_rccl_unique_id", "xpic_comm_init_rccl", "xpic_comm_init_callbacks",
     "xpic_profile_enable", "xpic_profile_reset", "xpic_profile_get", "xpic_probe_copy_bandwidth",
 ]
 
@@ -297,6 +297,11 @@ class Context:
         rho = np.zeros((self.nzl, self.n[1], self.n[0]))
         self._ck(self.L.xpic_charge_density(self.h, sort, _dp(rho)))
         return rho
+
+    def moment_density(self, sort):
+        out = np.zeros((self.nzl, self.n[1], self.n[0]))
+        self._ck(self.L.xpic_moment_density(self.h, sort, _dp(out)))
+        return out
 
     def charge_collect(self):
         self._ck(self.L.xpic_charge_collect(self.h))

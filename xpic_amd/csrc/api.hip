@@ -681,6 +681,17 @@ int xpic_charge_density(xpic_ctx* ctx, int sort, double* rho_zyx)
   return 0;
 }
 
+int xpic_moment_density(xpic_ctx* ctx, int sort, double* out_zyx)
+{
+  CTX_CHECK(ctx); SORT_CHECK(sort);
+  double* tmp = ctx->field[XPIC_W2];
+  XPIC_CALL(moment_density(ctx, ctx->sorts[sort], tmp));
+  std::vector<double> v3((size_t)ctx->g.nown * 3);
+  XPIC_CALL(field_export(ctx, tmp, v3.data()));
+  for (long i = 0; i < ctx->g.nown; ++i) out_zyx[i] = v3[3 * i];
+  return 0;
+}
+
 int xpic_charge_collect(xpic_ctx* ctx) // ChargeConservation::initialize, charge_conservation.cpp:117-123
 {
   CTX_CHECK(ctx);

@@ -200,6 +200,7 @@ int sort_download(xpic_ctx* c, Sort& s, double* pts6, int32_t* cell_of);
 int sort_fill_synthetic(xpic_ctx* c, Sort& s, int ppc, double vth, uint64_t seed);
 int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B);
 int charge_density(xpic_ctx* c, Sort& s, double* rho_vec);
+int moment_density(xpic_ctx* c, Sort& s, double* vec);
 int kinetic_sums_host(xpic_ctx* c, Sort& s, double* out5);   // local sums of vx, vy, vz, v^2 and the count
 int kinetic_sums_global(xpic_ctx* c, Sort& s, double* out5); // summed over the slabs
 int scale_velocities(xpic_ctx* c, Sort& s, double lambda);

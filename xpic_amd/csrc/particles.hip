@@ -381,6 +381,34 @@ __global__ void __launch_bounds__(kBlock) k_charge_density(GridDev g, SortDev s,
       }
 }
 
+// DistributionMoment::collect, moment "density" (src/diagnostics/distribution_moment.cpp:125-216): cell-centred,
+// 2 x 2 x 2 cells from round(r/dx - 1), spline_of_1st_order, value n/Np
+__global__ void __launch_bounds__(kBlock) k_moment_density(GridDev g, SortDev s, int64_t n, double n_Np, double* out)
+{
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n) return;
+  const double pr[3] = {s.r[0][p] / g.dx, s.r[1][p] / g.dy, s.r[2][p] / g.dz};
+  int st[3];
+  double w[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    st[a] = (int)round(pr[a] - 1.0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const double d = fabs(pr[a] - ((double)(st[a] + t) + 0.5));
+      w[a][t] = d <= 1.0 ? 1.0 - d : 0.0;
+    }
+  }
+  st[2] -= g.z0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int ix = i % 2, iy = (i / 2) % 2, iz = i / 4;
+    const int x = ((st[0] + ix) % g.nx + g.nx) % g.nx, y = ((st[1] + iy) % g.ny + g.ny) % g.ny;
+    const double c = w[0][ix] * w[1][iy] * w[2][iz];
+    if (c != 0.0) unsafeAtomicAdd(&out[g.node(x, y, g.wz(st[2] + iz))], c * n_Np);
+  }
+}
+
 // AoS Point records (host staging buffer on device) -> SoA tail of the sort
 __global__ void __launch_bounds__(kBlock) k_unpack(SortDev s, int64_t at, int64_t n, const double* pts6)
 {
@@ -665,6 +693,17 @@ int charge_density(xpic_ctx* c, Sort& s, double* rho_vec)
     XPIC_HIP(hipGetLastError());
   }
   return halo_add(c, rho_vec, 3); // DMLocalToGlobal(ADD) :95
+}
+
+int moment_density(xpic_ctx* c, Sort& s, double* vec)
+{
+  XPIC_HIP(hipMemsetAsync(vec, 0, sizeof(double) * c->nvec, c->stream));
+  if (s.n > 0) {
+    hipLaunchKernelGGL(k_moment_density, dim3(pgrid(s.n)), dim3(kBlock), 0, c->stream, c->g, s.d, s.n,
+      s.par.n / s.par.Np, vec);
+    XPIC_HIP(hipGetLastError());
+  }
+  return halo_add(c, vec, 3);
 }
 
 int kinetic_sums_host(xpic_ctx* c, Sort& s, double* out5)

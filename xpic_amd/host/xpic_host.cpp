@@ -3,6 +3,10 @@
 
 #include <sys/stat.h>
 
+#include <cstdint>
+#include <cstring>
+#include <filesystem>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -54,6 +58,14 @@ void Configuration::init(const std::string& config_path)
   std::stringstream ss;
   ss << file.rdbuf();
   overwrite(xjson::parse(ss.str()));
+  config.config_path = config_path;
+}
+bool Configuration::is_loaded_from_backup()
+{
+  const json_t* it = config.json.find("SimulationBackup");
+  if (!it) return false;
+  const json_t* load_it = it->find("load_from");
+  return load_it && load_it->type == xjson::Value::Number && load_it->as_double() == std::floor(load_it->as_double());
 }
 void Configuration::set_out_dir(const std::string& dir) { config.out_dir = dir; }
 
@@ -211,6 +223,7 @@ PetscErrorCode Simulation::initialize()
   std::vector<std::unique_ptr<Command>> presets;
   XCALL(build_commands(*this, "Presets", presets));
   XCALL(build_commands(*this, "StepPresets", step_presets_));
+  XCALL(build_diagnostics(*this, diagnostics_));
 
   LOG("Executing presets");
   for (auto&& preset : presets) XCALL(preset->execute(start));
@@ -391,6 +404,14 @@ PetscErrorCode build_commands(interfaces::Simulation& simulation, const std::str
   std::vector<std::unique_ptr<interfaces::Command>>& result)
 {
   using interfaces::Builder;
+  if (name == "Presets" && Configuration::is_loaded_from_backup()) { // command_builder.cpp:24-27
+    const auto& info = CONFIG().json.at("SimulationBackup");
+    const PetscInt load_from = (PetscInt)info.at("load_from").as_double();
+    LOG("Restoring simulation from backup at " << load_from * dt << " [1/w_pe], " << load_from << " [dt]");
+    simulation.start = load_from; // simulation_backup_builder.cpp:75-79
+    result.emplace_back(std::make_unique<SimulationBackup>(CONFIG().out_dir + "/simulation_backup/", -1, simulation));
+    return 0;
+  }
   const Configuration::json_t* it = CONFIG().json.find(name);
   if (!it || it->arr.empty()) return 0;
   for (auto&& info : it->arr) {
@@ -467,6 +488,270 @@ PetscErrorCode build_commands(interfaces::Simulation& simulation, const std::str
   return 0;
 }
 
+// ---- FieldView / DistributionMoment / SimulationBackup and their builders
+/* static */ std::string FieldView::format_time(PetscInt t)
+{
+  const size_t width = std::to_string(geom_nt).size();
+  std::string s = std::to_string(t);
+  return s.size() < width ? std::string(width - s.size(), '0') + s : s;
+}
+
+FieldView::FieldView(const std::string& out_dir, interfaces::Simulation& simulation, int field, const Region& region)
+  : simulation(simulation), out_dir_(out_dir), field_(field), region_(region)
+{
+}
+
+PetscErrorCode FieldView::fetch(std::vector<double>& data)
+{
+  data.resize((size_t)geom_nx * geom_ny * geom_nz * 3);
+  HIPCALL(xpic_field_get(simulation.ctx, field_, data.data()));
+  return 0;
+}
+
+PetscErrorCode FieldView::diagnose(PetscInt t)
+{
+  if (diagnose_period > 0 && t % diagnose_period != 0) return 0;
+  std::vector<double> data;
+  XCALL(fetch(data));
+  const PetscInt dof = region_.dof;
+  const PetscInt c0 = dof > 1 ? region_.start[3] : 0, nc = dof > 1 ? region_.size[3] : 1;
+  std::vector<float> out;
+  out.reserve((size_t)region_.size[0] * region_.size[1] * region_.size[2] * nc);
+  for (PetscInt z = region_.start[2]; z < region_.start[2] + region_.size[2]; ++z)
+    for (PetscInt y = region_.start[1]; y < region_.start[1] + region_.size[1]; ++y)
+      for (PetscInt x = region_.start[0]; x < region_.start[0] + region_.size[0]; ++x)
+        for (PetscInt cc = c0; cc < c0 + nc; ++cc)
+          out.push_back((float)data[(((size_t)z * geom_ny + y) * geom_nx + x) * dof + cc]); // write_floats: double -> float
+  make_dirs(out_dir_);
+  std::ofstream f(out_dir_ + "/" + format_time(t), std::ios::binary);
+  if (!f) throw std::runtime_error("Cannot open " + out_dir_ + "/" + format_time(t));
+  f.write(reinterpret_cast<const char*>(out.data()), (std::streamsize)(out.size() * sizeof(float)));
+  return 0;
+}
+
+DistributionMoment::DistributionMoment(const std::string& out_dir, interfaces::Simulation& simulation,
+  interfaces::Particles& particles, const Region& region)
+  : FieldView(out_dir, simulation, -1, region), particles_(particles)
+{
+}
+
+PetscErrorCode DistributionMoment::fetch(std::vector<double>& data)
+{
+  data.resize((size_t)geom_nx * geom_ny * geom_nz);
+  HIPCALL(xpic_moment_density(simulation.ctx, particles_.sort_id, data.data()));
+  return 0;
+}
+
+namespace {
+
+// FieldViewBuilder::parse_region_start_size / parse_res_dir_suffix / check_region (field_view_builder.cpp:60-147)
+void parse_plane_position(const Configuration::json_t& info, std::string& plane, PetscReal& position)
+{
+  plane = info.at("plane").as_string();
+  if (plane == "X") position = 0.5 * geom_x;
+  else if (plane == "Y") position = 0.5 * geom_y;
+  else if (plane == "Z") position = 0.5 * geom_z;
+  else throw std::runtime_error("Unknown plane " + plane);
+  if (info.contains("position")) position = info.at("position").as_double();
+}
+
+void parse_region(const Configuration::json_t& info, FieldView::Region& region, std::string& suffix,
+  const std::string& name)
+{
+  using interfaces::Builder;
+  Vector3R start, size;
+  size[0] = geom_x; size[1] = geom_y; size[2] = geom_z;
+  std::string type = info.contains("type") ? info.at("type").as_string() : "3D";
+  if (type != "3D" && type != "2D") throw std::runtime_error("Incorrect type is used for " + name + " .");
+  if (info.contains("start")) start = Builder::parse_vector(info, "start");
+  if (info.contains("size")) size = Builder::parse_vector(info, "size");
+  const PetscReal d[3] = {dx, dy, dz};
+  if (type == "2D") {
+    std::string plane;
+    PetscReal position;
+    parse_plane_position(info, plane, position);
+    const int dir = plane == "X" ? 0 : (plane == "Y" ? 1 : 2);
+    start[dir] = position;
+    size[dir] = d[dir];
+    char buf[32];
+    std::snprintf(buf, sizeof(buf), "plane%s_%04d", plane.c_str(), (int)FLOOR_STEP(position, d[dir]));
+    suffix += buf;
+  }
+  for (int i = 0; i < 3; ++i) {
+    region.start[i] = FLOOR_STEP(start[i], d[i]);
+    region.size[i] = FLOOR_STEP(size[i], d[i]);
+  }
+}
+
+void check_region(const FieldView::Region& region, const std::string& name)
+{
+  const PetscInt n[3] = {geom_nx, geom_ny, geom_nz};
+  for (int i = 0; i < 3; ++i)
+    if (region.start[i] < 0 || region.start[i] + region.size[i] > n[i])
+      throw std::runtime_error("Region is not in global boundaries for " + name + " diagnostic.");
+  if (!(region.size[0] > 0 && region.size[1] > 0 && region.size[2] > 0))
+    throw std::runtime_error("Sizes are invalid for " + name + " diagnostic.");
+}
+
+}  // namespace
+
+PetscErrorCode build_diagnostics(interfaces::Simulation& simulation,
+  std::vector<std::unique_ptr<interfaces::Diagnostic>>& result)
+{
+  using interfaces::Builder;
+  LOG("Building diagnostics");
+  if (const Configuration::json_t* it = CONFIG().json.find("SimulationBackup"); it && !it->obj.empty()) {
+    const PetscReal dp_wp = Builder::parse_value(it->at("diagnose_period"));
+    const PetscInt dp = ROUND_STEP(dp_wp, dt);
+    LOG("  Simulation backup diagnostic is added, diagnose period: " << dp_wp << " [1/w_pe], " << dp << " [dt]");
+    const std::string res_dir = CONFIG().out_dir + "/simulation_backup";
+    make_dirs(res_dir);
+    if (!CONFIG().config_path.empty()) { // Configuration::save (configuration.cpp:26-36)
+      std::error_code ec;
+      std::filesystem::copy(CONFIG().config_path, res_dir, std::filesystem::copy_options::overwrite_existing, ec);
+    }
+    result.emplace_back(std::make_unique<SimulationBackup>(res_dir + "/", dp, simulation));
+  }
+  const Configuration::json_t* list = CONFIG().json.find("Diagnostics");
+  if (!list || list->arr.empty()) return 0;
+  for (auto&& info : list->arr) {
+    if (!info.contains("diagnostic")) continue;
+    const std::string name = info.at("diagnostic").as_string();
+    FieldView::Region region;
+    region.size[0] = geom_nx; region.size[1] = geom_ny; region.size[2] = geom_nz;
+    std::string suffix;
+    if (name == "FieldView") {
+      const std::string field = info.at("field").as_string();
+      region.dim = 4; region.dof = 3; region.start[3] = 0; region.size[3] = 3;
+      if (info.contains("region")) parse_region(info.at("region"), region, suffix, field);
+      check_region(region, field);
+      LOG("  field view diagnostic is added for " << field << ", suffix: " << (suffix.empty() ? "<empty>" : suffix));
+      if (!suffix.empty()) suffix = "_" + suffix;
+      result.emplace_back(std::make_unique<FieldView>(CONFIG().out_dir + "/" + field + suffix + "/", simulation,
+        simulation.get_named_vector(field), region));
+    }
+    else if (name == "DistributionMoment") {
+      const std::string particles = info.at("particles").as_string(), moment = info.at("moment").as_string();
+      static const char* known[] = {"density", "current", "momentum_flux", "momentum_flux_cyl", "momentum_flux_diag",
+        "momentum_flux_diag_cyl"};
+      if (std::find_if(std::begin(known), std::end(known), [&](const char* k) { return moment == k; }) == std::end(known))
+        throw std::runtime_error("Unknown moment name " + moment + " for particles " + particles);
+      if (moment != "density")
+        throw std::runtime_error("moment " + moment + " is not offered by the HIP backends (density only)");
+      region.dim = 3; region.dof = 1; region.size[3] = 1;
+      if (info.contains("region")) parse_region(info.at("region"), region, suffix, particles + " " + moment);
+      check_region(region, particles + " " + moment);
+      LOG("  " << moment << " diagnostic is added for " << particles << ", suffix: " << (suffix.empty() ? "<empty>" : suffix));
+      if (!suffix.empty()) suffix = "_" + suffix;
+      result.emplace_back(std::make_unique<DistributionMoment>(CONFIG().out_dir + "/" + particles + "/" + moment + suffix,
+        simulation, simulation.get_named_particles(particles), region));
+    }
+    else throw std::runtime_error("Unknown diagnostic name " + name + " (HIP backends: FieldView, DistributionMoment)");
+  }
+  return 0;
+}
+
+namespace {
+
+// PETSc binary viewers write big endian (PetscViewerBinaryWrite -> PetscByteSwap on little-endian hosts)
+void put_be(std::ofstream& f, const void* src, size_t width, size_t count)
+{
+  const unsigned char* p = static_cast<const unsigned char*>(src);
+  std::vector<unsigned char> buf(width * count);
+  for (size_t i = 0; i < count; ++i)
+    for (size_t b = 0; b < width; ++b) buf[i * width + b] = p[i * width + (width - 1 - b)];
+  f.write(reinterpret_cast<const char*>(buf.data()), (std::streamsize)buf.size());
+}
+
+bool get_be(std::ifstream& f, void* dst, size_t width, size_t count)
+{
+  std::vector<unsigned char> buf(width * count);
+  f.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)buf.size());
+  if ((size_t)f.gcount() != buf.size()) return false;
+  unsigned char* p = static_cast<unsigned char*>(dst);
+  for (size_t i = 0; i < count; ++i)
+    for (size_t b = 0; b < width; ++b) p[i * width + b] = buf[i * width + (width - 1 - b)];
+  return true;
+}
+
+constexpr int32_t kVecFileClassId = 1211214; // petscvec.h VEC_FILE_CLASSID
+const char* const kBackupFields[3] = {"E", "B", "B0"};
+
+}  // namespace
+
+SimulationBackup::SimulationBackup(const std::string& out_dir, PetscInt diagnose_period, interfaces::Simulation& simulation)
+  : out_dir_(out_dir), diagnose_period_(diagnose_period), simulation(simulation)
+{
+}
+
+PetscErrorCode SimulationBackup::save(PetscInt t)
+{
+  if (diagnose_period_ <= 0 || t % diagnose_period_ != 0) return 0;
+  const std::string dir = out_dir_ + "/" + std::to_string(t);
+  make_dirs(dir);
+  const size_t n3 = (size_t)geom_nx * geom_ny * geom_nz * 3;
+  std::vector<double> data(n3);
+  for (const char* name : kBackupFields) { // save_fields :48-63, VecView of a DMDA vector = natural ordering
+    HIPCALL(xpic_field_get(simulation.ctx, simulation.get_named_vector(name), data.data()));
+    std::ofstream f(dir + "/" + name, std::ios::binary);
+    const int32_t header[2] = {kVecFileClassId, (int32_t)n3};
+    put_be(f, header, 4, 2);
+    put_be(f, data.data(), 8, n3);
+  }
+  for (auto& sort : simulation.particles_) { // save_particles :65-91
+    std::vector<Point> points;
+    std::vector<int> cells;
+    XCALL(sort->storage(points, cells));
+    const int32_t numparts = (int32_t)points.size();
+    std::ofstream fn(dir + "/" + sort->parameters.sort_name + ".numparts", std::ios::binary);
+    put_be(fn, &numparts, 4, 1);
+    std::ofstream fp(dir + "/" + sort->parameters.sort_name, std::ios::binary);
+    static_assert(sizeof(Point) == 6 * sizeof(double), "Point is six doubles");
+    put_be(fp, points.data(), 8, 6 * points.size());
+  }
+  std::error_code ec; // save_temporal_diagnostics :94-101
+  if (std::filesystem::exists(CONFIG().out_dir + "/temporal"))
+    std::filesystem::copy(CONFIG().out_dir + "/temporal", dir + "/temporal",
+      std::filesystem::copy_options::overwrite_existing | std::filesystem::copy_options::recursive, ec);
+  std::filesystem::remove_all(out_dir_ + "/" + std::to_string(t - num_periods_being_kept * diagnose_period_), ec);
+  return 0;
+}
+
+PetscErrorCode SimulationBackup::load(PetscInt t)
+{
+  if (!std::filesystem::exists(out_dir_)) throw std::runtime_error("Cannot load the timestep, no backup directory");
+  const std::string dir = out_dir_ + "/" + std::to_string(t);
+  const size_t n3 = (size_t)geom_nx * geom_ny * geom_nz * 3;
+  std::vector<double> data(n3);
+  for (const char* name : kBackupFields) { // load_fields :117-131
+    std::ifstream f(dir + "/" + name, std::ios::binary);
+    int32_t header[2] = {0, 0};
+    if (!f || !get_be(f, header, 4, 2) || header[0] != kVecFileClassId || (size_t)header[1] != n3 ||
+      !get_be(f, data.data(), 8, n3))
+      throw std::runtime_error(std::string("Incorrect field data in backup file ") + dir + "/" + name);
+    HIPCALL(xpic_field_set(simulation.ctx, simulation.get_named_vector(name), data.data()));
+  }
+  for (auto& sort : simulation.particles_) { // load_particles :133-160
+    const std::string fname = dir + "/" + sort->parameters.sort_name;
+    std::ifstream fn(fname + ".numparts", std::ios::binary);
+    int32_t numparts = 0;
+    if (!fn || !get_be(fn, &numparts, 4, 1)) throw std::runtime_error("Incorrect number of particles to read is specified");
+    std::ifstream fp(fname, std::ios::binary);
+    Point point;
+    for (int32_t i = 0; i < numparts; ++i) {
+      if (!fp || !get_be(fp, &point, 8, 6)) throw std::runtime_error("Point structure consists of 6 PetscReal values");
+      XCALL(sort->add_particle(point));
+    }
+    XCALL(sort->flush());
+  }
+  std::error_code ec; // load_temporal_diagnostics :162-169
+  if (std::filesystem::exists(dir + "/temporal"))
+    std::filesystem::copy(dir + "/temporal", CONFIG().out_dir + "/temporal",
+      std::filesystem::copy_options::overwrite_existing | std::filesystem::copy_options::recursive, ec);
+  LOG("  Simulation is successfully loaded from " << t * dt << " [1/w_pe], " << t << " [dt]");
+  return 0;
+}
+
 // ---- TableDiagnostic (src/diagnostics/utils/table_diagnostic.cpp:8-59, table_diagnostic.h:19-38)
 static std::string pad_left(const std::string& s, int w) // std::format("{:<{}.{}s}")
 {
@@ -516,13 +801,16 @@ void TableDiagnostic::write_formatted(const std::vector<std::string>& container)
 
 PetscErrorCode TableDiagnostic::diagnose(PetscInt t)
 {
-  if (t == 0) {
+  if (!file_.is_open()) {
     const size_t slash = filename_.rfind('/');
     if (slash != std::string::npos) make_dirs(filename_.substr(0, slash));
-    file_.open(filename_);
+    file_.open(filename_, t == 0 ? std::ios::out : std::ios::app); // a run restored from a backup appends
     if (!file_) throw std::runtime_error("Cannot open " + filename_);
   }
-  if (t == 0) XCALL(initialize());
+  if (!initialized_) { // t == 0, or the first step of a run restored from a backup
+    XCALL(initialize());
+    initialized_ = true;
+  }
   XCALL(add_columns(t));
   if (!values_.empty()) {
     if (t == 0) write_formatted(titles_);
@@ -530,7 +818,7 @@ PetscErrorCode TableDiagnostic::diagnose(PetscInt t)
     titles_.clear();
     values_.clear();
   }
-  if (diagnose_period > 0 && t % diagnose_period == 0) file_.flush();
+  file_.flush(); // every row (the reference flushes per diagnose period): a backup taken this step copies whole tables
   return 0;
 }
 
@@ -583,7 +871,7 @@ PetscErrorCode Energy::calculate()
 
 PetscErrorCode Energy::diagnose(PetscInt t)
 {
-  if (t == 0) XCALL(calculate());
+  if (t == simulation.start) XCALL(calculate());
   E0 = E; B0 = B; K0 = K;
   XCALL(calculate());
 

@@ -62,6 +62,8 @@ public:
   static void init(const std::string& config_path);
   static void overwrite(json_t&& json);
   static void set_out_dir(const std::string& dir);
+  static bool is_loaded_from_backup(); // configuration.cpp:76-86
+  std::string config_path;
   json_t json;
   std::string out_dir;
 
@@ -234,6 +236,7 @@ protected:
   std::string filename_;
   std::ofstream file_;
   std::vector<std::string> titles_, values_;
+  bool initialized_ = false;
 };
 
 class Energy : public interfaces::Diagnostic {
@@ -256,5 +259,58 @@ public:
   PetscErrorCode add_columns(PetscInt t) override;
 
 private:
+  interfaces::Simulation& simulation;
+};
+
+PetscErrorCode build_diagnostics(interfaces::Simulation& simulation,
+  std::vector<std::unique_ptr<interfaces::Diagnostic>>& result); // diagnostic_builder.cpp:16-75
+
+// ---- float32 dumps (src/diagnostics/field_view.cpp, src/utils/mpi_binary_file.cpp:95-108): one file
+// <out_dir>/<format_time(t)> per diagnose period, the region's values in C order [z][y][x][c] as float32
+class FieldView : public interfaces::Diagnostic {
+public:
+  struct Region { // field_view.h:15-20, axes in x, y, z, component order
+    PetscInt dim = 4, dof = 3;
+    PetscInt start[4] = {0, 0, 0, 0};
+    PetscInt size[4] = {0, 0, 0, 3};
+  };
+  FieldView(const std::string& out_dir, interfaces::Simulation& simulation, int field, const Region& region);
+  PetscErrorCode diagnose(PetscInt t) override;
+  static std::string format_time(PetscInt t); // src/interfaces/diagnostic.cpp:21-25
+
+protected:
+  virtual PetscErrorCode fetch(std::vector<double>& data); // the whole local array, [z][y][x][dof]
+  interfaces::Simulation& simulation;
+  std::string out_dir_;
+  int field_;
+  Region region_;
+};
+
+class DistributionMoment final : public FieldView { // src/diagnostics/distribution_moment.cpp, moment "density"
+public:
+  DistributionMoment(const std::string& out_dir, interfaces::Simulation& simulation, interfaces::Particles& particles,
+    const Region& region);
+
+protected:
+  PetscErrorCode fetch(std::vector<double>& data) override;
+  interfaces::Particles& particles_;
+};
+
+// ---- restart files (src/diagnostics/simulation_backup.cpp:30-160): <out_dir>/<t>/{E,B,B0} as PETSc binary Vecs
+// (big endian: int32 VEC_FILE_CLASSID = 1211214, int32 n, n doubles in natural [z][y][x][c] order), particles as
+// <sort_name> = raw big-endian doubles {r, p} per particle and <sort_name>.numparts = one big-endian int32
+class SimulationBackup final : public interfaces::Diagnostic, public interfaces::Command {
+public:
+  SimulationBackup(const std::string& out_dir, PetscInt diagnose_period, interfaces::Simulation& simulation);
+  PetscErrorCode diagnose(PetscInt t) override { return save(t); }
+  PetscErrorCode execute(PetscInt t) override { return load(t); }
+  PetscErrorCode finalize() override { return 0; }
+  PetscErrorCode save(PetscInt t);
+  PetscErrorCode load(PetscInt t);
+  static constexpr PetscInt num_periods_being_kept = 2;
+
+private:
+  std::string out_dir_;
+  PetscInt diagnose_period_;
   interfaces::Simulation& simulation;
 };
