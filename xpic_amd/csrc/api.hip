@@ -295,10 +295,10 @@ int xpic_create(const xpic_geometry* geom, int scheme, xpic_ctx** out)
       XPIC_HIP(hipMemsetAsync(c->kry_p[i], 0, sizeof(double) * c->nvec, c->stream));
     }
     {
-      // Chebyshev degree: error bound 2 rho^k / (1 + rho^2k) <= 5 % on the spectral interval of matM
+      // Chebyshev degree: error bound 2 rho^k / (1 + rho^2k) <= 8 % on the spectral interval of matM
       const double kappa = 1.0 + g.dt * g.dt * (1.0 / (g.dx * g.dx) + 1.0 / (g.dy * g.dy) + 1.0 / (g.dz * g.dz));
       const double rho = (std::sqrt(kappa) - 1.0) / (std::sqrt(kappa) + 1.0);
-      int k = rho > 0 ? (int)std::ceil(std::log(0.025) / std::log(rho)) : 2;
+      int k = rho > 0 ? (int)std::ceil(std::log(0.04) / std::log(rho)) : 2;
       c->cheb_degree = k < 2 ? 2 : (k > 32 ? 32 : k);
     }
     XPIC_CALL(build_ltab(c));
