@@ -59,7 +59,7 @@ static int resolve_profile(xpic_ctx* c)
 
 // matL holds one extra row plane below and above the slab when there are neighbours (rows of their nodes that
 // this rank's cells contribute to)
-static size_t matL_doubles(const GridDev& g) { return (size_t)3 * (g.nzl + (g.G ? 2 : 0)) * g.plane * kLStencil; }
+static size_t matL_doubles(const GridDev& g) { return (size_t)3 * g.nzp() * g.lplane(); }
 
 static bool valid_field(int f) { return f >= 0 && f < XPIC_NFIELDS; }
 
@@ -484,7 +484,7 @@ int xpic_matL_get(xpic_ctx* ctx, double* out)
       for (int y = 0; y < g.ny; ++y)
         for (int k = 0; k < kLStencil; ++k)
           for (int x = 0; x < g.nx; ++x) {
-            size_t src = ((((size_t)c1 * (g.nzl + (g.G ? 2 : 0)) + z + (g.G ? 1 : 0)) * g.ny + y) * kLStencil + k) * g.nx + x;
+            size_t src = (size_t)g.lindex(c1, z + (g.G ? 1 : 0), y, x, k);
             size_t row = (((size_t)z * g.ny + y) * g.nx + x) * 3 + c1;
             out[row * kLStencil + k] = tmp[src];
           }

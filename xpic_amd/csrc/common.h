@@ -39,6 +39,10 @@ void set_error(const std::string& msg);
   } while (0)
 
 constexpr int kLStencil = XPIC_LSTENCIL;
+// matL is blocked by 4 in x: one row block (c1, z, y) is stored as [x/4][k][x%4] with the 123 coefficients padded to
+// 124, so a 4-wide x-block of a row is 31 whole 128-byte lines and the assembly flushes whole lines (ecsim.hip).
+constexpr int kLPad = 124;
+constexpr int kLBlock = kLPad * 4; // doubles per (row block, x-block)
 
 // ---------------------------------------------------------------------------------------------
 // Grid of one z-slab.  Field vectors live in HBM as structure-of-arrays
@@ -69,6 +73,14 @@ struct GridDev {
   __host__ __device__ inline long node(int x, int y, int zs) const { return ((long)zs * ny + y) * nx + x; }
   // wrapped access: x,y,z are local signed indices
   __host__ __device__ inline long nodew(int x, int y, int z) const { return node(wx(x), wy(y), wz(z)); }
+  // matL: x-blocks per row, stored row planes (one ghost row plane on each side with z-neighbours), element offset
+  __host__ __device__ inline int nbx() const { return (nx + 3) >> 2; }
+  __host__ __device__ inline int nzp() const { return nzl + (G ? 2 : 0); }
+  __host__ __device__ inline long lplane() const { return (long)ny * nbx() * kLBlock; }
+  __host__ __device__ inline long lindex(int c1, int zp, int y, int x, int k) const
+  {
+    return ((((long)c1 * nzp() + zp) * ny + y) * nbx() + (x >> 2)) * kLBlock + k * 4 + (x & 3);
+  }
 };
 
 struct SortDev {

@@ -19,7 +19,11 @@
 //     the result is bitwise reproducible.  MatSetValuesCOO's duplicate summation (simulation.cpp:366) thus
 //     happens in LDS (x) and in launch order (y, z).
 // v1 flushed every cell block with ~1200 scattered fp64 atomics: 85 % of the kernel time at 256^3.
+#include <algorithm>
+#include <array>
 #include <cstdint>
+#include <map>
+#include <vector>
 
 #include "common.h"
 #include "device_common.h"
@@ -148,9 +152,8 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
     const int rz = cz + ((ld >> 4) & 3) - 1;
     // single slab: periodic fold; with z-neighbours matL carries one ghost row plane on each side
     const int rzw = g.G == 0 ? (rz < 0 ? rz + g.nzl : (rz >= g.nzl ? rz - g.nzl : rz)) : rz + 1;
-    const int nzp = g.nzl + (g.G ? 2 : 0);
     double* base = line < kMatLines
-      ? matL + ((((long)(ld & 3) * nzp + rzw) * g.ny + ry) * kLStencil + (ld >> 6)) * g.nx
+      ? matL + g.lindex(ld & 3, rzw, ry, 0, ld >> 6)
       : currI + (ld & 3) * g.cstride + g.node(0, ry, g.wz(rz));
     // First touch: if no other pencil that also writes this matL line runs in an EARLIER launch, this workgroup
     // is the first writer of the step and stores instead of read-modify-write (no memset of matL, half the reads).
@@ -353,7 +356,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
     // ---- the finished columns of this chunk leave by read-modify-write: request their current values NOW, so
     // that the HBM latency runs under the merge below (addresses depend only on the chunk, not on the data)
     const int ndone = min(kW, g.nx - j * kW);
-    const bool vec = ndone == kW && (g.nx & 1) == 0; // whole 16-byte aligned column groups
+    // matL lines: the kW finished columns are the x-block j of the row, 32 contiguous, aligned bytes;
+    // currI lines: kW consecutive doubles, 16-byte aligned when nx is even
+    const bool vecL = ndone == kW, vecI = vecL && (g.nx & 1) == 0;
     double old[kOwn][kW];
     double* ptr[kOwn];
     bool fst[kOwn];
@@ -362,7 +367,8 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
       const int line = threadIdx.x + mm * kThreads;
       const uintptr_t lb = line < kLines ? (uintptr_t)lbase[line] : 0;
       fst[mm] = lb & 1;
-      ptr[mm] = lb ? (double*)(lb & ~(uintptr_t)1) + j * kW : nullptr;
+      const bool vec = line < kMatLines ? vecL : vecI;
+      ptr[mm] = lb ? (double*)(lb & ~(uintptr_t)1) + (long)j * (line < kMatLines ? kLBlock : kW) : nullptr;
 #pragma unroll
       for (int c = 0; c < kW; ++c) old[mm][c] = 0.0;
       if (ptr[mm] && !fst[mm]) {
@@ -420,6 +426,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
         const double2* wp = (const double2*)(win + line * kSlots);
 #pragma unroll
         for (int c = 0; c < kSlots / 2; ++c) { const double2 v = wp[c]; w[2 * c] = v.x; w[2 * c + 1] = v.y; }
+        const bool vec = line < kMatLines ? vecL : vecI;
         bool any = fst[mm];
 #pragma unroll
         for (int c = 0; c < kW; ++c) any = any || (c < ndone && w[c] != 0.0);
@@ -470,7 +477,29 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
 int build_ltab(xpic_ctx* c)
 {
   std::vector<int> etab(36 * 36, -1), linetab(kLines, 0);
+  // line ids in (c1, row dy, row dz, k) order: consecutive threads of the flush then walk consecutive k of one row
+  // block, i.e. consecutive 32-byte pieces of matL
   std::map<int, int> line_of;
+  {
+    std::vector<std::array<int, 5>> keys;
+    for (int i = 0; i < 36; ++i)
+      for (int j = 0; j < 36; ++j) {
+        int c1 = i / 12, c2 = j / 12, o1[3], o2[3];
+        block_node_offset(c1, i % 12, o1);
+        block_node_offset(c2, j % 12, o2);
+        int k = lencode(c1, c2, o2[0] - o1[0], o2[1] - o1[1], o2[2] - o1[2]);
+        if (k < 0) continue;
+        keys.push_back({c1, o1[1] + 1, o1[2] + 1, k, c1 | ((o1[1] + 1) << 2) | ((o1[2] + 1) << 4) | (k << 6)});
+      }
+    std::sort(keys.begin(), keys.end());
+    for (auto& q : keys)
+      if (!line_of.count(q[4])) {
+        const int id = (int)line_of.size();
+        XPIC_CHECK(id < kMatLines, "matL line table overflow");
+        line_of.emplace(q[4], id);
+        linetab[id] = q[4];
+      }
+  }
   for (int i = 0; i < 36; ++i)
     for (int j = 0; j < 36; ++j) {
       int c1 = i / 12, c2 = j / 12, o1[3], o2[3];
@@ -480,12 +509,7 @@ int build_ltab(xpic_ctx* c)
       if (k < 0) continue;
       int key = c1 | ((o1[1] + 1) << 2) | ((o1[2] + 1) << 4) | (k << 6);
       auto it = line_of.find(key);
-      if (it == line_of.end()) {
-        int id = (int)line_of.size();
-        XPIC_CHECK(id < kMatLines, "matL line table overflow");
-        it = line_of.emplace(key, id).first;
-        linetab[id] = key;
-      }
+      XPIC_CHECK(it != line_of.end(), "matL line table is incomplete");
       etab[i * 36 + j] = (it->second << 2) | (o1[0] + 1);
     }
   XPIC_CHECK((int)line_of.size() == kMatLines, "unexpected number of matL lines per pencil");

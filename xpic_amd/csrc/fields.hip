@@ -272,16 +272,15 @@ struct FChebInit { double* d; double* z; double it; const double* r;
   __device__ void operator()(long i) const { const double v = r[i] * it; d[i] = v; z[i] = v; } };
 
 // ---- matL / matA SpMV ---------------------------------------------------------------------------
-// matL[c1][z][y][k][x]: one thread per row (c1, node), lane = x, so each of the 123 coefficient streams of a
-// wave is one contiguous 512-byte line; the operand vector comes out of L1/L2 (every element is used by 123
-// rows).  The stencil (c2, dx, dy, dz) of every k is a compile-time constant: the term list is expanded with
+// matL[c1][z][y][x/4][k][x%4] (common.h): one thread per row (c1, node), lane = x.  A wave reads 16 x-blocks; the
+// four coefficients k..k+3 of a block are one 128-byte line, consumed by four consecutive loads of the wave.  The
+// operand vector comes out of L1/L2 (every element is used by 123 rows).  The stencil (c2, dx, dy, dz) of every k is a compile-time constant: the term list is expanded with
 // an integer_sequence so that all address arithmetic folds into immediates and wave-uniform row bases.
 struct RowCtx {
   const char* Lb;    // wave-uniform: first coefficient of the row block (c1, z, y), x = 0
   const char* Xb;    // operand vector
-  unsigned x8;       // lane: 8 * x
+  unsigned xl8;      // lane: byte offset of (x-block, x % 4) inside the row block
   unsigned xs8[5];   // lane: 8 * wrap(x + d), d = -2..2
-  unsigned nx8;      // 8 * nx
   unsigned crow[3];  // wave-uniform byte offsets: component c2,
   unsigned yrow[5];  //   row wrap(y + d),
   unsigned zrow[5];  //   plane wrap(z + d)          (a field vector is < 4 GiB by construction)
@@ -293,7 +292,7 @@ __device__ __forceinline__ void lterm(double (&acc)[2], const RowCtx& r)
   constexpr LEntry e = ldecode(C1, K);
   const unsigned srow = r.crow[e.c2] + r.zrow[e.d[2] + 2] + r.yrow[e.d[1] + 2]; // scalar
   const double xv = *reinterpret_cast<const double*>(r.Xb + (size_t)(srow + r.xs8[e.d[0] + 2]));
-  const double lv = *reinterpret_cast<const double*>(r.Lb + (size_t)K * r.nx8 + r.x8);
+  const double lv = *reinterpret_cast<const double*>(r.Lb + (size_t)K * 32 + r.xl8);
   acc[K & 1] += lv * xv;
 }
 
@@ -302,10 +301,9 @@ __device__ __forceinline__ double row_apply(std::integer_sequence<int, Ks...>, c
   const double* __restrict__ L, const double* __restrict__ X, int x, int y, int z)
 {
   RowCtx r;
-  r.Lb = reinterpret_cast<const char*>(L + ((((long)C1 * (g.nzl + (g.G ? 2 : 0)) + z + (g.G ? 1 : 0)) * g.ny + y) * kLStencil) * g.nx);
+  r.Lb = reinterpret_cast<const char*>(L + g.lindex(C1, z + (g.G ? 1 : 0), y, 0, 0));
   r.Xb = reinterpret_cast<const char*>(X);
-  r.x8 = 8u * (unsigned)x;
-  r.nx8 = 8u * (unsigned)g.nx;
+  r.xl8 = (unsigned)(x >> 2) * (8u * kLBlock) + 8u * (unsigned)(x & 3);
 #pragma unroll
   for (int d = -2; d <= 2; ++d) {
     r.xs8[d + 2] = 8u * (unsigned)g.wx(x + d);
@@ -742,7 +740,7 @@ int matL_exchange_ghost_rows(xpic_ctx* c)
   const GridDev& g = c->g;
   if (g.G == 0) return 0;
   Timed t(c, "matL_ghost_rows");
-  const long per = (long)g.ny * kLStencil * g.nx; // one z-plane of one component
+  const long per = g.lplane(); // one z-plane of one component
   const size_t bytes = sizeof(double) * per;
   XPIC_CALL(ensure_halo_buf(c, bytes));
   const int nzp = g.nzl + 2;
