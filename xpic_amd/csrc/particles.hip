@@ -220,48 +220,72 @@ __global__ void __launch_bounds__(kBlock) k_scan_apply(const int* in, long n, co
 // (interpolate_E_s1 / interpolate_B_s1, ecsim/simulation.cpp:8-118): they are fetched once per cell into LDS, the
 // 48 gathers per particle then hit LDS instead of L1/L2, and the particle streams are read and written fully
 // coalesced (the cell's particles are contiguous).
-constexpr int kSPW = 4; // cells (waves) per workgroup
+constexpr int kSPW = 4;     // waves per workgroup
+constexpr int kSPCells = 256; // consecutive cells per workgroup: wave w takes cells w, w + 4, ... of the run
+
+struct PushPrefetch {
+  int start, cnt;
+  double e, b;       // lane's value of the cell's 36 E / 54 B neighbourhood
+  double r[2][3];    // lane's particle and the particle 64 further on
+  double v[2][3];
+};
 
 __global__ void __launch_bounds__(kSPW * 64) k_second_push(GridDev g, SortDev s, const double* __restrict__ E,
   const double* __restrict__ B, double qm, long ncell, long chunk)
 {
-  // workgroup -> 4 consecutive cells; XCD r sweeps its own contiguous run of cells (see k_matA)
+  // workgroup -> a run of kSPCells consecutive cells; XCD r sweeps its own contiguous range of runs (see k_matA).
+  // A wave marches over its cells with everything of the NEXT cell (neighbourhood, up to 128 particles) in flight
+  // while the current one is pushed: no dependent global round trip sits between two cells.
   const long q = (long)(blockIdx.x % 8) * chunk + blockIdx.x / 8;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long cell = q * kSPW + wave;
-  if (blockIdx.x / 8 >= chunk || cell >= ncell) return;
-  const int start = s.cell_start[cell];
-  const int cnt = s.cell_start[cell + 1] - start;
-  if (cnt == 0) return;
-  const int cx = (int)(cell % g.nx), cy = (int)((cell / g.nx) % g.ny), cz = (int)(cell / g.plane);
+  const long first = q * kSPCells;
+  if (blockIdx.x / 8 >= chunk || first >= ncell) return;
+  const int ncl = (int)min((long)kSPCells, ncell - first);
 
+  __shared__ int cstart[kSPCells + 1];
   __shared__ double nbE[kSPW][36], nbB[kSPW][54];
+  for (int i = threadIdx.x; i <= ncl; i += kSPW * 64) cstart[i] = s.cell_start[first + i];
+  __syncthreads();
+
+  // neighbourhood slot of this lane (node numbering of the cell's 3 x 12 E nodes: X (k*2+j)*3+l, Y (k*3+l)*2+i,
+  // Z (l*2+j)*2+i; B: as load_bnb of ecsim.hip)
+  int ec = 0, eo[3] = {0, 0, 0}, bc = 0, bo[3] = {0, 0, 0};
   if (lane < 36) {
-    const int c = lane / 12;
-    int o[3];
-    // node numbering of the cell's 3 x 12 E nodes: X (k*2+j)*3+l, Y (k*3+l)*2+i, Z (l*2+j)*2+i
+    ec = lane / 12;
     const int l = lane % 12;
-    if (c == 0) { o[0] = l % 3 - 1; o[1] = (l / 3) % 2; o[2] = l / 6; }
-    else if (c == 1) { o[0] = l % 2; o[1] = (l / 2) % 3 - 1; o[2] = l / 6; }
-    else { o[0] = l % 2; o[1] = (l / 2) % 2; o[2] = l / 4 - 1; }
-    nbE[wave][lane] = E[c * g.cstride + g.nodew(cx + o[0], cy + o[1], cz + o[2])];
+    if (ec == 0) { eo[0] = l % 3 - 1; eo[1] = (l / 3) % 2; eo[2] = l / 6; }
+    else if (ec == 1) { eo[0] = l % 2; eo[1] = (l / 2) % 3 - 1; eo[2] = l / 6; }
+    else { eo[0] = l % 2; eo[1] = (l / 2) % 2; eo[2] = l / 4 - 1; }
   }
   if (lane < 54) {
-    int c, ox, oy, oz;
-    if (lane < 18) { c = 0; ox = lane % 2; oy = (lane / 2) % 3 - 1; oz = lane / 6 - 1; }
-    else if (lane < 36) { const int l = lane - 18; c = 1; ox = l % 3 - 1; oy = (l / 3) % 2; oz = l / 6 - 1; }
-    else { const int l = lane - 36; c = 2; ox = l % 3 - 1; oy = (l / 3) % 3 - 1; oz = l / 9; }
-    nbB[wave][lane] = B[c * g.cstride + g.nodew(cx + ox, cy + oy, cz + oz)];
+    if (lane < 18) { bc = 0; bo[0] = lane % 2; bo[1] = (lane / 2) % 3 - 1; bo[2] = lane / 6 - 1; }
+    else if (lane < 36) { const int l = lane - 18; bc = 1; bo[0] = l % 3 - 1; bo[1] = (l / 3) % 2; bo[2] = l / 6 - 1; }
+    else { const int l = lane - 36; bc = 2; bo[0] = l % 3 - 1; bo[1] = (l / 3) % 3 - 1; bo[2] = l / 9; }
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
+
+  auto prefetch = [&](int ci, PushPrefetch& pf) {
+    pf.start = 0; pf.cnt = 0; pf.e = 0.0; pf.b = 0.0;
+    if (ci >= ncl) return;
+    pf.start = __builtin_amdgcn_readfirstlane(cstart[ci]);
+    pf.cnt = __builtin_amdgcn_readfirstlane(cstart[ci + 1]) - pf.start;
+    if (pf.cnt == 0) return;
+    const long cell = first + ci;
+    const int cx = (int)(cell % g.nx), cy = (int)((cell / g.nx) % g.ny), cz = (int)(cell / g.plane);
+    if (lane < 36) pf.e = E[ec * g.cstride + g.nodew(cx + eo[0], cy + eo[1], cz + eo[2])];
+    if (lane < 54) pf.b = B[bc * g.cstride + g.nodew(cx + bo[0], cy + bo[1], cz + bo[2])];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (64 * h + lane < pf.cnt) {
+        const long p = (long)pf.start + 64 * h + lane;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { pf.r[h][a] = s.r[a][p]; pf.v[h][a] = s.v[a][p]; }
+      }
+  };
+
   const double* eE = nbE[wave];
   const double* eB = nbB[wave];
-
-  for (int base = 0; base < cnt; base += 64) {
-    if (base + lane >= cnt) break;
-    const long p = (long)start + base + lane;
-    const W1 w(g, s.r[0][p], s.r[1][p], s.r[2][p]);
+  auto push = [&](long p, const double* r, double* v) {
+    const W1 w(g, r[0], r[1], r[2]);
     const int ox = w.is[0] - w.in[0] + 1, oy = w.is[1] - w.in[1] + 1, oz = w.is[2] - w.in[2] + 1;
     double Ep[3] = {0, 0, 0}, Bp[3] = {0, 0, 0};
 #pragma unroll
@@ -277,9 +301,33 @@ __global__ void __launch_bounds__(kSPW * 64) k_second_push(GridDev g, SortDev s,
           Bp[1] += eB[18 + ((oz + k) * 2 + j) * 3 + (ox + i)] * (w.ws[2][k] * w.wn[1][j] * w.ws[0][i]);
           Bp[2] += eB[36 + (k * 3 + (oy + j)) * 3 + (ox + i)] * (w.wn[2][k] * w.ws[1][j] * w.ws[0][i]);
         }
-    double v[3] = {s.v[0][p], s.v[1][p], s.v[2][p]};
     update_vEB(g.dt, qm, Ep, Bp, v);
     s.v[0][p] = v[0]; s.v[1][p] = v[1]; s.v[2][p] = v[2];
+  };
+
+  PushPrefetch pf;
+  prefetch(wave, pf);
+  for (int ci = wave; ci < ncl; ci += kSPW) {
+    PushPrefetch cur = pf;
+    prefetch(ci + kSPW, pf);
+    if (cur.cnt == 0) continue;
+    // the previous cell's gathers are done (in-order LDS) before its neighbourhood is overwritten
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 36) nbE[wave][lane] = cur.e;
+    if (lane < 54) nbB[wave][lane] = cur.b;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (64 * h + lane < cur.cnt) push((long)cur.start + 64 * h + lane, cur.r[h], cur.v[h]);
+    for (int base = 128; base < cur.cnt; base += 64) { // cells beyond 128 particles: plain loads
+      if (base + lane >= cur.cnt) break;
+      const long p = (long)cur.start + base + lane;
+      const double r[3] = {s.r[0][p], s.r[1][p], s.r[2][p]};
+      double v[3] = {s.v[0][p], s.v[1][p], s.v[2][p]};
+      push(p, r, v);
+    }
   }
 }
 
@@ -676,7 +724,7 @@ int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B)
 {
   if (s.n == 0) return 0;
   Timed t(c, "second_push");
-  const long ngroups = (c->ncell + kSPW - 1) / kSPW;
+  const long ngroups = (c->ncell + kSPCells - 1) / kSPCells;
   const long chunk = (ngroups + 7) / 8;
   hipLaunchKernelGGL(k_second_push, dim3((unsigned)(8 * chunk)), dim3(kSPW * 64), 0, c->stream, c->g, s.d, E, B,
     s.par.q / s.par.m, (long)c->ncell, chunk);
