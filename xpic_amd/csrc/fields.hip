@@ -247,29 +247,31 @@ __global__ void __launch_bounds__(kBlock) k_matM(GridDev g, const double* F, dou
   }
 }
 
-// ---- Chebyshev step on matM: res = r - matM z_in ; d = cd d + cr res ; z_out = z_in + d (first = 0: d, z from r)
+// ---- Chebyshev step on matM: res = r - matM z_in ; d = cd d + cr res ; z_out = z_in + d.
+// FIRST: the start z_0 = d_0 = r / theta is never stored: matM z_0 = (matM r) / theta, everything comes from r.
+template <bool FIRST>
 __global__ void __launch_bounds__(kBlock) k_cheb(GridDev g, const double* __restrict__ r, const double* __restrict__ zin,
-  double* __restrict__ d, double* __restrict__ zout, double cd, double cr)
+  double* __restrict__ d, double* __restrict__ zout, double cd, double cr, double itheta)
 {
   const long n = g.nown;
   const long stride = (long)gridDim.x * kBlock;
   for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
     int x = (int)(i % g.nx), y = (int)((i / g.nx) % g.ny), z = (int)(i / g.plane);
     double m[3];
-    matM_at(g, zin, x, y, z, m[0], m[1], m[2]);
+    matM_at(g, FIRST ? r : zin, x, y, z, m[0], m[1], m[2]);
     const long o = g.node(x, y, g.wz(z));
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const long oc = o + c * g.cstride;
-      const double dn = cd * d[oc] + cr * (r[oc] - m[c]);
+      const double rv = r[oc];
+      const double z0 = FIRST ? rv * itheta : zin[oc];
+      const double dn = cd * (FIRST ? z0 : d[oc]) + cr * (rv - (FIRST ? m[c] * itheta : m[c]));
       d[oc] = dn;
-      zout[oc] = zin[oc] + dn;
+      zout[oc] = z0 + dn;
     }
   }
 }
 
-struct FChebInit { double* d; double* z; double it; const double* r;
-  __device__ void operator()(long i) const { const double v = r[i] * it; d[i] = v; z[i] = v; } };
 
 // ---- matL / matA SpMV ---------------------------------------------------------------------------
 // matL[c1][z][y][x/4][k][x%4] (common.h): one thread per row (c1, node), lane = x.  A wave reads 16 x-blocks; the
@@ -576,20 +578,29 @@ int cheb_matM_inverse(xpic_ctx* c, const double* r, double* out)
   double* d = c->kry_p[0];
   double* z0 = c->kry_p[1];
   double* z1 = c->kry_p[2];
-  XPIC_CALL(launch_ew(c, FChebInit{d, z0, 1.0 / theta, r}));
+  const int degree = c->cheb_degree;
+  if (degree <= 1) return launch_ew(c, FScaleTo{out, 1.0 / theta, r});
   double rho = 1.0 / sigma1;
   long blocks = (g.nown + kBlock - 1) / kBlock;
   if (blocks > 65536) blocks = 65536;
-  for (int i = 1; i < c->cheb_degree; ++i) {
+  for (int i = 1; i < degree; ++i) {
     const double rho_new = 1.0 / (2.0 * sigma1 - rho);
-    XPIC_CALL(halo_fill(c, z0, 1));
-    hipLaunchKernelGGL(k_cheb, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, g, r, z0, d, z1, rho_new * rho,
-      2.0 * rho_new / delta);
+    double* zout = i == degree - 1 ? out : z1; // the last step lands in the caller's vector
+    if (i == 1) {
+      XPIC_CALL(halo_fill(c, const_cast<double*>(r), 1));
+      hipLaunchKernelGGL(k_cheb<true>, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, g, r, r, d, zout,
+        rho_new * rho, 2.0 * rho_new / delta, 1.0 / theta);
+    }
+    else {
+      XPIC_CALL(halo_fill(c, z0, 1));
+      hipLaunchKernelGGL(k_cheb<false>, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, g, r, z0, d, zout,
+        rho_new * rho, 2.0 * rho_new / delta, 1.0 / theta);
+    }
     XPIC_HIP(hipGetLastError());
     rho = rho_new;
     std::swap(z0, z1);
   }
-  return vec_copy(c, out, z0);
+  return 0;
 }
 
 int div_neg_add(xpic_ctx* c, double* v3, double* out_scalar)
