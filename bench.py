@@ -242,6 +242,17 @@ def main():
             "bytes_per_launch": bytes_apply, "launches": n_apply, "avg_ms": ms_apply / max(n_apply, 1),
         },
     }
+    n_fill, ms_fill = prof["fill_current"]
+    if n_fill and args.scheme != "basic":
+        # the assembly is the one dense contraction of the path: per particle a 36 x 36 rank-1 update = 2 * 1296 flop
+        # (issued on the matrix cores as 9 v_mfma_f64_16x16x4_f64 per 4 particles = 4608 flop per particle with the
+        # padding); fp64 matrix peak = fp64 vector peak = 78.6 TFLOP/s on MI355X (measured here: 75.5 with MFMA)
+        tf = 2.0 * 1296 * count / world / (ms_fill / n_fill * 1e-3) / 1e12
+        line["roofline_assembly"] = {
+            "kernel": "k_ecsim_fill (mass matrix + currI, all colour launches of one assembly)", "bound": "mfma",
+            "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6, "traffic": None,
+            "flop_per_particle": 2592, "issued_flop_per_particle": 4608, "avg_ms": ms_fill / n_fill,
+        }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.scheme == "ecsim":
             line["cpu_baseline"] = cpu_baseline(args)
