@@ -133,7 +133,8 @@ static int step_ecsim(xpic_ctx* c, int* its)
   XPIC_CALL(halo_fill(c, c->field[XPIC_B]));
   // second_push :212-239.  Positions did not change since the re-bin of first_push and are already wrapped,
   // so correct_coordinates() + update_cells() of :227,:233 are the identity here.
-  for (auto& s : c->sorts) XPIC_CALL(ecsim_second_push(c, s, c->field[XPIC_EP], c->field[XPIC_B]));
+  // the next step starts with sort_rebin(dt) of exactly this state: bin it in the same pass (Sort::prebinned)
+  for (auto& s : c->sorts) XPIC_CALL(ecsim_second_push(c, s, c->field[XPIC_EP], c->field[XPIC_B], true));
   XPIC_CALL(ecsim_final_update(c));
   return 0;
 }
@@ -378,6 +379,7 @@ int xpic_sort_clear(xpic_ctx* ctx, int sort)
   CTX_CHECK(ctx); SORT_CHECK(sort);
   Sort& s = ctx->sorts[sort];
   s.n = 0;
+  s.prebinned = false;
   XPIC_HIP(hipMemsetAsync(s.d.cell_count, 0, sizeof(int) * (ctx->ncell + 1), ctx->stream));
   XPIC_HIP(hipMemsetAsync(s.d.cell_start, 0, sizeof(int) * (ctx->ncell + 1), ctx->stream));
   return 0;

@@ -98,6 +98,10 @@ struct Sort {
   xpic_sort_params par;
   int64_t cap = 0;
   int64_t n = 0;
+  // cell[], rank[], cell_count (and the migration buffers) already hold the binning of r + v * prebinned_step
+  bool prebinned = false;
+  double prebinned_step = 0;
+  int64_t prebinned_n = 0;
   SortDev d{};
   double* J = nullptr;      // basic: J
   double* currI = nullptr;  // ecsim: currI
@@ -210,7 +214,7 @@ int sort_move(xpic_ctx* c, Sort& s, double step); // r += step*v in place, cells
 int sort_append_host(xpic_ctx* c, Sort& s, int64_t n, const double* pts6, int64_t* added);
 int sort_download(xpic_ctx* c, Sort& s, double* pts6, int32_t* cell_of);
 int sort_fill_synthetic(xpic_ctx* c, Sort& s, int ppc, double vth, uint64_t seed);
-int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B);
+int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B, bool prebin = false);
 int charge_density(xpic_ctx* c, Sort& s, double* rho_vec);
 int moment_density(xpic_ctx* c, Sort& s, double* vec);
 int kinetic_sums_host(xpic_ctx* c, Sort& s, double* out5);   // local sums of vx, vy, vz, v^2 and the count

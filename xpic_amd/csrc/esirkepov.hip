@@ -282,7 +282,8 @@ __global__ void __launch_bounds__(kThreadsB) k_esirkepov_push(GridDev g, SortDev
 }  // namespace
 
 int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double* B, double* J, double* pred_w_host)
-{
+{  s.prebinned = false;
+
   if (pred_w_host) *pred_w_host = 0.0;
   if (s.n == 0) {
     // an empty slab still takes part in the collective

@@ -38,6 +38,51 @@ struct Migr {
   int send_cap;
 };
 
+// New cell of a (moved, wrapped) particle and its arrival rank in that cell; with MIG also the send side of
+// update_cells_mpi.  Every live lane of the wave calls it together (ballots).
+template <bool MIG>
+__device__ __forceinline__ void bin_particle(const GridDev& g, const SortDev& s, int64_t p, double x, double y, double z,
+  double vx, double vy, double vz, const Migr& mg)
+{
+  int c = MIG ? dest_of(g, mg.rank, mg.nranks, x, y, z) : cell_of(g, x, y, z);
+  if (MIG && c <= -2) {
+    if (c == -4) { atomicOr(&mg.sendcount[2], 1); c = -1; }
+    else {
+      const int dir = c == -2 ? 0 : 1;
+      const int idx = atomicAdd(&mg.sendcount[dir], 1);
+      if (idx < mg.send_cap) {
+        double* o = mg.send[dir] + 6L * idx;
+        o[0] = x; o[1] = y; o[2] = z; o[3] = vx; o[4] = vy; o[5] = vz;
+      }
+      else atomicOr(&mg.sendcount[2], 2);
+      c = -1;
+    }
+  }
+  s.cell[p] = c;
+  // Arrival rank inside the new cell.  The input is (nearly) cell-sorted, so a wave sees a handful of distinct
+  // cells: the lanes are grouped by cell with ballots, then ONE atomic instruction carries the returning add of
+  // every group's first lane (one memory round trip per wave, not one per distinct cell).
+  const int lane = threadIdx.x & 63;
+  int my_leader = lane, rank_in = 0, gsize = 0;
+  unsigned long long todo = __ballot(c >= 0);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int lc = __shfl(c, leader, 64);
+    const unsigned long long same = __ballot(c == lc) & todo;
+    if (c == lc) {
+      my_leader = leader;
+      rank_in = __popcll(same & ((1ull << lane) - 1ull));
+      gsize = __popcll(same);
+    }
+    todo &= ~same;
+  }
+  int base = 0;
+  if (c >= 0 && lane == my_leader) base = atomicAdd(&s.cell_count[c], gsize);
+  base = __shfl(base, my_leader, 64);
+  const int rank = c >= 0 ? base + rank_in : 0;
+  s.rank[p] = rank;
+}
+
 // pass 1 of update_cells: (BorisPush::update_r) + correct_coordinates + new cell + arrival rank in it;
 // with MIG also the send side of update_cells_mpi (src/interfaces/particles.cpp:118-181)
 template <bool MOVE, bool WRAP, bool MIG>
@@ -58,37 +103,7 @@ __global__ void __launch_bounds__(kBlock) k_move_bin(GridDev g, SortDev s, int64
     y = bound_periodic(y, g.Ly);
     z = bound_periodic(z, g.Lz);
   }
-  int c = MIG ? dest_of(g, mg.rank, mg.nranks, x, y, z) : cell_of(g, x, y, z);
-  if (MIG && c <= -2) {
-    if (c == -4) { atomicOr(&mg.sendcount[2], 1); c = -1; }
-    else {
-      const int dir = c == -2 ? 0 : 1;
-      const int idx = atomicAdd(&mg.sendcount[dir], 1);
-      if (idx < mg.send_cap) {
-        double* o = mg.send[dir] + 6L * idx;
-        o[0] = x; o[1] = y; o[2] = z; o[3] = vx; o[4] = vy; o[5] = vz;
-      }
-      else atomicOr(&mg.sendcount[2], 2);
-      c = -1;
-    }
-  }
-  s.cell[p] = c;
-  // Arrival rank inside the new cell.  The input is (nearly) cell-sorted, so a wave sees a handful of distinct
-  // cells: one returning atomic per distinct cell and wave instead of one per particle.
-  int rank = 0;
-  unsigned long long todo = __ballot(c >= 0);
-  const int lane = threadIdx.x & 63;
-  while (todo) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const int lc = __shfl(c, leader, 64);
-    const unsigned long long same = __ballot(c == lc) & todo;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&s.cell_count[lc], __popcll(same));
-    base = __shfl(base, leader, 64);
-    if (c == lc) rank = base + __popcll(same & ((1ull << lane) - 1ull));
-    todo &= ~same;
-  }
-  s.rank[p] = rank;
+  bin_particle<MIG>(g, s, p, x, y, z, vx, vy, vz, mg);
 }
 
 // receive side of update_cells_mpi (:226-241): bin what the neighbours sent
@@ -230,8 +245,9 @@ struct PushPrefetch {
   double v[2][3];
 };
 
+template <bool PREBIN, bool MIG>
 __global__ void __launch_bounds__(kSPW * 64) k_second_push(GridDev g, SortDev s, const double* __restrict__ E,
-  const double* __restrict__ B, double qm, long ncell, long chunk)
+  const double* __restrict__ B, double qm, long ncell, long chunk, Migr mg)
 {
   // workgroup -> a run of kSPCells consecutive cells; XCD r sweeps its own contiguous range of runs (see k_matA).
   // A wave marches over its cells with everything of the NEXT cell (neighbourhood, up to 128 particles) in flight
@@ -303,6 +319,14 @@ __global__ void __launch_bounds__(kSPW * 64) k_second_push(GridDev g, SortDev s,
         }
     update_vEB(g.dt, qm, Ep, Bp, v);
     s.v[0][p] = v[0]; s.v[1][p] = v[1]; s.v[2][p] = v[2];
+    if (PREBIN) {
+      // the next step opens with first_push + update_cells of exactly this state: r + v dt, wrapped, binned.  Doing
+      // the binning here (same expressions as k_move_bin<true, true, .>) saves that pass its 48 B per particle.
+      const double x = bound_periodic(r[0] + v[0] * g.dt, g.Lx);
+      const double y = bound_periodic(r[1] + v[1] * g.dt, g.Ly);
+      const double z = bound_periodic(r[2] + v[2] * g.dt, g.Lz);
+      bin_particle<MIG>(g, s, p, x, y, z, v[0], v[1], v[2], mg);
+    }
   };
 
   PushPrefetch pf;
@@ -586,19 +610,30 @@ void sort_free(Sort& s)
 // (optional) r += step*v, periodic wrap, re-bin, drop what left the box: the whole of
 // first_push + update_cells_seq (src/impls/ecsim/particles.cpp:21-31, src/interfaces/particles.cpp:79-116);
 // with nranks > 1 also update_cells_mpi (:118-248): leavers go to the z-neighbours, arrivals are binned in.
-int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap)
+static Migr make_migr(xpic_ctx* c, Sort& s)
 {
-  XPIC_HIP(hipMemsetAsync(s.d.cell_count, 0, sizeof(int) * (c->ncell + 1), c->stream));
-  const bool move = step != 0.0;
-  const bool mig = c->comm.kind != 0;
   Migr mg{};
-  if (mig) {
+  if (c->comm.kind != 0) {
     mg.rank = c->comm.rank; mg.nranks = c->comm.nranks;
     mg.send[0] = s.mig_send[0]; mg.send[1] = s.mig_send[1];
     mg.sendcount = s.mig_count; mg.send_cap = s.mig_cap;
-    XPIC_HIP(hipMemsetAsync(s.mig_count, 0, sizeof(int) * 4, c->stream));
   }
-  if (s.n > 0) {
+  return mg;
+}
+
+int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap)
+{
+  const bool move = step != 0.0;
+  const bool mig = c->comm.kind != 0;
+  // keys, ranks, counts (and the migration send buffers) of exactly this move may already be there (ecsim_second_push)
+  const bool prebinned = s.prebinned && move && wrap && step == s.prebinned_step && s.n == s.prebinned_n;
+  s.prebinned = false;
+  Migr mg = make_migr(c, s);
+  if (!prebinned) {
+    XPIC_HIP(hipMemsetAsync(s.d.cell_count, 0, sizeof(int) * (c->ncell + 1), c->stream));
+    if (mig) XPIC_HIP(hipMemsetAsync(s.mig_count, 0, sizeof(int) * 4, c->stream));
+  }
+  if (s.n > 0 && !prebinned) {
     Timed t(c, "move_bin");
     const unsigned nb = pgrid(s.n);
 #define LAUNCH(M, W, G) hipLaunchKernelGGL((k_move_bin<M, W, G>), dim3(nb), dim3(kBlock), 0, c->stream, c->g, s.d, s.n, step, mg)
@@ -672,7 +707,8 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap)
 }
 
 int sort_append_host(xpic_ctx* c, Sort& s, int64_t n, const double* pts6, int64_t* added)
-{
+{  s.prebinned = false;
+
   XPIC_CHECK(s.n + n <= s.cap, "sort capacity exceeded in add_particles");
   const int64_t before = s.n;
   if (n > 0) {
@@ -709,7 +745,8 @@ int sort_download(xpic_ctx* c, Sort& s, double* pts6, int32_t* cell_of_out)
 }
 
 int sort_fill_synthetic(xpic_ctx* c, Sort& s, int ppc, double vth, uint64_t seed)
-{
+{  s.prebinned = false;
+
   const int64_t n = (int64_t)c->ncell * ppc;
   XPIC_CHECK(n <= s.cap, "sort capacity exceeded in fill_synthetic");
   hipLaunchKernelGGL(k_synthetic, dim3(pgrid(n)), dim3(kBlock), 0, c->stream, c->g, s.d, n, ppc, vth, seed);
@@ -720,15 +757,29 @@ int sort_fill_synthetic(xpic_ctx* c, Sort& s, int ppc, double vth, uint64_t seed
   return 0;
 }
 
-int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B)
+// prebin: also bin the particles for the first_push + update_cells that opens the next ecsim step (sort_rebin with
+// step = dt consumes it if nothing touched the species in between)
+int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B, bool prebin)
 {
+  s.prebinned = false;
   if (s.n == 0) return 0;
   Timed t(c, "second_push");
   const long ngroups = (c->ncell + kSPCells - 1) / kSPCells;
   const long chunk = (ngroups + 7) / 8;
-  hipLaunchKernelGGL(k_second_push, dim3((unsigned)(8 * chunk)), dim3(kSPW * 64), 0, c->stream, c->g, s.d, E, B,
-    s.par.q / s.par.m, (long)c->ncell, chunk);
+  const bool mig = c->comm.kind != 0;
+  Migr mg = make_migr(c, s);
+  if (prebin) {
+    XPIC_HIP(hipMemsetAsync(s.d.cell_count, 0, sizeof(int) * (c->ncell + 1), c->stream));
+    if (mig) XPIC_HIP(hipMemsetAsync(s.mig_count, 0, sizeof(int) * 4, c->stream));
+  }
+#define LAUNCH(P, G) hipLaunchKernelGGL((k_second_push<P, G>), dim3((unsigned)(8 * chunk)), dim3(kSPW * 64), 0, c->stream, \
+    c->g, s.d, E, B, s.par.q / s.par.m, (long)c->ncell, chunk, mg)
+  if (!prebin) LAUNCH(false, false);
+  else if (mig) LAUNCH(true, true);
+  else LAUNCH(true, false);
+#undef LAUNCH
   XPIC_HIP(hipGetLastError());
+  if (prebin) { s.prebinned = true; s.prebinned_step = c->g.dt; s.prebinned_n = s.n; }
   return 0;
 }
 
@@ -778,7 +829,8 @@ int kinetic_sums_global(xpic_ctx* c, Sort& s, double* out5)
 }
 
 int sort_move(xpic_ctx* c, Sort& s, double step)
-{
+{  s.prebinned = false;
+
   if (s.n == 0) return 0;
   Timed t(c, "move");
   hipLaunchKernelGGL(k_move, dim3(pgrid(s.n)), dim3(kBlock), 0, c->stream, s.d, s.n, step);
@@ -787,7 +839,8 @@ int sort_move(xpic_ctx* c, Sort& s, double step)
 }
 
 int scale_velocities(xpic_ctx* c, Sort& s, double lambda)
-{
+{  s.prebinned = false;
+
   if (s.n == 0) return 0;
   hipLaunchKernelGGL(k_scale_v, dim3(pgrid(s.n)), dim3(kBlock), 0, c->stream, s.d, s.n, lambda);
   XPIC_HIP(hipGetLastError());
