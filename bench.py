@@ -253,6 +253,18 @@ def main():
             "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6, "traffic": None,
             "flop_per_particle": 2592, "issued_flop_per_particle": 4608, "avg_ms": ms_fill / n_fill,
         }
+    if args.scheme == "ecsim":
+        # algorithmic HBM bytes per particle and step of the ecsim particle phases: first_push 72 +
+        # assembly 48 (+ 2952 B of matL per cell) + second_push 72 + re-binning 96
+        ms_part = sum(prof[k][1] for k in ("fill_current", "second_push", "move_bin", "scatter", "scan")) / args.steps
+        bpp = 72 + 48 + 72 + 96 + 2952.0 / args.ppc
+        gbs = bpp * count / world / (ms_part * 1e-3) / 1e9
+        line["roofline_particles"] = {
+            "kernels": "k_ecsim_fill + k_second_push + k_move_bin + k_scatter (all particle phases of a step)",
+            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "bytes_per_particle": bpp, "ms_per_step": ms_part,
+            "particles_per_s": count / world / (ms_part * 1e-3),
+        }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.scheme == "ecsim":
             line["cpu_baseline"] = cpu_baseline(args)
