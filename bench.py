@@ -13,6 +13,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL across processes)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy rate
 
@@ -83,8 +84,8 @@ def main():
     ap.add_argument("--dt", type=float, default=1.0)
     ap.add_argument("--vth", type=float, default=0.014)  # T = 0.1 keV electrons (tests/ecsim/ecsim_ex1.cpp:66-70)
     ap.add_argument("--b0", type=float, default=0.2)
-    ap.add_argument("--cpu-grid", type=int, default=40)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-grid", type=int, default=48)   # 48^3 x 64 ppc x 4 steps: ~13 s of oracle work
+    ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--probe", action="store_true", help="also run the device copy probes (PMC calibration)")
     ap.add_argument("--plain-gmres", action="store_true", help="unpreconditioned GMRES(30), as the CPU oracle runs")
