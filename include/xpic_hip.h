@@ -169,6 +169,21 @@ int xpic_moment_density(xpic_ctx* ctx, int sort, double* out_zyx);
 int xpic_charge_collect(xpic_ctx* ctx);
 int xpic_charge_columns(xpic_ctx* ctx, double* out);
 
+/* ---- inner kernels of the `eccapfim` scheme, batch form over n path segments r0 -> rn (host arrays,
+ * 3 doubles per point).  The scheme's outer loops are not part of this library.
+ * cell_traversal (src/impls/eccapfim/cell_traversal.cpp:3-77): for every segment the points start, face crossings of the
+ * node-centred cells, end -> pts[(q * max_pts + i) * 3 ..], counts[q] (may exceed max_pts: then the tail is dropped). */
+int xpic_cell_traversal(xpic_ctx* ctx, int64_t n, const double* end3, const double* start3, int max_pts, double* pts,
+  int* counts);
+/* ImplicitEsirkepov::interpolate (src/algorithms/implicit_esirkepov.cpp:60-90): E_p with the segment's 54-weight shape,
+ * B_p with Shape(midpoint) + SimpleInterpolation, from the context's XPIC_E / XPIC_B. */
+int xpic_implicit_esirkepov_interpolate(xpic_ctx* ctx, int64_t n, const double* rn3, const double* r03, double* Ep3,
+  double* Bp3);
+/* ImplicitEsirkepov::decompose (:92-117): field += alpha[q] * v[q] * shape(q), ghost contributions folded like
+ * DMLocalToGlobal(ADD_VALUES).  Uses the scratch vector XPIC_W2. */
+int xpic_implicit_esirkepov_decompose(xpic_ctx* ctx, int64_t n, const double* alpha, const double* v3, const double* rn3,
+  const double* r03, int field);
+
 /* ---- z-slab decomposition (DMDA da_processors_z = nranks; src/utils/world.cpp:36-38).  A context created with
  * nranks > 1 owns planes [rank*nz/nranks, (rank+1)*nz/nranks) and must be given a communicator before any
  * call that moves data between slabs (steps, solves, operator applies, re-binning, energy): those calls are

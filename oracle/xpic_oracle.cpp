@@ -1187,6 +1187,101 @@ struct RhoShape { /* ParticlesChargeDensity::Shape (src/diagnostics/charge_conse
   }
 };
 
+
+/* ------------------------------------------------------------------------------------------
+ * eccapfim inner kernels
+ * cell_traversal  (src/impls/eccapfim/cell_traversal.cpp:3-77): the points at which the straight
+ * path start -> end crosses the faces of the node-centred cells (cell of r = round(r/d)).
+ * ---------------------------------------------------------------------------------------- */
+std::vector<V3> cell_traversal(const double* d3, const V3& end, const V3& start)
+{
+  int curr[3], last[3];
+  for (int c = 0; c < 3; ++c) {
+    curr[c] = (int)std::round(start[c] / d3[c]);
+    last[c] = (int)std::round(end[c] / d3[c]);
+  }
+  if (curr[0] == last[0] && curr[1] == last[1] && curr[2] == last[2]) return {start, end};
+  V3 dir(end[X] - start[X], end[Y] - start[Y], end[Z] - start[Z]);
+  int sg[3];
+  double nxt[3], tt[3], dtt[3];
+  static const double max = std::numeric_limits<double>::max();
+  for (int c = 0; c < 3; ++c) {
+    sg[c] = dir[c] > 0 ? 1 : -1;
+    nxt[c] = (curr[c] + sg[c] * 0.5) * d3[c];
+    tt[c] = (dir[c] != 0) ? (nxt[c] - start[c]) / dir[c] : max;
+    dtt[c] = (dir[c] != 0) ? d3[c] / dir[c] * sg[c] : 0.0;
+  }
+  std::vector<V3> points;
+  points.push_back(start);
+  double t;
+  while (!(curr[0] == last[0] && curr[1] == last[1] && curr[2] == last[2])) {
+    if (tt[X] < tt[Y]) {
+      if (tt[X] < tt[Z]) { t = tt[X]; curr[X] += sg[X]; tt[X] += dtt[X]; }
+      else { t = tt[Z]; curr[Z] += sg[Z]; tt[Z] += dtt[Z]; }
+    }
+    else {
+      if (tt[Y] < tt[Z]) { t = tt[Y]; curr[Y] += sg[Y]; tt[Y] += dtt[Y]; }
+      else { t = tt[Z]; curr[Z] += sg[Z]; tt[Z] += dtt[Z]; }
+    }
+    points.push_back(V3(start[X] + dir[X] * t, start[Y] + dir[Y] * t, start[Z] + dir[Z] * t));
+    if (points.size() > 64) break; /* the reference loops until curr == last; a guard for degenerate input */
+  }
+  points.push_back(end);
+  return points;
+}
+
+/* ImplicitEsirkepov::Shape::setup  (src/algorithms/implicit_esirkepov.cpp:11-57) */
+struct ImplicitShape {
+  static constexpr int shw1 = 2, shw2 = 3, shm = 3 * 3 * 2 * 3;
+  int start[3];
+  double cache[shm];
+  static double sfunc_1(double s) { return 1.0 - std::abs(s); }
+  static double sfunc_21(double s) { s = std::abs(s); return (0.75 - s * s); }
+  static double sfunc_22(double s) { s = std::abs(s); return 0.5 * (1.5 - s) * (1.5 - s); }
+  static double sfunc_2(int j, double s) { return j == 1 ? sfunc_21(s) : sfunc_22(s); }
+  void setup(const double* d3, const V3& rn, const V3& r0)
+  {
+    double prn[3], pr0[3], prh[3], gc[3], gv[3];
+    for (int c = 0; c < 3; ++c) {
+      prn[c] = rn[c] / d3[c];
+      pr0[c] = r0[c] / d3[c];
+      prh[c] = 0.5 * (prn[c] + pr0[c]);
+      gc[c] = std::round(prh[c]);
+      start[c] = (int)gc[c] - 1;
+      gv[c] = gc[c] + 0.5;
+    }
+    int m = 0;
+    static constexpr double sixth = 1.0 / 6.0;
+    for (int cx = 0; cx < 3; cx++) {
+      int cy = (cx + 1) % 3, cz = (cx + 2) % 3;
+      for (int i = 0; i < 2; i++) {
+        double shx = sixth * sfunc_1(gv[cx] + (i - 1) - prh[cx]);
+        for (int j = 0; j < 3; j++) {
+          double sny = sfunc_2(j, gc[cy] + (j - 1) - prn[cy]);
+          double s0y = sfunc_2(j, gc[cy] + (j - 1) - pr0[cy]);
+          for (int k = 0; k < 3; k++) {
+            double snz = sfunc_2(k, gc[cz] + (k - 1) - prn[cz]);
+            double s0z = sfunc_2(k, gc[cz] + (k - 1) - pr0[cz]);
+            cache[m++] = shx * (sny * (2 * snz + s0z) + s0y * (2 * s0z + snz));
+          }
+        }
+      }
+    }
+  }
+  /* the 54 (node, component) pairs in cache order (:73-88, :99-114) */
+  template <class F>
+  void for_each(F f) const
+  {
+    int m = 0, i[3];
+    for (int cx = 0; cx < 3; cx++) {
+      int cy = (cx + 1) % 3, cz = (cx + 2) % 3;
+      for (i[cx] = 0; i[cx] < 2; i[cx]++)
+        for (i[cy] = 0; i[cy] < 3; i[cy]++)
+          for (i[cz] = 0; i[cz] < 3; i[cz]++) f(start[X] + i[X], start[Y] + i[Y], start[Z] + i[Z], cx, cache[m++]);
+    }
+  }
+};
+
 /* ParticlesChargeDensity::collect  (src/diagnostics/charge_conservation.cpp:67-97) */
 void charge_collect(const orc_sim* s, const Sort& sort, std::vector<double>& field)
 {
@@ -1723,6 +1818,53 @@ void orc_charge_density(orc_sim* s, int isort, double* rho)
   std::vector<double> f;
   charge_collect(s, s->sorts[isort], f);
   std::copy(f.begin(), f.end(), rho);
+}
+
+
+int orc_cell_traversal(const double* d3, const double* end3, const double* start3, int max_pts, double* pts)
+{
+  std::vector<V3> p = cell_traversal(d3, V3(end3), V3(start3));
+  int n = (int)p.size();
+  for (int i = 0; i < n && i < max_pts; ++i)
+    for (int c = 0; c < 3; ++c) pts[3 * i + c] = p[i][c];
+  return n;
+}
+
+/* ImplicitEsirkepov::interpolate (src/algorithms/implicit_esirkepov.cpp:60-90) on the simulation's E and B */
+void orc_implicit_esirkepov_interpolate(orc_sim* s, long n, const double* rn3, const double* r03, double* Ep3, double* Bp3)
+{
+  const Grid& gr = s->gr;
+  std::vector<double> El, Bl;
+  global_to_local(gr, s->E, El, 3);
+  global_to_local(gr, s->B, Bl, 3);
+  for (long q = 0; q < n; ++q) {
+    V3 rn(rn3 + 3 * q), r0(r03 + 3 * q), E_p, B_p, none;
+    Shape sh_m;
+    V3 mid(0.5 * (rn[X] + r0[X]), 0.5 * (rn[Y] + r0[Y]), 0.5 * (rn[Z] + r0[Z]));
+    sh_m.setup(gr.d, mid, 1.5, spline_of(2)); /* shape_radius / shape_function, sort_parameters.h:44-46 */
+    simple_interpolation(gr, sh_m, nullptr, Bl.data(), none, B_p);
+    ImplicitShape sh_e;
+    sh_e.setup(gr.d, rn, r0);
+    sh_e.for_each([&](int gx, int gy, int gz, int c, double w) { E_p[c] += El[gr.vl(gx, gy, gz, c)] * w; });
+    for (int c = 0; c < 3; ++c) { Ep3[3 * q + c] = E_p[c]; Bp3[3 * q + c] = B_p[c]; }
+  }
+}
+
+/* ImplicitEsirkepov::decompose (:92-117), then DMLocalToGlobal(ADD) into the named vector */
+int orc_implicit_esirkepov_decompose(orc_sim* s, long n, const double* alpha, const double* v3, const double* rn3,
+  const double* r03, const char* field)
+{
+  const Grid& gr = s->gr;
+  std::vector<double>* F = named(s, field);
+  if (!F) return 1;
+  std::vector<double> Jl(gr.G * 3, 0.0);
+  for (long q = 0; q < n; ++q) {
+    ImplicitShape sh_e;
+    sh_e.setup(gr.d, V3(rn3 + 3 * q), V3(r03 + 3 * q));
+    sh_e.for_each([&](int gx, int gy, int gz, int c, double w) { Jl[gr.vl(gx, gy, gz, c)] += alpha[q] * v3[3 * q + c] * w; });
+  }
+  local_to_global_add(gr, Jl, *F, 3);
+  return 0;
 }
 
 void orc_moment_density(orc_sim* s, int isort, double* out)

@@ -149,6 +149,13 @@ void orc_charge_collect(orc_sim*);
 void orc_charge_columns(orc_sim*, double* out);
 /* ParticlesChargeDensity::collect of one sort into rho[z][y][x] */
 void orc_charge_density(orc_sim*, int sort, double* rho);
+/* eccapfim inner kernels.  cell_traversal (src/impls/eccapfim/cell_traversal.cpp:3-77): returns the
+ * number of points (start, face crossings, end), the first max_pts of them in pts[3*i..]. */
+int orc_cell_traversal(const double* d3, const double* end3, const double* start3, int max_pts, double* pts);
+/* ImplicitEsirkepov::interpolate / decompose (src/algorithms/implicit_esirkepov.cpp:60-117) for n segments r0 -> rn */
+void orc_implicit_esirkepov_interpolate(orc_sim*, long n, const double* rn3, const double* r03, double* Ep3, double* Bp3);
+int orc_implicit_esirkepov_decompose(orc_sim*, long n, const double* alpha, const double* v3, const double* rn3,
+  const double* r03, const char* field);
 /* DistributionMoment "density" (src/diagnostics/distribution_moment.cpp:125-216) -> out[z][y][x] */
 void orc_moment_density(orc_sim*, int sort, double* out);
 

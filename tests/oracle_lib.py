@@ -97,6 +97,11 @@ def lib():
     L.orc_charge_columns.argtypes = [C.c_void_p, c_dp]
     L.orc_charge_density.argtypes = [C.c_void_p, C.c_int, c_dp]
     L.orc_moment_density.argtypes = [C.c_void_p, C.c_int, c_dp]
+    L.orc_cell_traversal.argtypes = [c_dp, c_dp, c_dp, C.c_int, c_dp]
+    L.orc_cell_traversal.restype = C.c_int
+    L.orc_implicit_esirkepov_interpolate.argtypes = [C.c_void_p, C.c_long, c_dp, c_dp, c_dp, c_dp]
+    L.orc_implicit_esirkepov_decompose.argtypes = [C.c_void_p, C.c_long, c_dp, c_dp, c_dp, c_dp, C.c_char_p]
+    L.orc_implicit_esirkepov_decompose.restype = C.c_int
     L.orc_boris_test_trajectory.argtypes = [C.c_int, C.c_char_p, c_dp, C.c_int]
     L.orc_spline.restype = C.c_double
     L.orc_spline.argtypes = [C.c_int, C.c_double]
@@ -219,6 +224,24 @@ class OracleSim:
         out = np.zeros(2 * self.nsorts + 2)
         self.L.orc_charge_columns(self.h, _dp(out))
         return out
+
+    def cell_traversal(self, end, start, max_pts=8):
+        d3 = np.array(self.d, dtype=np.float64)
+        pts = np.zeros((max_pts, 3))
+        n = self.L.orc_cell_traversal(_dp(d3), _dp(np.ascontiguousarray(end, dtype=np.float64)),
+                                      _dp(np.ascontiguousarray(start, dtype=np.float64)), max_pts, _dp(pts))
+        return pts[:min(n, max_pts)].copy(), n
+
+    def implicit_esirkepov_interpolate(self, rn, r0):
+        rn, r0 = np.ascontiguousarray(rn, dtype=np.float64), np.ascontiguousarray(r0, dtype=np.float64)
+        Ep, Bp = np.zeros_like(rn), np.zeros_like(rn)
+        self.L.orc_implicit_esirkepov_interpolate(self.h, rn.shape[0], _dp(rn), _dp(r0), _dp(Ep), _dp(Bp))
+        return Ep, Bp
+
+    def implicit_esirkepov_decompose(self, alpha, v, rn, r0, field):
+        alpha, v = np.ascontiguousarray(alpha, dtype=np.float64), np.ascontiguousarray(v, dtype=np.float64)
+        rn, r0 = np.ascontiguousarray(rn, dtype=np.float64), np.ascontiguousarray(r0, dtype=np.float64)
+        assert self.L.orc_implicit_esirkepov_decompose(self.h, rn.shape[0], _dp(alpha), _dp(v), _dp(rn), _dp(r0), field.encode()) == 0
 
     def moment_density(self, sort):
         out = np.zeros(self.fshape()[:3])

@@ -28,7 +28,8 @@ SYMBOLS = [
     "xpic_update_cells", "xpic_ecsim_fill_current", "xpic_ecsim_second_push", "xpic_basic_push",
     "xpic_ecsimcorr_first_push", "xpic_ecsimcorr_second_push", "xpic_ecsimcorr_final_update",
     "xpic_calculate_energy", "xpic_ecsimcorr_scalars", "xpic_solve", "xpic_set_tolerances", "xpic_set_preconditioner", "xpic_step",
-    "xpic_energy", "xpic_charge_density", "xpic_moment_density", "xpic_charge_collect", "xpic_charge_columns", "xpic_comm_rccl_unique_id", "xpic_comm_init_rccl", "xpic_comm_init_callbacks",
+    "xpic_energy", "xpic_charge_density", "xpic_moment_density", "xpic_cell_traversal", "xpic_implicit_esirkepov_interpolate",
+    "xpic_implicit_esirkepov_decompose", "xpic_charge_collect", "xpic_charge_columns", "xpic_comm_rccl_unique_id", "xpic_comm_init_rccl", "xpic_comm_init_callbacks",
     "xpic_profile_enable", "xpic_profile_reset", "xpic_profile_get", "xpic_probe_copy_bandwidth",
 ]
 
@@ -302,6 +303,26 @@ class Context:
         out = np.zeros((self.nzl, self.n[1], self.n[0]))
         self._ck(self.L.xpic_moment_density(self.h, sort, _dp(out)))
         return out
+
+    def cell_traversal(self, end, start, max_pts=8):
+        end, start = np.ascontiguousarray(end, dtype=np.float64), np.ascontiguousarray(start, dtype=np.float64)
+        n = end.shape[0]
+        pts = np.zeros((n, max_pts, 3))
+        counts = np.zeros(n, dtype=np.int32)
+        self._ck(self.L.xpic_cell_traversal(self.h, C.c_int64(n), _dp(end), _dp(start), max_pts, _dp(pts),
+                                            counts.ctypes.data_as(C.POINTER(C.c_int))))
+        return pts, counts
+
+    def implicit_esirkepov_interpolate(self, rn, r0):
+        rn, r0 = np.ascontiguousarray(rn, dtype=np.float64), np.ascontiguousarray(r0, dtype=np.float64)
+        Ep, Bp = np.zeros_like(rn), np.zeros_like(rn)
+        self._ck(self.L.xpic_implicit_esirkepov_interpolate(self.h, C.c_int64(rn.shape[0]), _dp(rn), _dp(r0), _dp(Ep), _dp(Bp)))
+        return Ep, Bp
+
+    def implicit_esirkepov_decompose(self, alpha, v, rn, r0, field):
+        alpha, v = np.ascontiguousarray(alpha, dtype=np.float64), np.ascontiguousarray(v, dtype=np.float64)
+        rn, r0 = np.ascontiguousarray(rn, dtype=np.float64), np.ascontiguousarray(r0, dtype=np.float64)
+        self._ck(self.L.xpic_implicit_esirkepov_decompose(self.h, C.c_int64(rn.shape[0]), _dp(alpha), _dp(v), _dp(rn), _dp(r0), field))
 
     def charge_collect(self):
         self._ck(self.L.xpic_charge_collect(self.h))
