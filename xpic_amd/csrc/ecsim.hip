@@ -102,44 +102,68 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
 
   // Phase 2 runs on the matrix cores.  For a row component c1 the cell block is the GEMM
   //   D_c1[12 x 36] = S_c1^T [12 x P] * ( S [P x 36] o matB_c1 )        (P = particles of the cell)
-  // issued as v_mfma_f64_16x16x4_f64 over K = 4 particles: A = 12 (+4 unused) rows of component c1, B = three
-  // 16-column tiles.  The third tile holds block columns 32..35 and, in its 12 spare columns, the stage rows
-  // 36..47: column 45 + c1 is multiplied by one (every other spare column by zero), so D_c1[.][45 + c1] is the
-  // cell's currI = sum_p s_p I_p[c1] for free.
-  // MFMA lane roles: operand element (i or j = lane & 15, k = lane >> 4); result rows (lane >> 4) + 4 r, r < 3.
+  // over K = 4 particles per step.  Columns 0..31 go through v_mfma_f64_16x16x4_f64 (A = the 12 (+4 unused) rows of the
+  // component, B = two 16-column tiles): 6 instructions.  The last four columns 32..35 and the cell's currI
+  // (sum_p s_p I_p[c1], i.e. the product with the stage rows 45..47) would fill a third 16-column tile only to 5/16;
+  // they are 18 blocks of 4 x 4 instead and take 5 v_mfma_f64_4x4x4_4b_f64 (4 independent blocks each).
+  // 16x16x4 lane roles: operand element (i or j = lane & 15, k = lane >> 4); result rows (lane >> 4) + 4 r, r < 3.
+  // 4x4x4 lane roles (probed, tools/ubench/mfma_f64_4x4.hip): A[b][i][k], B[b][k][j] at lane 16 k + 4 b + (i or j);
+  // D[b][i][j] at lane 16 i + 4 b + j.
   const int mj = lane & 15, mk = lane >> 4;
   const double* a_ptr = st + min(mj, 11) * kPadP + mk;                 // + c1 * 12 rows
   const double* b_ptr = st + mj * kPadP + mk;                          // + t * 16 rows
   const double* m0_ptr = st + (36 + (mj < 12 ? 0 : 1)) * kPadP + mk;  // tile 0: columns 0..15   (+ c1 * 3 rows)
   const double* m1_ptr = st + (36 + (mj < 8 ? 1 : 2)) * kPadP + mk;   // tile 1: columns 16..31
-  const double* m2_ptr[3];                                             // tile 2: columns 32..35 | spare
+  // 4x4x4 instructions n = 0..4, block b = (lane >> 2) & 3 of each:
+  //   n = 0, 1: row blocks 4 n + b, columns 32..35          n = 2, 3: row blocks 4 (n - 2) + b, currI
+  //   n = 4   : b = 0: row block 8, columns 32..35;  b = 1: row block 8, currI;  b = 2, 3: idle (zeros)
+  const int qb = (lane >> 2) & 3, qj = lane & 3;
+  const double* a4_ptr[3] = {st + mj * kPadP + mk, st + (16 + mj) * kPadP + mk, st + (32 + qj) * kPadP + mk};
+  const double* x4_ptr[5]; // first factor of B
+  const double* y4_ptr[3]; // second factor of B for n = 0, 1, 4 (the currI operands need none)
 #pragma unroll
-  for (int c = 0; c < 3; ++c)
-    m2_ptr[c] = st + (mj < 4 ? 36 + 3 * c + 2 : (mj == 13 + c ? kRowOne : kRowZero)) * kPadP + mk;
+  for (int n = 0; n < 2; ++n) {
+    const int c1n = (4 * n + qb) / 3; // row component of this block's rows
+    x4_ptr[n] = st + (32 + qj) * kPadP + mk;
+    y4_ptr[n] = st + (36 + 3 * c1n + 2) * kPadP + mk;
+    x4_ptr[2 + n] = st + (qj == c1n ? 45 + qj : kRowZero) * kPadP + mk;
+  }
+  x4_ptr[4] = st + (qb == 0 ? 32 + qj : (qb == 1 && qj == 2 ? 47 : kRowZero)) * kPadP + mk;
+  y4_ptr[2] = st + (qb == 0 ? 44 : (qb == 1 ? kRowOne : kRowZero)) * kPadP + mk;
 
-  // per-lane flush descriptors (line << 2 | row x offset + 1) of the 27 results, constant over the march; two
-  // 16-bit descriptors per register, 0xffff = nothing to add (structural zero or spare column)
-  unsigned edesc[14];
+  // per-lane flush descriptors (line << 2 | row x offset + 1) of the 18 + 5 results, constant over the march; two
+  // 16-bit descriptors per register, 0xffff = nothing to add (structural zero, unused row, idle block)
+  auto curdesc = [&](int row) {
+    const int c = row / 12;
+    int o[3];
+    block_node_offset(c, row % 12, o);
+    const int id = c == 0 ? o[2] * 2 + o[1] : (c == 1 ? 4 + o[2] * 3 + (o[1] + 1) : 10 + (o[2] + 1) * 2 + o[1]);
+    return ((kMatLines + id) << 2) | (o[0] + 1);
+  };
+  constexpr int kDesc = 18 + 5;
+  unsigned edesc[(kDesc + 1) / 2];
 #pragma unroll
-  for (int e = 0; e < 14; ++e) edesc[e] = 0xffffffffu;
+  for (int e = 0; e < (kDesc + 1) / 2; ++e) edesc[e] = 0xffffffffu;
+  auto set_desc = [&](int e, int d) {
+    edesc[e / 2] = (edesc[e / 2] & ~(0xffffu << (16 * (e & 1)))) | (((unsigned)d & 0xffffu) << (16 * (e & 1)));
+  };
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const int row = 12 * c + mk + 4 * r, col = 16 * t + mj;
-        int d = -1;
-        if (col < 36) d = etab[row * 36 + col];
-        else if (col == 45 + c) {
-          int o[3];
-          block_node_offset(c, row % 12, o);
-          const int id = c == 0 ? o[2] * 2 + o[1] : (c == 1 ? 4 + o[2] * 3 + (o[1] + 1) : 10 + (o[2] + 1) * 2 + o[1]);
-          d = ((kMatLines + id) << 2) | (o[0] + 1);
-        }
-        const int e = (c * 3 + t) * 3 + r;
-        edesc[e / 2] = (edesc[e / 2] & ~(0xffffu << (16 * (e & 1)))) | (((unsigned)d & 0xffffu) << (16 * (e & 1)));
-      }
+      for (int r = 0; r < 3; ++r) set_desc((c * 2 + t) * 3 + r, etab[(12 * c + mk + 4 * r) * 36 + 16 * t + mj]);
+  {
+    const int di = lane >> 4; // D[b][i][j]: i = lane >> 4
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int row = 4 * (4 * n + qb) + di;
+      set_desc(18 + n, etab[row * 36 + 32 + qj]);
+      set_desc(18 + 2 + n, qj == row / 12 ? curdesc(row) : -1);
+    }
+    const int row8 = 32 + di;
+    set_desc(18 + 4, qb == 0 ? etab[row8 * 36 + 32 + qj] : (qb == 1 && qj == 2 ? curdesc(row8) : -1));
+  }
 
   const long pencil0 = ((long)cz * g.ny + cy) * g.nx;
   const bool cs_lds = g.nx <= kMaxNxLds;
@@ -213,11 +237,12 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
     const int i = j * kW + wave;
     const bool active = i < g.nx;
 
-    mfma_acc acc[3][3];
+    mfma_acc acc[3][2];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int t = 0; t < 3; ++t) acc[c][t] = mfma_acc{0.0, 0.0, 0.0, 0.0};
+      for (int t = 0; t < 2; ++t) acc[c][t] = mfma_acc{0.0, 0.0, 0.0, 0.0};
+    double acc4[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
 
     if (active) {
       const int start = pf.start, cnt = pf.cnt;
@@ -310,27 +335,35 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
         wave_sync();
 
         {
-          // K = 4 particles per step: 15 operands (3 A, 3 B, 9 matB multipliers), 9 products, 9 MFMAs; the operands
-          // of step s+1 are requested before the MFMAs of step s
-          struct Operands { double a[3], b[3], m[9]; };
+          // K = 4 particles per step: 22 operands, 9 products, 6 + 5 MFMAs; the operands of step s+1 are requested
+          // before the MFMAs of step s
+          struct Operands { double a[3], b[2], m[6], a4[3], x4[5], y4[3]; };
           auto load = [&](Operands& o, int p0) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) o.a[c] = a_ptr[c * 12 * kPadP + p0];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) o.b[t] = b_ptr[t * 16 * kPadP + p0];
+            for (int t = 0; t < 2; ++t) o.b[t] = b_ptr[t * 16 * kPadP + p0];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-              o.m[c * 3 + 0] = m0_ptr[c * 3 * kPadP + p0];
-              o.m[c * 3 + 1] = m1_ptr[c * 3 * kPadP + p0];
-              o.m[c * 3 + 2] = m2_ptr[c][p0];
+              o.m[c * 2 + 0] = m0_ptr[c * 3 * kPadP + p0];
+              o.m[c * 2 + 1] = m1_ptr[c * 3 * kPadP + p0];
             }
+#pragma unroll
+            for (int n = 0; n < 3; ++n) { o.a4[n] = a4_ptr[n][p0]; o.y4[n] = y4_ptr[n][p0]; }
+#pragma unroll
+            for (int n = 0; n < 5; ++n) o.x4[n] = x4_ptr[n][p0];
           };
           auto gemm = [&](const Operands& o) {
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
-              for (int t = 0; t < 3; ++t)
-                acc[c][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[c], o.b[t] * o.m[c * 3 + t], acc[c][t], 0, 0, 0);
+              for (int t = 0; t < 2; ++t)
+                acc[c][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[c], o.b[t] * o.m[c * 2 + t], acc[c][t], 0, 0, 0);
+            acc4[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a4[0], o.x4[0] * o.y4[0], acc4[0], 0, 0, 0);
+            acc4[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a4[1], o.x4[1] * o.y4[1], acc4[1], 0, 0, 0);
+            acc4[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a4[0], o.x4[2], acc4[2], 0, 0, 0);
+            acc4[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a4[1], o.x4[3], acc4[3], 0, 0, 0);
+            acc4[4] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a4[2], o.x4[4] * o.y4[2], acc4[4], 0, 0, 0);
           };
           const int nks = (mcnt + 3) >> 2;
           Operands A, Bo;
@@ -405,16 +438,18 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
     lds_barrier();
     if (active) {
       // row node x of cell (unwrapped) u = i+1 with offset o is column u+o; window column 0 is kW*j
+      auto add = [&](int e, double val) {
+        const unsigned d = (edesc[e / 2] >> (16 * (e & 1))) & 0xffffu;
+        if (d != 0xffffu) unsafeAtomicAdd(&win[(d >> 2) * kSlots + wave + (d & 3)], val);
+      };
 #pragma unroll
       for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 3; ++r) {
-            const int e = (c * 3 + t) * 3 + r;
-            const unsigned d = (edesc[e / 2] >> (16 * (e & 1))) & 0xffffu;
-            if (d != 0xffffu) unsafeAtomicAdd(&win[(d >> 2) * kSlots + wave + (d & 3)], acc[c][t][r]);
-          }
+          for (int r = 0; r < 3; ++r) add((c * 2 + t) * 3 + r, acc[c][t][r]);
+#pragma unroll
+      for (int n = 0; n < 5; ++n) add(18 + n, acc4[n]);
     }
     lds_barrier();
     // ---- stream out the finished columns (plain RMW, kW consecutive doubles per line), keep 2 in registers
