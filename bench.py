@@ -64,7 +64,7 @@ def cpu_baseline(args):
 def pmc_traffic(grid):
     """HBM bytes per k_matA launch from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     passes, KiB units, FETCH_SIZE x 2 on gfx950 -- tools/pmc_summary.py); only valid for the grid it was taken on."""
-    path = os.path.join(ROOT, "profiles", "r01_v7_pmc_traffic_256.txt")
+    path = os.path.join(ROOT, "profiles", "r01_v8_pmc_traffic_256.txt")
     if grid != 256 or not os.path.exists(path):
         return None
     for line in open(path):
