@@ -9,7 +9,7 @@ def rep(a, b, count=1):
     assert a in s, a
     s = s.replace(a, b, count)
 rep("int per_y, int per_z, int first_sort)\n{", "int per_y, int per_z, int first_sort, long long* stamps)\n{\n#define STAMP(k) do { if (stamps && blockIdx.x % 97 == 0 && blockIdx.x / 97 < 32 && lane == 0 && j >= 8 && j < 40) stamps[(((blockIdx.x / 97) * 32 + (j - 8)) * 4 + wave) * 8 + (k)] = clock64(); } while (0)\n")
-rep("    mfma_acc acc[3][3];\n", "    STAMP(0);\n    mfma_acc acc[3][3];\n")
+rep("    mfma_acc acc[3][2];\n", "    STAMP(0);\n    mfma_acc acc[3][2];\n")
 rep("    // next chunk's cell: particle data and B neighbourhood travel", "    STAMP(1);\n    // next chunk's cell: particle data and B neighbourhood travel")
 rep("    lds_barrier();\n    double* win = sh;", "    STAMP(2);\n    lds_barrier();\n    STAMP(3);\n    double* win = sh;")
 rep("    lds_barrier();\n    if (active) {\n      // row node x", "    lds_barrier();\n    STAMP(4);\n    if (active) {\n      // row node x")

@@ -94,7 +94,6 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
 
   __shared__ __attribute__((aligned(16))) double sh[kW * kStage];
   __shared__ int cstart[kMaxNxLds + 2];
-  __shared__ double* lbase[kLines];
   __shared__ double bnb[kW][54];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double* st = sh + wave * kStage;
@@ -169,8 +168,13 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
   const bool cs_lds = g.nx <= kMaxNxLds;
   if (cs_lds)
     for (int i = threadIdx.x; i <= g.nx; i += kThreads) cstart[i] = s.cell_start[pencil0 + i];
-  // address of column 0 of every line of this pencil
-  for (int line = threadIdx.x; line < kLines; line += kThreads) {
+  // address of column 0 of the window lines this thread owns (line = thread + mm * kThreads), first-touch flag in bit 0
+  uintptr_t lbase[kOwn];
+#pragma unroll
+  for (int mm = 0; mm < kOwn; ++mm) {
+    const int line = threadIdx.x + mm * kThreads;
+    lbase[mm] = 0;
+    if (line >= kLines) continue;
     const int ld = linetab[line];
     const int ry = g.wy(cy + ((ld >> 2) & 3) - 1);
     const int rz = cz + ((ld >> 4) & 3) - 1;
@@ -198,10 +202,10 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
         if (cb * ncol_y + ca < my_order) first = false;
       }
     }
-    lbase[line] = (double*)((uintptr_t)base | (first ? 1u : 0u));
+    lbase[mm] = (uintptr_t)base | (first ? 1u : 0u);
   }
 
-  // lbase / cstart are read by other threads from the first chunk on (the RMW prefetch comes before any barrier)
+  // cstart is read by other threads from the first chunk on
   __syncthreads();
 
   // cells are visited in the order 1, 2, ..., nx-1, 0 so that finished columns start 64-byte aligned
@@ -398,7 +402,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
 #pragma unroll
     for (int mm = 0; mm < kOwn; ++mm) {
       const int line = threadIdx.x + mm * kThreads;
-      const uintptr_t lb = line < kLines ? (uintptr_t)lbase[line] : 0;
+      const uintptr_t lb = lbase[mm];
       fst[mm] = lb & 1;
       const bool vec = line < kMatLines ? vecL : vecI;
       ptr[mm] = lb ? (double*)(lb & ~(uintptr_t)1) + (long)j * (line < kMatLines ? kLBlock : kW) : nullptr;
@@ -495,7 +499,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
   for (int mm = 0; mm < kOwn; ++mm) {
     const int line = threadIdx.x + mm * kThreads;
     if (line < kLines) {
-      double* base = (double*)((uintptr_t)lbase[line] & ~(uintptr_t)1);
+      double* base = (double*)(lbase[mm] & ~(uintptr_t)1);
 #pragma unroll
       for (int c = 0; c < 2; ++c)
         if (carry[mm][c] != 0.0) unsafeAtomicAdd(base + g.wx(c), carry[mm][c]);
