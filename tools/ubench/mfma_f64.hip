@@ -46,7 +46,7 @@ int main()
     hipEventRecord(e0); k_mfma<<<256 * 4, 64 * waves>>>(out, cyc, n); hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1); hipMemcpy(h, cyc, 8, hipMemcpyDeviceToHost);
     printf("mfma_f64_16x16x4: %d wave(s)/WG, 4 WG/CU: %.3f ms, %.1f clock64 ticks per MFMA, %.1f TFLOP/s\n", waves, ms,
-      (double)h[0] / (4.0 * n), 1024.0 * waves * 4 * 2048.0 * 4 * n / (ms * 1e-3) / 1e12);
+      (double)h[0] / (4.0 * n), 1024.0 * waves * 4 * 2048.0 * n / (ms * 1e-3) / 1e12);
     k_fma<<<256 * 4, 64 * waves>>>(out, cyc, n); hipDeviceSynchronize();
     hipEventRecord(e0); k_fma<<<256 * 4, 64 * waves>>>(out, cyc, n); hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1); hipMemcpy(h, cyc, 8, hipMemcpyDeviceToHost);
