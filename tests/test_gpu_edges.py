@@ -118,3 +118,38 @@ def test_capacity_and_argument_errors():
         X.Context("ecsim", (3, 8, 8), (0.5, 0.5, 0.5), 1.0)  # extent below the stencil width
     with pytest.raises(X.XpicError, match="basic scheme"):
         X.Context("basic", (8, 8, 8), (0.5, 0.5, 0.5), 1.0).ecsim_fill_current()
+
+
+def test_long_pencils_and_odd_colour_periods(oracle):
+    """A pencil longer than the LDS cell_start row (1024 cells), extents whose colour periods are 5 and 4, nx not a
+    multiple of the 4-wide matL x-block, two species: assembly, solve and push against the oracle for two steps."""
+    import xpic_amd as X
+
+    n, d = (1030, 5, 4), (0.5, 0.5, 0.5)
+    o, g = pair(oracle, "ecsim", n, d, 0.4)
+    rng = np.random.default_rng(11)
+    N = n[0] * n[1] * n[2]
+    for (q, m) in ((-1.0, 1.0), (1.0, 25.0)):
+        so = o.add_sort(2, 1.0, q, m)
+        sg = g.add_sort(2, 1.0, q, m, capacity=4 * N)
+        pts = np.hstack([rng.random((2 * N, 3)) * np.array(n) * np.array(d), rng.normal(0, 0.05, (2 * N, 3))])
+        assert o.add_particles(so, pts) == g.add_particles(sg, pts) == 2 * N
+    B = np.zeros(o.fshape()) + np.array([0.05, 0.1, -0.2])
+    for name, fid in (("B", X.B), ("B0", X.B0)):
+        o.set_field(name, B)
+        g.set_field(fid, B)
+    oracle.lib().orc_ecsim_fill_current(o.h)
+    g.ecsim_fill_current()
+    Lo, Lg = o.matL(), g.matL()
+    assert np.abs(Lo - Lg).max() <= 1e-12 * np.abs(Lo).max()
+    same_fields(o, g, ["currI"], 1e-12)
+    for s in (o, g):
+        s.set_tolerances(1e-11, 1e-50, 300)
+    for _ in range(2):
+        assert o.step() >= 0
+        g.step()
+    same_fields(o, g, ["E", "B"], 1e-6)
+    for k in range(2):
+        po, co = canon(*o.particles(k))
+        pg, cg = canon(*g.particles(k))
+        assert np.array_equal(co, cg) and np.abs(po - pg).max() < 1e-9
