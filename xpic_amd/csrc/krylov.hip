@@ -26,7 +26,9 @@ int gmres(xpic_ctx* c, int op, const double* b, double* x, double rtol, double a
   int* reason, double* rnorm_out)
 {
   const int m = kRestart;
-  const bool pc = op == XPIC_OP_MATA_GMRES && c->precond == 1;
+  // both GMRES solves are right-preconditioned by the Chebyshev polynomial in matM: for the "correct" solve on matM
+  // itself it is an approximate inverse (1-2 iterations instead of ~25)
+  const bool pc = (op == XPIC_OP_MATA_GMRES || op == XPIC_OP_MATM_GMRES) && c->precond == 1;
   double* tmp = c->kry_t;
   double* V = c->kry_V;
   double* w = c->kry_w;
@@ -35,7 +37,10 @@ int gmres(xpic_ctx* c, int op, const double* b, double* x, double rtol, double a
   double bb;
   XPIC_CALL(vec_dot_host(c, b, b, &bb));
   const double bnorm = std::sqrt(bb);
-  const double tol = std::max(rtol * bnorm, atol);
+  // The preconditioned "correct" solve costs next to nothing per iteration: it is run two orders beyond the
+  // requested tolerance, so its result does not depend on where inside the tolerance the iteration happens to stop
+  // (the reference's tables pin 7 digits of the field energy).
+  const double tol = std::max(rtol * bnorm, atol) * (pc && op == XPIC_OP_MATM_GMRES ? 1e-2 : 1.0);
   double rnorm = bnorm;
   int its = 0;
   *reason = 0;
