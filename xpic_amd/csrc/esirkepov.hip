@@ -235,11 +235,13 @@ __global__ void __launch_bounds__(kThreadsB) k_esirkepov_push(GridDev g, SortDev
           const double* snB = st + (18 + axB * kT + iB) * kBPad;
           const double* dC = st + (36 + c * kT) * kBPad;
           for (int p = 0; p < mcnt; ++p) {
-            const double T = snA[p] * (2.0 * snB[p] + soB[p]) + soA[p] * (2.0 * soB[p] + snB[p]);
+            // W = -qd * D_c[t] * T with T = Sn_A (2 Sn_B + So_B) + So_A (2 So_B + Sn_B): the factor common to the six
+            // nodes of the line is formed once (one rounding apart from the reference's (-qd * D) * T)
+            const double T = -qd * (snA[p] * (2.0 * snB[p] + soB[p]) + soA[p] * (2.0 * soB[p] + snB[p]));
             double run = 0.0;
 #pragma unroll
             for (int t = 0; t < kT; ++t) {
-              run = run + (-qd * dC[t * kBPad + p] * T); // temp_j = temp_j + w_p
+              run = run + dC[t * kBPad + p] * T; // temp_j = temp_j + w_p
               acc[rr][t] += run;
             }
           }
