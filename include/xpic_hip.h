@@ -136,15 +136,16 @@ int xpic_calculate_energy(xpic_ctx* ctx, int sort, double* energy);
 /* pred_w, corr_w, lambda_dK, pred_dK, corr_dK, energy (ecsimcorr/particles.h:44-49) */
 int xpic_ecsimcorr_scalars(xpic_ctx* ctx, int sort, double* out6);
 
-/* KSPSolve (src/impls/ecsim/simulation.cpp:266): x0 = 0, no preconditioner, converged when
- * ||r|| <= max(rtol ||b||, atol). *iterations >= 0; *reason > 0 converged, < 0 diverged (maxit).
+/* KSPSolve (src/impls/ecsim/simulation.cpp:266): x0 = 0, preconditioner as set by xpic_set_preconditioner (both GMRES
+ * operators; CG is unpreconditioned), converged when the TRUE residual ||r|| <= max(rtol ||b||, atol) (the cheap
+ * preconditioned XPIC_OP_MATM_GMRES is run to 1e-2 of that). *iterations >= 0; *reason > 0 converged, < 0 diverged (maxit).
  * A non-converged solve RETURNS NON-ZERO, like KSPSetErrorIfNotConverged (:562). */
 int xpic_solve(xpic_ctx* ctx, int op, int rhs, int x, double rtol, double atol, int maxit, int* iterations,
   int* reason, double* rnorm);
 /* KSPSetTolerances used by the step drivers (src/impls/ecsim/simulation.h:15-18: 1e-7,1e-7,100) */
 int xpic_set_tolerances(xpic_ctx* ctx, double rtol, double atol, int maxit);
 
-/* PCSetType for the "predict" KSP.  The reference runs PETSc's default ILU(0) (not part of its tree, not a GPU
+/* PCSetType for the "predict" and "correct" KSPs.  The reference runs PETSc's default ILU(0) (not part of its tree, not a GPU
  * algorithm); here: kind 0 = none, kind 1 (default) = a fixed Chebyshev polynomial in matM applied from the right
  * (matM = 2 I + 0.5 dt^2 rotB rotE dominates matA and its spectral interval is known in closed form).
  * degree <= 0 keeps the automatic choice.  The stopping rule of xpic_solve is unchanged: true residual norm. */
