@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- xpic hot-path benchmark on MI355X (contract: see the task statement / DESIGN.md section 6).
 
-A "step" is one full ECSIM timestep (first_push + re-bin, current/mass-matrix assembly, implicit field solve,
-second_push, field update) of BASELINE.json's headline configuration: 256^3 cells, 64 particles per cell,
-one electron species, uniform B0 -- all resident in HBM before the timed region.  One process per GPU.
+A "step" is one full timestep of the selected scheme (default: ECSIM = first_push + re-bin, current/mass-matrix
+assembly, implicit field solve, second_push, field update) of BASELINE.json's headline configuration: 256^3 cells,
+64 particles per cell, one electron species, uniform B0 -- all resident in HBM before the timed region.
+
+One process per GPU.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment STARTS the N ranks
+itself (fresh child processes, one per GPU, RCCL over xGMI; the parent never touches the GPU); under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` each process is one of the ranks.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -15,7 +21,88 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL across processes)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy rate
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy rate
+FP64_PEAK_TF = 78.6     # fp64 vector = fp64 matrix peak of MI355X (measured with v_mfma_f64_16x16x4: 75.5)
+FILL_FLOP_PER_PARTICLE = 1200.0  # 576 products + adds of decompose_ecsim_current + the per-particle algebra
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--grid", type=int, default=None, help="cells per axis (default 256; 128 for the side schemes)")
+    ap.add_argument("--ppc", type=int, default=None, help="particles per cell (default 64; 32 for the side schemes)")
+    ap.add_argument("--dx", type=float, default=0.5)
+    ap.add_argument("--dt", type=float, default=None, help="default 1.0 (ecsim, ecsimcorr), 0.1 (basic: explicit, CFL)")
+    ap.add_argument("--vth", type=float, default=0.014)  # T = 0.1 keV electrons (tests/ecsim/ecsim_ex1.cpp:66-70)
+    ap.add_argument("--b0", type=float, default=0.2)
+    ap.add_argument("--loader", default="poisson", choices=["poisson", "regular"],
+                    help="poisson: positions uniform over the box like CoordinateInBox (Poisson occupancy of the cells); "
+                         "regular: exactly ppc particles in every cell")
+    ap.add_argument("--cpu-grid", type=int, default=64)   # 64^3 x ppc, as SURVEY 8(d) asks: ~20 s of oracle work
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--probe", action="store_true", help="also run the device copy probes (PMC calibration)")
+    ap.add_argument("--plain-gmres", action="store_true", help="unpreconditioned GMRES(30), as the CPU oracle runs")
+    ap.add_argument("--cheb-degree", type=int, default=0, help="override the Chebyshev preconditioner degree (experiments)")
+    ap.add_argument("--scheme", default="ecsim", choices=["ecsim", "ecsimcorr", "basic"],
+                    help="ecsim is the headline workload (BASELINE configs[2]); basic = configs[1], ecsimcorr = configs[4] "
+                         "at one GPU's share: side measurements")
+    args = ap.parse_args(argv)
+    side = args.scheme != "ecsim"
+    if args.grid is None:
+        args.grid = 128 if side else 256
+    if args.ppc is None:
+        args.ppc = 32 if side else 64
+    if args.dt is None:
+        args.dt = 0.1 if args.scheme == "basic" else 1.0
+    return args
+
+
+# ---------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks.  The parent only counts devices (no HIP context on this image) and
+# waits; it never initialises the GPU and never execs.  Mirrors `mpiexec -np N ... -da_processors_z N`
+# (tests/ecsim/CMakeLists.txt:15-17 of the reference).
+# ---------------------------------------------------------------------------------------------------------
+def launch_ranks(args, argv):
+    import torch
+
+    n = args.gpus
+    rehearsal = os.environ.get("XPIC_BENCH_COMM", "rccl") == "gloo"
+    ndev = torch.cuda.device_count()
+    need = 1 if rehearsal else n
+    if ndev < need:
+        print(f"bench.py --gpus {n}: needs {need} MI355X device(s), found {ndev}; the xpic HIP path has no CPU "
+              f"fallback and will not run fewer ranks than asked", file=sys.stderr, flush=True)
+        return 3
+    if args.grid % n or args.grid // n < 6:
+        print(f"bench.py --gpus {n}: the {args.grid}^3 box cannot be cut into {n} z-slabs of >= 6 planes",
+              file=sys.stderr, flush=True)
+        return 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for q in live:
+                    procs[q].terminate()  # exact PIDs of our own children
+        time.sleep(0.2)
+    return rc
 
 
 def cpu_baseline(args):
@@ -29,7 +116,7 @@ def cpu_baseline(args):
     n = args.cpu_grid
     ppc = args.ppc
     threads = oracle_lib.default_threads()
-    o = oracle_lib.OracleSim("ecsim", (n, n, n), (args.dx,) * 3, args.dt)
+    o = oracle_lib.OracleSim(args.scheme, (n, n, n), (args.dx,) * 3, args.dt)
     s = o.add_sort(ppc, 1.0, -1.0, 1.0)
     rng = np.random.default_rng(1)
     npart = ppc * n ** 3
@@ -44,55 +131,49 @@ def cpu_baseline(args):
     o.set_field("B", B)
     o.set_field("B0", B)
     o.step()  # warm-up (first touch, allocator)
+    o.solve_stats(reset=True)
     t0 = time.perf_counter()
-    its = 0
     nsteps = args.cpu_steps
     for _ in range(nsteps):
-        its += o.step()
+        o.step()
     dt = time.perf_counter() - t0
+    ksp_s, its = o.solve_stats()
+    solver = "GMRES(30), no preconditioner" if args.scheme != "basic" else "none (explicit scheme)"
     return {
         "value": npart * nsteps / dt,
         "unit": "particles/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"oracle ecsim step, {n}^3 cells x {ppc} ppc ({npart} particles), {nsteps} steps, "
-                  f"{its} GMRES(30) iterations, {dt:.1f} s on {threads} OpenMP threads",
-        "ksp_iters_per_s_at_sample_grid": None,
+        "sample": f"oracle {args.scheme} step, {n}^3 cells x {ppc} ppc ({npart} particles), {nsteps} steps, "
+                  f"{its} Krylov iterations ({solver}), {dt:.1f} s on {threads} OpenMP threads",
+        "ksp_iters_per_s_at_sample_grid": (its / ksp_s) if its and ksp_s > 0 else None,
+        "ksp_rows_per_s": (its * 3 * n ** 3 / ksp_s) if its and ksp_s > 0 else None,  # grid-size independent rate
+        "ksp_iterations_per_step": its / nsteps,
     }
 
 
-def pmc_traffic(grid):
-    """HBM bytes per k_matA launch from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-    passes, KiB units, FETCH_SIZE x 2 on gfx950 -- tools/pmc_summary.py); only valid for the grid it was taken on."""
-    path = os.path.join(ROOT, "profiles", "r01_v8_pmc_traffic_256.txt")
-    if grid != 256 or not os.path.exists(path):
+def pmc_traffic(scheme, grid, kernel):
+    """HBM bytes per launch of `kernel` from this round's committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate passes, KiB units, FETCH_SIZE x 2 on gfx950 -- tools/pmc_summary.py); valid only for the grid and scheme
+    the file was taken on."""
+    name = {"ecsim": "r02_pmc_traffic_256.txt", "basic": "r02_pmc_traffic_basic_128.txt",
+            "ecsimcorr": "r02_pmc_traffic_ecsimcorr_128.txt"}[scheme]
+    path = os.path.join(ROOT, "profiles", name)
+    if grid != (256 if scheme == "ecsim" else 128) or not os.path.exists(path):
         return None
     for line in open(path):
-        if line.startswith("k_matA<true, true>"):
+        if line.startswith(kernel):
             return float(line.split()[-2]) * 1e9
     return None
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--grid", type=int, default=256)
-    ap.add_argument("--ppc", type=int, default=64)
-    ap.add_argument("--dx", type=float, default=0.5)
-    ap.add_argument("--dt", type=float, default=1.0)
-    ap.add_argument("--vth", type=float, default=0.014)  # T = 0.1 keV electrons (tests/ecsim/ecsim_ex1.cpp:66-70)
-    ap.add_argument("--b0", type=float, default=0.2)
-    ap.add_argument("--cpu-grid", type=int, default=48)   # 48^3 x 64 ppc x 4 steps: ~13 s of oracle work
-    ap.add_argument("--cpu-steps", type=int, default=4)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--probe", action="store_true", help="also run the device copy probes (PMC calibration)")
-    ap.add_argument("--plain-gmres", action="store_true", help="unpreconditioned GMRES(30), as the CPU oracle runs")
-    ap.add_argument("--cheb-degree", type=int, default=0, help="override the Chebyshev preconditioner degree (experiments)")
-    ap.add_argument("--scheme", default="ecsim", choices=["ecsim", "ecsimcorr", "basic"],
-                    help="ecsim is the headline workload; the others are side measurements (no cpu_baseline)")
-    args = ap.parse_args()
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, argv))
 
     import torch
     import torch.distributed as dist
@@ -100,6 +181,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: refusing to report a run "
+                         f"with a different number of ranks than asked")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the xpic HIP path has no CPU fallback")
     # XPIC_BENCH_COMM=gloo: rehearse the N > 1 path on a one-GPU box (all ranks share GPU 0, host-staged exchange)
@@ -114,6 +198,7 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    import numpy as np
     import xpic_amd as X
 
     n = args.grid
@@ -126,11 +211,13 @@ def main():
             GlooRing().attach(ctx)
         else:
             init_rccl(ctx)
+    comm_ranks = ctx.comm_size()  # read back from the communicator itself (ncclCommCount)
+    if comm_ranks != world:
+        raise SystemExit(f"the communicator holds {comm_ranks} ranks, expected {world}")
     N = ctx.N  # local cells
     npart = args.ppc * N
     s = ctx.add_sort(args.ppc, 1.0, -1.0, 1.0, capacity=int(npart * 1.02) + 1024)
-    ctx.fill_synthetic(s, args.ppc, args.vth, seed=1234 + rank)
-    import numpy as np
+    ctx.fill_synthetic(s, args.ppc, args.vth, seed=1234 + rank, regular=args.loader == "regular")
 
     # SetMagneticField(SetUniformField): B = B0 = (0, 0, b0)
     B = np.zeros(ctx.fshape())
@@ -161,12 +248,12 @@ def main():
         its += ctx.step()
     barrier()
     elapsed = time.perf_counter() - t0
+    red_dev = "cpu" if rehearsal else "cuda"
     if world > 1:
-        dev = "cpu" if rehearsal else "cuda"
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        it_t = torch.tensor([its], dtype=torch.float64, device=dev)
+        it_t = torch.tensor([its], dtype=torch.float64, device=red_dev)
         dist.all_reduce(it_t, op=dist.ReduceOp.SUM)
         its_total = float(it_t.item())
     else:
@@ -195,79 +282,140 @@ def main():
     prof = {k: ctx.profile_get(k) for k in ("matA_apply", "solve_matA", "fill_current", "move_bin", "scatter",
                                             "second_push", "mdot", "maxpy", "matL_zero", "scan", "rot_apply",
                                             "halo", "migrate", "matL_ghost_rows", "basic_push", "corr_first_push",
-                                            "corr_second_push", "solve_matM", "precond", "matL_apply")}
-    n_apply, ms_apply = prof["matA_apply"]
-    n_solve, ms_solve = prof["solve_matA"]
-    # algorithmic bytes of one matA apply: 123 fp64 coefficients per row, 3N rows, + read x + write y
-    bytes_apply = (123 * 3 * 8 + 2 * 24) * N  # per GPU: its own slab
-    achieved = bytes_apply / (ms_apply / max(n_apply, 1) * 1e-3) / 1e9 if n_apply else 0.0
-    count = ctx.count(s)
+                                            "corr_second_push", "solve_matM", "precond", "matL_apply", "rebin")}
+    count_local = ctx.count(s)
+    count = count_local
     if world > 1:
-        ct = torch.tensor([count], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        ct = torch.tensor([count], dtype=torch.float64, device=red_dev)
         dist.all_reduce(ct)
         count = int(ct.item())
     assert count == world * npart, "particles were lost in a periodic box"
 
+    headline = {"ecsim": "particles pushed/sec (ECSIM full step) + KSP iters/sec, 256^3 grid 64ppc",
+                "basic": "particles pushed/sec (basic full step: Boris + Esirkepov + FDTD)",
+                "ecsimcorr": "particles pushed/sec (ecsimcorr full step) + KSP iters/sec"}[args.scheme]
+    workload = {
+        "ecsim": f"3D ECSIM electromagnetic, {n}^3 cells, {args.ppc} ppc, 1 electron species, GMRES(30) on matL+matM "
+                 f"rtol=atol=1e-7 (BASELINE.json configs[2])",
+        "basic": f"3D explicit (basic) scheme, {n}^3 cells, {args.ppc} ppc, Boris push + Esirkepov deposit + FDTD, "
+                 f"and CG on matM as the SPD solve (BASELINE.json configs[1]; side measurement)",
+        "ecsimcorr": f"3D ecsimcorr charge-conserving scheme, {n}^3 cells, {args.ppc} ppc, two Esirkepov deposits + two "
+                     f"solves per step (one GPU's share of BASELINE.json configs[4]; side measurement)",
+    }[args.scheme]
+    ms_solve = prof["solve_matA"][1] + prof["solve_matM"][1]
     line = {
-        "metric": "particles pushed/sec (ECSIM full step) + KSP iters/sec, 256^3 grid 64ppc",
+        "metric": headline,
         "value": world * npart * args.steps / elapsed,  # every rank holds npart particles of the one global box
         "unit": "particles/s",
-        "n_gpus": world,
+        "n_gpus": comm_ranks,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "strong",  # the 256^3 box is fixed; N GPUs cut it into N z-slabs (BASELINE.json configs[2] / [3])
+        "scaling": "strong",  # the box is fixed; N GPUs cut it into N z-slabs (BASELINE.json configs[2] / [3])
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": (f"3D ECSIM electromagnetic, {n}^3 cells, {args.ppc} ppc, 1 electron species, "
-                         f"GMRES(30) on matL+matM rtol=atol=1e-7 (BASELINE.json configs[2])") if args.scheme == "ecsim"
-                        else f"scheme {args.scheme}, {n}^3 cells, {args.ppc} ppc (side measurement)",
+            "workload": workload,
             "grid": [n, n, n], "ppc": args.ppc, "particles_per_gpu": npart, "dx": args.dx, "dt": args.dt,
+            "loader": "uniform over the box (Poisson cell occupancy, as CoordinateInBox)" if args.loader == "poisson"
+                      else "exactly ppc particles in every cell",
             "parallelism": "1 GPU" if world == 1 else
-                           f"{world} z-slabs of {n // world} planes, RCCL halo / migration / dot all-reduce over xGMI",
+                           f"{world} z-slabs of {n // world} planes, RCCL halo / migration / dot all-reduce over xGMI"
+                           + (" [gloo rehearsal: all ranks share one GPU]" if rehearsal else ""),
         },
         "ksp_iters_per_s": its_total / world / (ms_solve * 1e-3) if ms_solve else None,  # iterations are global
-        "ksp_method": "GMRES(30), right-preconditioned by a Chebyshev polynomial in matM" if not args.plain_gmres
-                      else "GMRES(30), no preconditioner",
+        "ksp_method": None if args.scheme == "basic" else
+                      ("GMRES(30), right-preconditioned by a Chebyshev polynomial in matM (outer iterations; each = 1 matA "
+                       "apply + the polynomial's matM applies)" if not args.plain_gmres else "GMRES(30), no preconditioner"),
         "ksp_iterations_per_step": its_total / world / args.steps,
         "phase_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},
         "device_copy_GBps": copy_rate / 1e9 if copy_rate else None,
         "cg_matM": cg_line,
-        "roofline": {
+    }
+
+    # ---- rooflines.  `roofline` describes the kernel that takes the largest share of the step.
+    n_fill, ms_fill = prof["fill_current"]  # one entry per colour launch of k_ecsim_fill
+    fill = None
+    if n_fill and args.scheme != "basic":
+        launches_per_step = n_fill / args.steps
+        avg_ms = ms_fill / n_fill
+        # algorithmic flop per launch: SURVEY 8(d)'s ~1200 flop per particle (576 products of the 24 x 24 block the
+        # reference fills, :149-166, + their adds + the per-particle algebra) x the particles one colour launch covers
+        flop_launch = FILL_FLOP_PER_PARTICLE * count_local / launches_per_step
+        tf = flop_launch / (avg_ms * 1e-3) / 1e12
+        bytes_launch = (48.0 + 2952.0 / args.ppc) * count_local / launches_per_step
+        fill = {
+            "kernel": "k_ecsim_fill (mass matrix + currI; one colour launch)", "bound": "mfma",
+            "achieved": tf, "peak": FP64_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TF,
+            "traffic": pmc_traffic(args.scheme, n, "k_ecsim_fill") if world == 1 else None,
+            "flop_per_particle": FILL_FLOP_PER_PARTICLE, "flop_per_launch": flop_launch,
+            "launches": n_fill, "launches_per_step": launches_per_step, "avg_ms": avg_ms,
+            "ms_per_assembly": ms_fill / args.steps,
+            "hbm_view": {"bytes_per_launch": bytes_launch, "achieved_GBps": bytes_launch / (avg_ms * 1e-3) / 1e9,
+                         "frac_of_8TBps": bytes_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+    n_apply, ms_apply = prof["matA_apply"]
+    spmv = None
+    if n_apply:
+        # algorithmic bytes of one matA apply: 123 fp64 coefficients per row, 3N rows, + read x + write y
+        bytes_apply = (123 * 3 * 8 + 2 * 24) * N  # per GPU: its own slab
+        achieved = bytes_apply / (ms_apply / n_apply * 1e-3) / 1e9
+        spmv = {
             "kernel": "k_matA (matL+matM SpMV)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(n) if world == 1 else None,
-            "bytes_per_launch": bytes_apply, "launches": n_apply, "avg_ms": ms_apply / max(n_apply, 1),
-        },
-    }
-    n_fill, ms_fill = prof["fill_current"]
-    if n_fill and args.scheme != "basic":
-        # the assembly is the one dense contraction of the path: per particle a 36 x 36 rank-1 update = 2 * 1296 flop
-        # (issued on the matrix cores as 9 v_mfma_f64_16x16x4_f64 per 4 particles = 4608 flop per particle with the
-        # padding); fp64 matrix peak = fp64 vector peak = 78.6 TFLOP/s on MI355X (measured here: 75.5 with MFMA)
-        tf = 2.0 * 1296 * count / world / (ms_fill / n_fill * 1e-3) / 1e12
-        line["roofline_assembly"] = {
-            "kernel": "k_ecsim_fill (mass matrix + currI, all colour launches of one assembly)", "bound": "mfma",
-            "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6, "traffic": None,
-            "flop_per_particle": 2592, "issued_flop_per_particle": 4608, "avg_ms": ms_fill / n_fill,
+            "traffic": pmc_traffic(args.scheme, n, "k_matA<true, true>") if world == 1 else None,
+            "bytes_per_launch": bytes_apply, "launches": n_apply, "avg_ms": ms_apply / n_apply,
+        }
+    esk = {}
+    for key, kern, bpp, bpc in (("basic_push", "k_esirkepov_push<0>", 96.0, 72.0),
+                                ("corr_first_push", "k_esirkepov_push<1>", 72.0, 24.0),
+                                ("corr_second_push", "k_esirkepov_push<2>", 96.0, 72.0)):
+        nl, ms = prof[key]
+        if not nl:
+            continue
+        # R 48 + W 48 B per particle (first_push of ecsimcorr writes positions only: W 24) + the E/B
+        # read and J write of a cell, once per cell
+        bytes_launch = bpp * count_local + bpc * N
+        gbs = bytes_launch / (ms / nl * 1e-3) / 1e9
+        esk[key] = {
+            "kernel": f"{kern} ({key})", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(args.scheme, n, kern) if world == 1 else None,
+            "bytes_per_launch": bytes_launch, "bytes_per_particle": bpp, "launches": nl, "avg_ms": ms / nl,
+            "particles_per_s": count_local / (ms / nl * 1e-3),
         }
     if args.scheme == "ecsim":
+        line["roofline"] = fill
+        line["roofline_spmv"] = spmv
         # algorithmic HBM bytes per particle and step of the ecsim particle phases: first_push 72 +
         # assembly 48 (+ 2952 B of matL per cell) + second_push 72 + re-binning 96
-        ms_part = sum(prof[k][1] for k in ("fill_current", "second_push", "move_bin", "scatter", "scan")) / args.steps
+        ms_part = sum(prof[k][1] for k in ("fill_current", "second_push", "move_bin", "scatter", "scan", "rebin")) / args.steps
         bpp = 72 + 48 + 72 + 96 + 2952.0 / args.ppc
-        gbs = bpp * count / world / (ms_part * 1e-3) / 1e9
+        gbs = bpp * count_local / (ms_part * 1e-3) / 1e9
         line["roofline_particles"] = {
-            "kernels": "k_ecsim_fill + k_second_push + k_move_bin + k_scatter (all particle phases of a step)",
+            "kernels": "k_ecsim_fill + k_second_push + re-binning (all particle phases of a step)",
             "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
             "bytes_per_particle": bpp, "ms_per_step": ms_part,
-            "particles_per_s": count / world / (ms_part * 1e-3),
+            "particles_per_s": count_local / (ms_part * 1e-3),
         }
+    elif args.scheme == "basic":
+        line["roofline"] = esk.get("basic_push")
+    else:
+        # ecsimcorr: the two Esirkepov passes and the assembly; `roofline` = whichever takes longer per step
+        cands = [r for r in (esk.get("corr_second_push"), esk.get("corr_first_push")) if r]
+        per_step = lambda r: r["avg_ms"] * r["launches"] / args.steps
+        best = max(cands, key=per_step) if cands else None
+        if fill and (best is None or fill["ms_per_assembly"] > per_step(best)):
+            line["roofline"] = fill
+            line["roofline_esirkepov"] = esk
+        else:
+            line["roofline"] = best
+            line["roofline_esirkepov"] = esk
+            line["roofline_assembly"] = fill
+        line["roofline_spmv"] = spmv
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and args.scheme == "ecsim":
+        if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
         else:
             line["cpu_baseline"] = None

@@ -39,6 +39,8 @@ typedef struct xpic_geometry {
   int32_t rank;     /* z-slab index of this context (DMDA da_processors_z) */
   int32_t nranks;   /* number of z-slabs */
   int32_t device;   /* HIP device ordinal */
+  int32_t self_ring; /* nranks == 1 only: keep the ghost planes and run the exchange layer with the slab as its own
+                        lower and upper neighbour (exercises the RCCL transport on one GPU); 0 in production */
 } xpic_geometry;
 
 /* SortParameters (src/interfaces/sort_parameters.h:7-19) */
@@ -83,9 +85,12 @@ int xpic_sort_count(xpic_ctx* ctx, int sort, int64_t* count);
 /* storage read-back in cell order: points6[count][6], cell_of[count] = local cell index g (world.s_g) */
 int xpic_sort_get_particles(xpic_ctx* ctx, int sort, double* points6, int32_t* cell_of);
 int xpic_sort_clear(xpic_ctx* ctx, int sort);
-/* synthetic plasma generated on the device (bench/smoke only; no reference counterpart): ppc particles per
- * cell, uniform in the cell, Maxwellian velocities of thermal spread vth (then v /= sqrt(1+v^2), "tov") */
-int xpic_sort_fill_synthetic(xpic_ctx* ctx, int sort, int ppc, double vth, uint64_t seed);
+/* synthetic plasma generated on the device (bench/smoke only): ppc * (local cells) particles, Maxwellian velocities of
+ * thermal spread vth (then v /= sqrt(1+v^2), "tov").  regular == 0: positions uniform over the slab, i.e. Poisson
+ * occupancy of the cells, the load CoordinateInBox + SetParticles produce (src/utils/particles_load.cpp:11-18,
+ * src/commands/set_particles.cpp:19-43; the device RNG is its own, not mt19937); regular != 0: exactly ppc particles
+ * in every cell.  Collective over the z-slabs like xpic_update_cells. */
+int xpic_sort_fill_synthetic(xpic_ctx* ctx, int sort, int ppc, double vth, uint64_t seed, int regular);
 
 /* Vec access (DMDAVecGetArray / VecGetArray): copies in/out in the [z][y][x][3] layout, local slab */
 int xpic_field_set(xpic_ctx* ctx, int field, const double* v);
@@ -159,6 +164,11 @@ int xpic_step(xpic_ctx* ctx, int* ksp_iterations);
  * out = {wE, wB, sE, sB, wK_0, sK_0, wK_1, sK_1, ...} */
 int xpic_energy(xpic_ctx* ctx, double* out);
 
+/* MomentumConservation::calculate (src/diagnostics/momentum_conservation.cpp:77-131): per sort
+ * out[6 i ..] = {Px, Py, Pz, QEx, QEy, QEz}, P = sum (m/Np) v ns and QE = sum (q/Np) E Es over the particle's
+ * 2nd-order shape nodes */
+int xpic_momentum(xpic_ctx* ctx, double* out);
+
 /* ParticlesChargeDensity::collect of one sort (src/diagnostics/charge_conservation.cpp:67-97) -> rho[z][y][x] */
 int xpic_charge_density(xpic_ctx* ctx, int sort, double* rho_zyx);
 /* DistributionMoment::collect with moment "density" (src/diagnostics/distribution_moment.cpp:125-216): cell-centred
@@ -203,6 +213,9 @@ typedef struct xpic_comm_callbacks {
   int (*allreduce_sum)(void* user, double* buf, int n);
 } xpic_comm_callbacks;
 int xpic_comm_init_callbacks(xpic_ctx* ctx, const xpic_comm_callbacks* cb);
+/* number of ranks of the attached communicator: ncclCommCount for RCCL, the z-slab count for callbacks, 1 without one
+ * (MPI_Comm_size on PETSC_COMM_WORLD, src/utils/world.cpp:40-42) */
+int xpic_comm_size(xpic_ctx* ctx, int* nranks);
 
 /* ---- measurement: HIP-event timers around kernel families, on the context's own stream */
 int xpic_profile_enable(xpic_ctx* ctx, int on);

@@ -581,6 +581,8 @@ struct orc_sim {
   double rtol = 1e-7, atol = 1e-7; /* src/impls/ecsim/simulation.h:15-18 */
   int maxit = 100;
   int last_its[2] = {0, 0};
+  double solve_seconds = 0; /* wall time spent inside the Krylov solves of orc_step (bench.py's cpu_baseline) */
+  long solve_its = 0;
 };
 
 namespace {
@@ -965,9 +967,12 @@ int advance_fields(orc_sim* s, int op, const std::vector<double>& curr, std::vec
   rot_apply(s->gr, -1, +s->dt, Bm.data(), rhs.data(), true);             /* MatMultAdd(rotB) :264, rotB = +dt rot(-) :554 */
   double rn;
   int its;
+  const double t0 = omp_get_wtime();
   if (op == 0) its = gmres(s, matA_apply, rhs.data(), out.data(), s->rtol, s->atol, s->maxit, &rn);
   else if (op == 1) its = gmres(s, matM_apply, rhs.data(), out.data(), s->rtol, s->atol, s->maxit, &rn);
   else its = cg(s, matM_apply, rhs.data(), out.data(), s->rtol, s->atol, s->maxit, &rn);
+  s->solve_seconds += omp_get_wtime() - t0;
+  if (its > 0) s->solve_its += its;
   s->last_its[slot] = its;
   return its;
 }
@@ -1765,6 +1770,13 @@ int orc_solve(orc_sim* s, int op, const double* rhs, double* x, double rtol, dou
   return cg(s, matM_apply, rhs, x, rtol, atol, maxit, rn);
 }
 
+void orc_solve_stats(orc_sim* s, double* seconds, long* iterations, int reset)
+{
+  *seconds = s->solve_seconds;
+  *iterations = s->solve_its;
+  if (reset) { s->solve_seconds = 0; s->solve_its = 0; }
+}
+
 int orc_step(orc_sim* s)
 {
   switch (s->scheme) {
@@ -1872,6 +1884,44 @@ void orc_moment_density(orc_sim* s, int isort, double* out)
   std::vector<double> f;
   density_collect(s, s->sorts[isort], f);
   std::copy(f.begin(), f.end(), out);
+}
+
+/* MomentumConservation::calculate (src/diagnostics/momentum_conservation.cpp:77-131): per sort
+ * P = sum_p sum_nodes (m/Np) v ns,  QE = sum_p sum_nodes (q/Np) E[node] Es   with Shape::setup(point.r) */
+void orc_momentum(orc_sim* s, double* out)
+{
+  const Grid& gr = s->gr;
+  std::vector<double> El;
+  global_to_local(gr, s->E, El, 3);
+  for (size_t is = 0; is < s->sorts.size(); ++is) {
+    Sort& sort = s->sorts[is];
+    const double Np = (double)sort.Np;
+    const double m = sort.m / Np, q = sort.q / Np;
+    double px = 0, py = 0, pz = 0, qex = 0, qey = 0, qez = 0;
+    const long ncell = (long)sort.storage.size();
+#pragma omp parallel for reduction(+ : px, py, pz, qex, qey, qez)
+    for (long g = 0; g < ncell; ++g)
+      for (auto& point : sort.storage[g]) {
+        Shape shape;
+        shape.setup(gr.d, point.r, 1.5, spline2);
+        for (int i = 0; i < shape.elements(); ++i) {
+          int gx = shape.start[X] + i % shape.size[X];
+          int gy = shape.start[Y] + (i / shape.size[X]) % shape.size[Y];
+          int gz = shape.start[Z] + (i / shape.size[X]) / shape.size[Y];
+          double ns = shape(i, No, Z) * shape(i, No, Y) * shape(i, No, X);
+          V3 Es = shape.electric(i);
+          long l = gr.vl(gx, gy, gz, 0);
+          px += m * point.p[X] * ns;
+          py += m * point.p[Y] * ns;
+          pz += m * point.p[Z] * ns;
+          qex += q * El[l + X] * Es[X];
+          qey += q * El[l + Y] * Es[Y];
+          qez += q * El[l + Z] * Es[Z];
+        }
+      }
+    double* o = out + 6 * is;
+    o[0] = px; o[1] = py; o[2] = pz; o[3] = qex; o[4] = qey; o[5] = qez;
+  }
 }
 
 void orc_charge_collect(orc_sim* s) /* ChargeConservation::initialize :117-123 */

@@ -134,6 +134,9 @@ void orc_ecsimcorr_scalars(orc_sim*, int sort, double* out6);
 int orc_solve(orc_sim*, int op, const double* rhs, double* x, double rtol, double atol, int maxit,
   double* final_rnorm);
 void orc_set_tolerances(orc_sim*, double rtol, double atol, int maxit);
+/* wall time and iterations spent inside the Krylov solves of orc_step since the last reset (timing aid of bench.py's
+ * cpu_baseline leg; no reference counterpart) */
+void orc_solve_stats(orc_sim*, double* seconds, long* iterations, int reset);
 
 /* timestep_implementation of the scheme (basic/simulation.cpp:30-43, ecsim/simulation.cpp:145-155,
  * ecsimcorr/simulation.cpp:21-32).  Returns KSP iterations of the step (sum), <0 on failure. */
@@ -149,6 +152,9 @@ void orc_charge_collect(orc_sim*);
 void orc_charge_columns(orc_sim*, double* out);
 /* ParticlesChargeDensity::collect of one sort into rho[z][y][x] */
 void orc_charge_density(orc_sim*, int sort, double* rho);
+/* MomentumConservation::calculate (src/diagnostics/momentum_conservation.cpp:77-131):
+ * out = {Px, Py, Pz, QEx, QEy, QEz} per sort */
+void orc_momentum(orc_sim*, double* out);
 /* eccapfim inner kernels.  cell_traversal (src/impls/eccapfim/cell_traversal.cpp:3-77): returns the
  * number of points (start, face crossings, end), the first max_pts of them in pts[3*i..]. */
 int orc_cell_traversal(const double* d3, const double* end3, const double* start3, int max_pts, double* pts);

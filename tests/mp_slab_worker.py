@@ -1,6 +1,8 @@
 """Worker of tests/test_gpu_slabs.py: `nranks` processes share ONE GPU, each owns a z-slab, the exchange goes
 through gloo (xpic_comm_init_callbacks).  Every rank runs the same seeded problem; rank 0 also runs it on a
-single-slab context and checks that the decomposed run reproduces it."""
+single-slab context AND on the CPU oracle (whole box) and checks that the decomposed run reproduces both: fields,
+particle totals and the per-cell occupancy of the whole box (update_cells_mpi, src/interfaces/particles.cpp:118-248).
+usage: mp_slab_worker.py <scheme> [planes per slab]"""
 import os
 import sys
 
@@ -13,28 +15,56 @@ import xpic_amd as X  # noqa: E402
 from xpic_amd.parallel import GlooRing  # noqa: E402
 
 
-def build(scheme, n, d, dt, rank, nranks, seed):
+SORTS = [(8, 1.0, -1.0, 1.0), (8, 1.0, 1.0, 16.0)]
+
+
+def problem(scheme, n, d, seed):
+    """The seeded inputs: particles per sort and the E, B, B0 arrays of the whole box."""
     rng = np.random.default_rng(seed)
     vth = 0.25 if scheme == "ecsim" else 0.1  # Esirkepov moves must stay below one cell (dz = 0.25, dt = 0.2)
-    ctx = X.Context(scheme, n, d, dt, device=0, rank=rank, nranks=nranks)
     N = n[0] * n[1] * n[2]
-    sorts = [(8, 1.0, -1.0, 1.0), (8, 1.0, 1.0, 16.0)]
     L = np.array(n) * np.array(d)
-    for (Np, dens, q, m) in sorts:
-        s = ctx.add_sort(Np, dens, q, m, capacity=3 * 8 * N)
+    parts = []
+    for _ in SORTS:
         pts = np.empty((8 * N, 6))
         pts[:, :3] = rng.random((8 * N, 3)) * L
         pts[:, 3:] = rng.normal(0, vth, (8 * N, 3))
-        ctx.add_particles(s, pts)  # add_particle keeps what lies in the local slab
+        parts.append(pts)
     shape = (n[2], n[1], n[0], 3)
     E = rng.normal(0, 0.02, shape)
     B = rng.normal(0, 0.02, shape) + np.array([0.0, 0.1, 0.3])
     B0 = np.zeros(shape) + np.array([0.0, 0.1, 0.3])
+    return parts, E, B, B0
+
+
+def build(scheme, n, d, dt, rank, nranks, seed):
+    parts, E, B, B0 = problem(scheme, n, d, seed)
+    ctx = X.Context(scheme, n, d, dt, device=0, rank=rank, nranks=nranks)
+    N = n[0] * n[1] * n[2]
+    for (Np, dens, q, m), pts in zip(SORTS, parts):
+        s = ctx.add_sort(Np, dens, q, m, capacity=3 * 8 * N)
+        ctx.add_particles(s, pts)  # add_particle keeps what lies in the local slab
     z0, nzl = ctx.z0, ctx.nzl
     for fid, F in ((X.E, E), (X.B, B), (X.B0, B0)):
         ctx.set_field(fid, F[z0:z0 + nzl])
     ctx.set_tolerances(1e-12, 1e-50, 400)
     return ctx
+
+
+def build_oracle(scheme, n, d, dt, seed):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+
+    oracle_lib.build()
+    parts, E, B, B0 = problem(scheme, n, d, seed)
+    o = oracle_lib.OracleSim(scheme, n, d, dt)
+    for (Np, dens, q, m), pts in zip(SORTS, parts):
+        so = o.add_sort(Np, dens, q, m)
+        assert o.add_particles(so, pts) == pts.shape[0]
+    for name, F in (("E", E), ("B", B), ("B0", B0)):
+        o.set_field(name, F)
+    o.set_tolerances(1e-12, 1e-50, 400)
+    return o
 
 
 def gather_field(ctx, fid, nranks):
@@ -46,9 +76,10 @@ def gather_field(ctx, fid, nranks):
 
 def main():
     scheme = sys.argv[1]
+    nzl = int(sys.argv[2]) if len(sys.argv) > 2 else 12
     dist.init_process_group("gloo")
     rank, nranks = dist.get_rank(), dist.get_world_size()
-    n, d = (12, 10, 12 * nranks), (0.5, 0.4, 0.25)
+    n, d = (12, 10, nzl * nranks), (0.5, 0.4, 0.25)
     dt = 0.2 if scheme != "ecsim" else 0.8
     ctx = build(scheme, n, d, dt, rank, nranks, seed=42)
     GlooRing().attach(ctx)
@@ -60,6 +91,11 @@ def main():
     counts = [ctx.count(s) for s in range(2)]
     allc = [None] * nranks
     dist.all_gather_object(allc, (counts0, counts))
+    # per-cell occupancy of the whole box: local cell + the cells below this slab
+    occ = [np.bincount(ctx.particles(s)[1].astype(np.int64) + ctx.z0 * n[0] * n[1], minlength=n[0] * n[1] * n[2])
+           for s in range(2)]
+    allocc = [None] * nranks
+    dist.all_gather_object(allocc, occ)
     ok = True
     if rank == 0:
         ref = build(scheme, n, d, dt, 0, 1, seed=42)
@@ -79,6 +115,23 @@ def main():
         ok &= np.allclose(en, ren, rtol=1e-9, atol=1e-15)
         if scheme != "basic":
             ok &= all(abs(a - b) <= 2 for a, b in zip(its, rits))
+        # ---- the same problem on the CPU oracle, whole box
+        o = build_oracle(scheme, n, d, dt, seed=42)
+        for _ in range(nsteps):
+            assert o.step() >= 0
+        for name in ("E", "B"):
+            a = o.get_field(name)
+            err = np.abs(a - fields[name]).max() / np.abs(a).max()
+            print(name, "rel err vs oracle", err, flush=True)
+            ok &= err < 1e-8
+        for s in range(2):
+            ok &= o.count(s) == tot1[s]
+            oo = np.bincount(o.particles(s)[1].astype(np.int64), minlength=n[0] * n[1] * n[2])
+            mine = sum(r[s] for r in allocc)
+            same = np.array_equal(oo, mine)
+            print("sort", s, "per-cell occupancy equals the oracle's:", same, flush=True)
+            ok &= same
+        ok &= np.allclose(en, o.energy(), rtol=1e-9, atol=1e-15)
     flag = [ok]
     dist.broadcast_object_list(flag, src=0)
     ctx.close()

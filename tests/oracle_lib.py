@@ -92,10 +92,12 @@ def lib():
     L.orc_solve.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, C.c_double, C.c_double, C.c_int, c_dp]
     L.orc_set_tolerances.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
     L.orc_step.argtypes = [C.c_void_p]
+    L.orc_solve_stats.argtypes = [C.c_void_p, c_dp, C.POINTER(C.c_long), C.c_int]
     L.orc_energy.argtypes = [C.c_void_p, c_dp]
     L.orc_charge_collect.argtypes = [C.c_void_p]
     L.orc_charge_columns.argtypes = [C.c_void_p, c_dp]
     L.orc_charge_density.argtypes = [C.c_void_p, C.c_int, c_dp]
+    L.orc_momentum.argtypes = [C.c_void_p, c_dp]
     L.orc_moment_density.argtypes = [C.c_void_p, C.c_int, c_dp]
     L.orc_cell_traversal.argtypes = [c_dp, c_dp, c_dp, C.c_int, c_dp]
     L.orc_cell_traversal.restype = C.c_int
@@ -212,6 +214,12 @@ class OracleSim:
     def step(self):
         return self.L.orc_step(self.h)
 
+    def solve_stats(self, reset=False):
+        """(seconds, iterations) spent inside the Krylov solves of step() since the last reset."""
+        sec, its = np.zeros(1), C.c_long()
+        self.L.orc_solve_stats(self.h, _dp(sec), C.byref(its), int(reset))
+        return float(sec[0]), int(its.value)
+
     def energy(self):
         out = np.zeros(4 + 2 * self.nsorts)
         self.L.orc_energy(self.h, _dp(out))
@@ -223,6 +231,12 @@ class OracleSim:
     def charge_columns(self):
         out = np.zeros(2 * self.nsorts + 2)
         self.L.orc_charge_columns(self.h, _dp(out))
+        return out
+
+    def momentum(self):
+        """MomentumConservation::calculate: rows {Px, Py, Pz, QEx, QEy, QEz}, one per sort."""
+        out = np.zeros((self.nsorts, 6))
+        self.L.orc_momentum(self.h, _dp(out))
         return out
 
     def cell_traversal(self, end, start, max_pts=8):

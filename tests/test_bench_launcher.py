@@ -1,0 +1,84 @@
+"""bench.py's N > 1 entry: `--gpus N` must start N ranks (or fail loudly), never quietly run one.
+The reference's analogue is `mpiexec -np 2 ... -da_processors_x 2` (tests/ecsim/CMakeLists.txt:15-17)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", **kw)
+    return env
+
+
+def test_gpus_2_without_devices_fails_cleanly():
+    """No GPU in this container: the launcher must refuse (non-zero, message, no JSON line), not fall back to one rank."""
+    import torch
+
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is present")
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--grid", "32", "--ppc", "8", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline"], env=_env(XPIC_BENCH_COMM="gloo"), capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert "needs 1 MI355X device" in out.stderr and "will not run fewer ranks" in out.stderr
+    assert "n_gpus" not in out.stdout
+
+
+def test_world_size_mismatch_is_refused():
+    """Started as ONE rank by a launcher but asked for --gpus 2: refuse instead of reporting n_gpus = 1."""
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--grid", "32", "--ppc", "8", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline"], env=_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)
+    assert "n_gpus" not in out.stdout
+
+
+def test_launcher_does_not_touch_the_gpu_or_exec():
+    """The parent of the N ranks only counts devices: no torch.cuda.is_available / set_device / os.exec* in launch_ranks."""
+    import inspect
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    src = inspect.getsource(bench.launch_ranks)
+    assert "is_available" not in src and "set_device" not in src and "os.exec" not in src and "Context(" not in src
+    assert "device_count" in src and "Popen" in src
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_reports_two_ranks():
+    """`bench.py --gpus 2` on the one-GPU box: two child ranks share GPU 0, exchange over gloo (XPIC_BENCH_COMM=gloo),
+    the line says n_gpus = 2 (read back from the communicator) and no particle is lost."""
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--grid", "32", "--ppc", "8", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], env=_env(XPIC_BENCH_COMM="gloo"), capture_output=True, text=True, timeout=500)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "strong"
+    assert line["config"]["particles_per_gpu"] == 8 * 32 * 32 * 16
+    assert line["value"] > 0 and line["ksp_iterations_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_single_rank_line_has_the_contract_fields():
+    out = subprocess.run([sys.executable, BENCH, "--grid", "32", "--ppc", "16", "--steps", "2", "--warmup", "1",
+                          "--cpu-grid", "16", "--cpu-steps", "1"], env=_env(), capture_output=True, text=True, timeout=500)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["dtype"] == "f64" and line["vs_baseline"] is None
+    r = line["roofline"]
+    assert r["kernel"].startswith("k_ecsim_fill") and r["bound"] == "mfma" and r["flop_per_particle"] == 1200.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert line["roofline_spmv"]["bound"] == "hbm"
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["ksp_iters_per_s_at_sample_grid"] > 0

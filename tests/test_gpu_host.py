@@ -20,28 +20,40 @@ def read_table(path):
     return header, np.array(rows)
 
 
-@pytest.mark.parametrize("name,exact_rows,steps", [("basic_ex1", 100, 100), ("ecsim_ex1", 1, 12), ("ecsimcorr_ex1", 1, 6)])
-def test_host_executable_reproduces_reference_tables(tmp_path, name, exact_rows, steps):
+# bounds of tests/test_oracle_golden.py (what the reference's own KSP stop and the noise amplification allow; see there)
+EARLY = dict(wE=5e-4, wB=5e-4, wK=1e-6)     # rows 2..10
+LATE = dict(wE=6e-2, wB=2.5e-2, wK=2e-4)    # rows 11..100
+DUMPS = {50: dict(E=0.10, B=0.08, density=0.012), 100: dict(E=0.40, B=0.40, density=0.045)}
+
+
+@pytest.mark.parametrize("name,exact_rows", [("basic_ex1", 100), ("ecsim_ex1", 1), ("ecsimcorr_ex1", 1)])
+def test_host_executable_reproduces_reference_tables(tmp_path, name, exact_rows):
+    """All 100 steps of the reference's three integration tests through xpic_hip.out, every golden table and dump."""
     import json
 
+    steps = 100
     cfg = json.load(open(os.path.join(GOLD, name, "config.json")))
     # FieldView (E, B) and DistributionMoment (density) stay on: float32 dumps every 50 steps
-    cfg["Geometry"]["t"] = steps * cfg["Geometry"]["dt"]
     cfg["OutputDirectory"] = str(tmp_path)
     cpath = tmp_path / "config.json"
     cpath.write_text(json.dumps(cfg))
-    out = subprocess.run([EXE, str(cpath)], capture_output=True, text=True, timeout=500)
+    out = subprocess.run([EXE, str(cpath)], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     for table in ("energy.txt", "energy_conservation.txt"):
         gh, gold = read_table(os.path.join(GOLD, name, table))
         mh, mine = read_table(os.path.join(tmp_path, "temporal", table))
         assert mh == gh  # same columns, same titles
-        assert mine.shape[0] == steps + 1
-        gold = gold[: steps + 1]
+        assert mine.shape == gold.shape and mine.shape[0] == steps + 1
         n = exact_rows + 1
         if table == "energy.txt":
             assert np.abs(mine[:n] - gold[:n]).max() < 1e-10  # PETSC_SMALL, as compare_temporal
-            assert np.allclose(mine[n:], gold[n:], rtol=1e-3, atol=1e-12)
+            col = {h: i for i, h in enumerate(gh)}
+            for t in range(n, steps + 1):
+                tol = EARLY if t <= 10 else LATE
+                for h, key in (("wE", "wE"), ("wB", "wB"), ("wK_electrons", "wK"), ("sE", "wE"), ("sB", "wB"),
+                               ("sK_electrons", "wK")):
+                    a, b = mine[t, col[h]], gold[t, col[h]]
+                    assert abs(a - b) <= (tol[key] if h[0] == "w" else tol["wE"]) * abs(b), (t, h, a, b)
         else:
             # differences of 7-digit energies: the leading columns to 1e-10 on the exact rows; the
             # round-off columns (dE+dB+dK, PWD, LdK, WD ~ 1e-13 .. 1e-16) only in magnitude
@@ -59,19 +71,69 @@ def test_host_executable_reproduces_reference_tables(tmp_path, name, exact_rows,
         assert mh == gh and mine.shape == (steps + 1, gold.shape[1])
         # round-off of differently ordered sums: same magnitude as the reference's columns, not the same digits
         assert (mine[:, 1:].max(axis=0) < 8 * gold[:, 1:].max(axis=0)).all()
+    # MomentumConservation is always on (simulation.cpp:55-56); the reference holds its table for basic_ex1
+    mh, mine = read_table(os.path.join(tmp_path, "temporal", "momentum_conservation.txt"))
+    assert mine.shape == (steps + 1, 10)
+    if name == "basic_ex1":
+        gh, gold = read_table(os.path.join(GOLD, name, "momentum_conservation.txt"))
+        assert mh == gh
+        assert np.abs(mine[:, 1:7] - gold[:, 1:7]).max() < 1e-10   # P, QE: every printed digit
+        assert np.abs(mine[:, [7, 9]] - gold[:, [7, 9]]).max() < 3e-9  # defect: (p1 - p0) / dt cancels 3-4 digits
+        assert np.abs(mine[2:, 8] - gold[2:, 8]).max() <= 2e-6 * np.abs(gold[2:, 8]).max() and mine[1, 8] < 1e-10
+        with open(os.path.join(GOLD, name, "momentum_conservation.txt")) as g, \
+                open(os.path.join(tmp_path, "temporal", "momentum_conservation.txt")) as m:
+            assert [g.readline(), g.readline()] == [m.readline(), m.readline()]
     # float32 dumps <out>/E/<t>, <out>/B/<t>, <out>/electrons/density/<t> (FieldView / DistributionMoment)
     for t in range(0, steps + 1, 50):
         for sub, gname in (("E", "E"), ("B", "B"), ("electrons/density", "density")):
-            gold = np.fromfile(os.path.join(GOLD, name, f"{gname}_{t:03d}.f32"), dtype=np.float32)
-            mine = np.fromfile(os.path.join(tmp_path, sub, f"{t:0{len(str(steps))}d}"), dtype=np.float32)  # format_time
+            gold = np.fromfile(os.path.join(GOLD, name, f"{gname}_{t:03d}.f32"), dtype=np.float32).astype(np.float64)
+            mine = np.fromfile(os.path.join(tmp_path, sub, f"{t:0{len(str(steps))}d}"), dtype=np.float32).astype(np.float64)
             assert mine.shape == gold.shape, (sub, t)
             if t == 0:
                 assert np.array_equal(mine, gold), (sub, t)  # initial state: bit-equal in float32
-            else:
+            elif name == "basic_ex1":
                 assert np.abs(mine - gold).max() <= 2e-6 * np.abs(gold).max(), (sub, t)
+            elif gname == "density":
+                assert np.abs(mine - gold).max() <= DUMPS[t]["density"] * np.abs(gold).max(), (sub, t)
+            else:
+                sign = -1.0 if gname == "B" else 1.0  # the golden B dumps of these two tests: see test_oracle_golden.py
+                assert np.linalg.norm(mine - sign * gold) <= DUMPS[t][gname] * np.linalg.norm(gold), (sub, t)
     # the text format itself: first two lines byte-identical to the reference's file
     with open(os.path.join(GOLD, name, "energy.txt")) as g, open(os.path.join(tmp_path, "temporal", "energy.txt")) as m:
         assert [g.readline(), g.readline()] == [m.readline(), m.readline()]
+
+
+@pytest.mark.parametrize("scheme", ["ecsim", "ecsimcorr"])
+def test_hundred_steps_track_the_oracle_at_tight_tolerance(scheme):
+    """The long-run parity check that does not depend on anybody's KSP stop: the reference's ecsim_ex1 / ecsimcorr_ex1
+    set-up (RNG-exact load, taken from the oracle's loader), 100 steps on the HIP path and on the CPU oracle, both
+    solving to rtol = 1e-13.  Round-off differences are amplified ~2e3 x over the run (see test_oracle_golden.py): the
+    energies must agree to 1e-8, the fields to 1e-6 of their norm, particle counts exactly."""
+    import oracle_lib
+    import xpic_amd as X
+
+    oracle_lib.build()
+    oracle_lib.lib().orc_reset_rng()
+    n, d, dt = (10, 10, 10), (0.5, 0.5, 0.5), 1.5
+    o = oracle_lib.OracleSim(scheme, n, d, dt)
+    so = o.add_sort(100, 1.0, -1.0, 1.0, (0.1, 0.1, 0.1))
+    o.load_maxwell_box(so, True)
+    pts, _ = o.particles(so)
+    g = X.Context(scheme, n, d, dt)
+    sg = g.add_sort(100, 1.0, -1.0, 1.0, capacity=2 * len(pts))
+    assert g.add_particles(sg, pts) == len(pts) == 100000
+    for sim in (o, g):
+        sim.set_tolerances(1e-13, 1e-50, 400)
+    for t in range(1, 101):
+        assert o.step() > 0 and g.step() > 0
+        if t % 10 == 0 or t < 3:
+            eo, eg = o.energy(), g.energy()
+            assert np.allclose(eo, eg, rtol=1e-8, atol=1e-16), (t, eo, eg)
+    for name, fid in (("E", X.E), ("B", X.B)):
+        a, b = o.get_field(name), g.get_field(fid)
+        assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(a), name
+    assert o.count(so) == g.count(sg)
+    g.close()
 
 
 def test_host_rejects_unknown_simulation(tmp_path):

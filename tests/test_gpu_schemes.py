@@ -224,3 +224,19 @@ def test_reference_golden_ecsimcorr_ex1(oracle):
             assert np.allclose(row(en), gold[t, 1:], rtol=1e-3)
         assert abs(sc["pred_dK"] - 1.5 * sc["pred_w"]) < 1e-14  # PWD column
         assert abs(sc["corr_dK"] - 1.5 * sc["corr_w"]) < 1e-14  # LdK column
+
+
+@pytest.mark.parametrize("scheme", ["basic", "ecsimcorr"])
+def test_momentum_conservation_sums_on_device(oracle, scheme):
+    """xpic_momentum (MomentumConservation::calculate, src/diagnostics/momentum_conservation.cpp:77-131): P and QE of
+    every sort equal the oracle's sums (2nd-order Shape at the particle position, E with a random part) to 1e-12 of
+    the largest entry, before and after two steps."""
+    n, d, dt = GRID
+    o, g = make_pair(oracle, scheme, n, d, dt, [(6, 1.0, -1.0, 1.0), (3, 1.0, 1.0, 50.0)], B0=(0.0, 0.1, 0.5), vth=0.1)
+    for t in range(3):
+        a, b = o.momentum(), g.momentum()
+        assert a.shape == b.shape == (2, 6) and np.abs(a[:, 3:]).max() > 0
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max(), t
+        if t < 2:
+            assert o.step() >= 0
+            g.step()

@@ -1,6 +1,7 @@
 """z-slab decomposition on the GPU: 2 (and 3) processes share the one GPU of the box, exchange through gloo
-(xpic_comm_init_callbacks), and must reproduce the single-slab run of the same seeded problem: particle totals
-exactly, fields to 1e-8 (the Krylov dot products are summed in a different order)."""
+(xpic_comm_init_callbacks), and must reproduce the single-slab run of the same seeded problem AND the CPU oracle's
+whole-box run: particle totals and per-cell occupancy exactly, fields to 1e-8 (the Krylov dot products are summed in
+a different order)."""
 import os
 import subprocess
 import sys
@@ -11,11 +12,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("scheme,world", [("ecsim", 2), ("ecsim", 3), ("basic", 2), ("ecsimcorr", 2)])
-def test_slabs_reproduce_single_slab(scheme, world):
+# nzl = 32 and 64 planes per slab are the slab thicknesses of BASELINE configs[3] (256^3 on 8 GPUs) and configs[4]
+# (512^3 on 8 GPUs)
+@pytest.mark.parametrize("scheme,world,nzl", [("ecsim", 2, 12), ("ecsim", 3, 12), ("basic", 2, 12), ("ecsimcorr", 2, 12),
+                                              ("ecsimcorr", 2, 32), ("ecsimcorr", 2, 64), ("ecsim", 2, 32)])
+def test_slabs_reproduce_single_slab_and_oracle(scheme, world, nzl):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
-           "127.0.0.1", "--master-port", str(29700 + world), os.path.join(ROOT, "tests", "mp_slab_worker.py"), scheme]
+           "127.0.0.1", "--master-port", str(29700 + world), os.path.join(ROOT, "tests", "mp_slab_worker.py"), scheme,
+           str(nzl)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
     assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-4000:]
     assert out.stdout.count(" ok") == world
@@ -23,7 +28,7 @@ def test_slabs_reproduce_single_slab(scheme, world):
 
 def test_rccl_transport_on_a_self_ring():
     """The RCCL backend itself (ncclSend/ncclRecv ring, ncclAllReduce on the context's stream) on the one GPU we
-    have: a single slab that keeps its ghost planes and is its own lower and upper neighbour (XPIC_FORCE_HALO=1)
+    have: a single slab that keeps its ghost planes and is its own lower and upper neighbour (geometry.self_ring)
     must reproduce the ghost-free single-slab run."""
     code = r'''
 import os, sys
@@ -32,11 +37,9 @@ sys.path.insert(0, %r)
 import xpic_amd as X
 
 def build(force):
-    if force: os.environ["XPIC_FORCE_HALO"] = "1"
-    else: os.environ.pop("XPIC_FORCE_HALO", None)
     rng = np.random.default_rng(3)
     n, d = (12, 10, 8), (0.5, 0.4, 0.25)
-    ctx = X.Context("ecsimcorr", n, d, 0.2)
+    ctx = X.Context("ecsimcorr", n, d, 0.2, self_ring=force)
     if force: ctx.comm_init_rccl(X.rccl_unique_id())
     N = n[0] * n[1] * n[2]
     s = ctx.add_sort(8, 1.0, -1.0, 1.0, capacity=4 * 8 * N)
@@ -65,3 +68,31 @@ print("self-ring ok")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=400)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "self-ring ok" in out.stdout
+
+
+def test_migration_overflow_fails_on_every_rank():
+    """Error state is collective: rank 0 overflows its migration send buffer, rank 1 has nothing wrong locally.  Both
+    must return the error (no rank left waiting in ncclRecv / the ring exchange of the next phase)."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_overflow_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=300)[0])  # a hang would end here
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert [p.returncode for p in procs] == [7, 7], outs
+    for r, o in enumerate(outs):
+        assert f"rank {r} error" in o and "migration buffer overflow" in o, o
+    assert "of the z-slabs" in outs[1]

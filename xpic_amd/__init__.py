@@ -28,8 +28,8 @@ SYMBOLS = [
     "xpic_update_cells", "xpic_ecsim_fill_current", "xpic_ecsim_second_push", "xpic_basic_push",
     "xpic_ecsimcorr_first_push", "xpic_ecsimcorr_second_push", "xpic_ecsimcorr_final_update",
     "xpic_calculate_energy", "xpic_ecsimcorr_scalars", "xpic_solve", "xpic_set_tolerances", "xpic_set_preconditioner", "xpic_step",
-    "xpic_energy", "xpic_charge_density", "xpic_moment_density", "xpic_cell_traversal", "xpic_implicit_esirkepov_interpolate",
-    "xpic_implicit_esirkepov_decompose", "xpic_charge_collect", "xpic_charge_columns", "xpic_comm_rccl_unique_id", "xpic_comm_init_rccl", "xpic_comm_init_callbacks",
+    "xpic_energy", "xpic_momentum", "xpic_charge_density", "xpic_moment_density", "xpic_cell_traversal", "xpic_implicit_esirkepov_interpolate",
+    "xpic_implicit_esirkepov_decompose", "xpic_charge_collect", "xpic_charge_columns", "xpic_comm_rccl_unique_id", "xpic_comm_init_rccl", "xpic_comm_init_callbacks", "xpic_comm_size",
     "xpic_profile_enable", "xpic_profile_reset", "xpic_profile_get", "xpic_probe_copy_bandwidth",
 ]
 
@@ -40,7 +40,7 @@ class XpicError(RuntimeError):
 
 class Geometry(C.Structure):
     _fields_ = [("n", C.c_int32 * 3), ("d", C.c_double * 3), ("dt", C.c_double), ("periodic", C.c_int32 * 3),
-                ("rank", C.c_int32), ("nranks", C.c_int32), ("device", C.c_int32)]
+                ("rank", C.c_int32), ("nranks", C.c_int32), ("device", C.c_int32), ("self_ring", C.c_int32)]
 
 
 class SortParams(C.Structure):
@@ -73,14 +73,14 @@ def _dp(a):
 class Context:
     """One z-slab context = one `interfaces::Simulation` backend instance."""
 
-    def __init__(self, scheme, n, d, dt, device=0, rank=0, nranks=1):
+    def __init__(self, scheme, n, d, dt, device=0, rank=0, nranks=1, self_ring=False):
         self.L = load_library()
         g = Geometry()
         g.n[:] = [int(v) for v in n]
         g.d[:] = [float(v) for v in d]
         g.dt = float(dt)
         g.periodic[:] = [1, 1, 1]
-        g.rank, g.nranks, g.device = rank, nranks, device
+        g.rank, g.nranks, g.device, g.self_ring = rank, nranks, device, int(self_ring)
         self.n = tuple(int(v) for v in n)
         self.d = tuple(float(v) for v in d)
         self.dt = float(dt)
@@ -133,6 +133,11 @@ class Context:
         self._cb = CB(None, SR(_sr), AR(_ar))
         self._ck(self.L.xpic_comm_init_callbacks(self.h, C.byref(self._cb)))
 
+    def comm_size(self):
+        n = C.c_int()
+        self._ck(self.L.xpic_comm_size(self.h, C.byref(n)))
+        return n.value
+
     def _ck(self, rc):
         if rc != 0:
             raise XpicError(f"xpic error {rc}: {self.L.xpic_last_error().decode()}")
@@ -177,8 +182,8 @@ class Context:
     def clear(self, sort):
         self._ck(self.L.xpic_sort_clear(self.h, sort))
 
-    def fill_synthetic(self, sort, ppc, vth, seed=1):
-        self._ck(self.L.xpic_sort_fill_synthetic(self.h, sort, int(ppc), C.c_double(vth), C.c_uint64(seed)))
+    def fill_synthetic(self, sort, ppc, vth, seed=1, regular=False):
+        self._ck(self.L.xpic_sort_fill_synthetic(self.h, sort, int(ppc), C.c_double(vth), C.c_uint64(seed), int(regular)))
 
     # ---- fields
     def fshape(self):
@@ -292,6 +297,11 @@ class Context:
     def energy(self):
         out = np.zeros(4 + 2 * self.nsorts)
         self._ck(self.L.xpic_energy(self.h, _dp(out)))
+        return out
+
+    def momentum(self):
+        out = np.zeros((self.nsorts, 6))
+        self._ck(self.L.xpic_momentum(self.h, _dp(out)))
         return out
 
     def charge_density(self, sort):

@@ -260,10 +260,10 @@ int xpic_create(const xpic_geometry* geom, int scheme, xpic_ctx** out)
   g.nzl = g.nzg / geom->nranks;
   g.z0 = geom->rank * g.nzl;
   // ceil(shape_radius) + 1 ghost planes (c-2 .. c+3 of the 2nd-order shape pair) when there are z-neighbours.
-  // XPIC_FORCE_HALO=1 keeps the ghost planes and the exchange layer on a single slab (its own neighbour): the
+  // geometry.self_ring keeps the ghost planes and the exchange layer on a single slab (its own neighbour): the
   // way to exercise the RCCL transport on a one-GPU box.
-  const bool force_halo = getenv("XPIC_FORCE_HALO") && atoi(getenv("XPIC_FORCE_HALO")) != 0;
-  g.G = (geom->nranks > 1 || force_halo) ? 3 : 0;
+  XPIC_CHECK(!geom->self_ring || geom->nranks == 1, "self_ring is a single-slab option");
+  g.G = (geom->nranks > 1 || geom->self_ring) ? 3 : 0;
   g.nzs = g.nzl + 2 * g.G;
   g.dx = geom->d[0]; g.dy = geom->d[1]; g.dz = geom->d[2]; g.dt = geom->dt;
   g.Lx = g.nx * g.dx; g.Ly = g.ny * g.dy; g.Lz = g.nzg * g.dz;
@@ -385,10 +385,11 @@ int xpic_sort_clear(xpic_ctx* ctx, int sort)
   return 0;
 }
 
-int xpic_sort_fill_synthetic(xpic_ctx* ctx, int sort, int ppc, double vth, uint64_t seed)
+int xpic_sort_fill_synthetic(xpic_ctx* ctx, int sort, int ppc, double vth, uint64_t seed, int regular)
 {
   CTX_CHECK(ctx); SORT_CHECK(sort);
-  return sort_fill_synthetic(ctx, ctx->sorts[sort], ppc, vth, seed);
+  XPIC_CHECK(ppc > 0, "ppc must be positive");
+  return sort_fill_synthetic(ctx, ctx->sorts[sort], ppc, vth, seed, regular != 0);
 }
 
 int xpic_field_set(xpic_ctx* ctx, int field, const double* v)
@@ -664,6 +665,16 @@ int xpic_energy(xpic_ctx* ctx, double* out)
     out[4 + 2 * i] = K;
     out[5 + 2 * i] = sK;
   }
+  return 0;
+}
+
+int xpic_momentum(xpic_ctx* ctx, double* out) // MomentumConservation::calculate, momentum_conservation.cpp:77-131
+{
+  CTX_CHECK(ctx);
+  XPIC_CHECK(out, "null argument");
+  XPIC_CALL(halo_fill(ctx, ctx->field[XPIC_E])); // DMGlobalToLocal(da, E, INSERT_VALUES, El) :82
+  for (size_t i = 0; i < ctx->sorts.size(); ++i)
+    XPIC_CALL(momentum_sums_global(ctx, ctx->sorts[i], ctx->field[XPIC_E], out + 6 * i));
   return 0;
 }
 

@@ -134,6 +134,19 @@ int xpic_comm_init_rccl(xpic_ctx* ctx, const void* id128)
   return 0;
 }
 
+int xpic_comm_size(xpic_ctx* ctx, int* nranks)
+{
+  XPIC_CHECK(ctx && nranks, "null argument");
+  *nranks = 1;
+  if (ctx->comm.kind == 1) {
+    int n = 0;
+    XPIC_NCCL(ncclCommCount((ncclComm_t)ctx->comm.nccl, &n)); // what RCCL itself holds, not what the caller asked for
+    *nranks = n;
+  }
+  else if (ctx->comm.kind == 2) *nranks = ctx->comm.nranks;
+  return 0;
+}
+
 int xpic_comm_init_callbacks(xpic_ctx* ctx, const xpic_comm_callbacks* cb)
 {
   XPIC_CHECK(ctx && cb && cb->sendrecv && cb->allreduce_sum, "null argument");

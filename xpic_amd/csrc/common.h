@@ -213,13 +213,14 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap);
 int sort_move(xpic_ctx* c, Sort& s, double step); // r += step*v in place, cells left stale // (optional move by step*v), wrap, bin, scatter
 int sort_append_host(xpic_ctx* c, Sort& s, int64_t n, const double* pts6, int64_t* added);
 int sort_download(xpic_ctx* c, Sort& s, double* pts6, int32_t* cell_of);
-int sort_fill_synthetic(xpic_ctx* c, Sort& s, int ppc, double vth, uint64_t seed);
+int sort_fill_synthetic(xpic_ctx* c, Sort& s, int ppc, double vth, uint64_t seed, bool regular);
 int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B, bool prebin = false);
 int charge_density(xpic_ctx* c, Sort& s, double* rho_vec);
 int moment_density(xpic_ctx* c, Sort& s, double* vec);
 int kinetic_sums_host(xpic_ctx* c, Sort& s, double* out5);   // local sums of vx, vy, vz, v^2 and the count
 int kinetic_sums_global(xpic_ctx* c, Sort& s, double* out5); // summed over the slabs
 int scale_velocities(xpic_ctx* c, Sort& s, double lambda);
+int momentum_sums_global(xpic_ctx* c, Sort& s, const double* E, double* out6);
 
 // ecsim.hip
 int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, double* matL, bool first_sort);

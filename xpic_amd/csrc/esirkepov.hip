@@ -288,8 +288,14 @@ int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double
 
   if (pred_w_host) *pred_w_host = 0.0;
   if (s.n == 0) {
-    // an empty slab still takes part in the collective
-    if (pred_w_host) XPIC_CALL(comm_allreduce_sum_host(c, pred_w_host, 1));
+    // an empty slab still takes part in the collective (pred_w and the error count)
+    double red[2] = {0.0, 0.0};
+    XPIC_CALL(comm_allreduce_sum_host(c, red, 2));
+    if (pred_w_host) *pred_w_host = red[0];
+    if (red[1] != 0.0) {
+      set_error(std::to_string((long)red[1]) + " particle(s) moved more than one cell in an Esirkepov step on another z-slab");
+      return 6;
+    }
     return 0;
   }
   const GridDev& g = c->g;
@@ -315,13 +321,13 @@ int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double
   XPIC_HIP(hipStreamSynchronize(c->stream));
   int bad;
   memcpy(&bad, &c->red_host[1], sizeof(int));
-  if (pred_w_host) {
-    double pw = c->red_host[0];
-    XPIC_CALL(comm_allreduce_sum_host(c, &pw, 1)); // MPI_Allreduce(pred_w), ecsimcorr/particles.cpp:85
-    *pred_w_host = pw;
-  }
-  if (bad) {
-    set_error(std::to_string(bad) + " particle(s) moved more than one cell in an Esirkepov step "
+  // one collective for both scalars: MPI_Allreduce(pred_w) (ecsimcorr/particles.cpp:85) and the error count, so that
+  // every z-slab leaves with the same return code (a rank returning alone would leave its neighbours waiting)
+  double red[2] = {c->red_host[0], (double)bad};
+  XPIC_CALL(comm_allreduce_sum_host(c, red, 2));
+  if (pred_w_host) *pred_w_host = red[0];
+  if (red[1] != 0.0) {
+    set_error(std::to_string((long)red[1]) + " particle(s) moved more than one cell in an Esirkepov step "
       "(the reference overflows Shape::shape[] here, src/utils/shape.h:18,91-92)");
     return 6;
   }

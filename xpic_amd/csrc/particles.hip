@@ -481,6 +481,60 @@ __global__ void __launch_bounds__(kBlock) k_moment_density(GridDev g, SortDev s,
   }
 }
 
+// MomentumConservation::calculate (src/diagnostics/momentum_conservation.cpp:77-131): per particle the 2nd-order
+// Shape::setup(point.r) (shape.cpp:31-41), sums of m v ns and q E[node] Es over its nodes.  Diagnostic, off the hot
+// path: E straight from global memory; deterministic two-stage reduction (6 rows of block partials).
+__global__ void __launch_bounds__(kBlock) k_momentum(GridDev g, SortDev s, int64_t n, const double* __restrict__ E,
+  double m, double q, double* partial, int nblocks)
+{
+  double a[6] = {0, 0, 0, 0, 0, 0};
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const double dd[3] = {g.dx, g.dy, g.dz};
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += stride) {
+    const double r[3] = {s.r[0][p], s.r[1][p], s.r[2][p]};
+    const double v[3] = {s.v[0][p], s.v[1][p], s.v[2][p]};
+    int st[3], sz[3];
+    double No[3][4], Sh[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double pr = r[c] / dd[c];
+      st[c] = (int)round(pr - 1.5);              // Shape::make_start
+      sz[c] = (int)floor(pr + 1.5) + 1 - st[c];  // Shape::make_end
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double gx = (double)(st[c] + t);
+        No[c][t] = spline2_d(pr - gx);
+        Sh[c][t] = spline2_d(pr - (gx + 0.5));
+      }
+    }
+    st[2] -= g.z0;
+    for (int kz = 0; kz < sz[2]; ++kz)
+      for (int jy = 0; jy < sz[1]; ++jy)
+        for (int ix = 0; ix < sz[0]; ++ix) {
+          const long node = g.nodew(st[0] + ix, st[1] + jy, st[2] + kz);
+          const double ns = No[2][kz] * No[1][jy] * No[0][ix];
+          a[0] += m * v[0] * ns;
+          a[1] += m * v[1] * ns;
+          a[2] += m * v[2] * ns;
+          // Shape::electric (shape.h:54-61)
+          a[3] += q * E[node] * (No[2][kz] * No[1][jy] * Sh[0][ix]);
+          a[4] += q * E[g.cstride + node] * (No[2][kz] * Sh[1][jy] * No[0][ix]);
+          a[5] += q * E[2 * g.cstride + node] * (Sh[2][kz] * No[1][jy] * No[0][ix]);
+        }
+  }
+  __shared__ double sm[6][kBlock / 64];
+  for (int j = 0; j < 6; ++j) {
+    double v = wave_sum(a[j]);
+    if ((threadIdx.x & 63) == 0) sm[j][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double v = 0;
+    for (int w = 0; w < kBlock / 64; ++w) v += sm[threadIdx.x][w];
+    partial[(long)threadIdx.x * nblocks + blockIdx.x] = v;
+  }
+}
+
 // AoS Point records (host staging buffer on device) -> SoA tail of the sort
 __global__ void __launch_bounds__(kBlock) k_unpack(SortDev s, int64_t at, int64_t n, const double* pts6)
 {
@@ -513,18 +567,30 @@ __device__ inline uint64_t splitmix(uint64_t& x)
 }
 __device__ inline double u01(uint64_t& st) { return ((splitmix(st) >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
 
+// REGULAR: particle p sits in cell p / ppc (exactly ppc per cell, the generated order IS the sorted order);
+// otherwise the position is uniform over the whole slab like CoordinateInBox + SetParticles
+// (src/utils/particles_load.cpp:11-18, src/commands/set_particles.cpp:19-43): Poisson occupancy of the cells,
+// binned afterwards by the ordinary counting sort
+template <bool REGULAR>
 __global__ void __launch_bounds__(kBlock) k_synthetic(GridDev g, SortDev s, int64_t n, int ppc, double vth, uint64_t seed)
 {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= n) return;
-  const int64_t cell = p / ppc;
-  const int cx = (int)(cell % g.nx), cy = (int)((cell / g.nx) % g.ny), cz = (int)(cell / g.plane);
   uint64_t st = seed * 0xD1342543DE82EF95ull + (uint64_t)p * 0x2545F4914F6CDD1Dull;
-  // strictly inside the cell so that the generated order IS the sorted order
+  // strictly inside (0, 1): a generated point is never on the upper face of the box
   const double fx = u01(st) * 0.999999 + 0.0000005, fy = u01(st) * 0.999999 + 0.0000005, fz = u01(st) * 0.999999 + 0.0000005;
-  s.r[0][p] = (cx + fx) * g.dx;
-  s.r[1][p] = (cy + fy) * g.dy;
-  s.r[2][p] = (cz + g.z0 + fz) * g.dz;
+  if (REGULAR) {
+    const int64_t cell = p / ppc;
+    const int cx = (int)(cell % g.nx), cy = (int)((cell / g.nx) % g.ny), cz = (int)(cell / g.plane);
+    s.r[0][p] = (cx + fx) * g.dx;
+    s.r[1][p] = (cy + fy) * g.dy;
+    s.r[2][p] = (cz + g.z0 + fz) * g.dz;
+  }
+  else {
+    s.r[0][p] = fx * g.nx * g.dx;
+    s.r[1][p] = fy * g.ny * g.dy;
+    s.r[2][p] = (g.z0 + fz * g.nzl) * g.dz;
+  }
   double v[3];
   for (int c = 0; c < 3; ++c) {
     const double u1 = u01(st), u2 = u01(st);
@@ -652,6 +718,20 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap)
 #undef LAUNCH
     XPIC_HIP(hipGetLastError());
   }
+  // Error state is COLLECTIVE on slabs: a rank that returned early while its neighbours wait in the next exchange
+  // would hang the job.  Every rank contributes its local flags to one small all-reduce and all of them leave with
+  // the same return code, before the next collective is entered.
+  auto agree = [&](const bool (&local)[4], const char* const (&what)[4]) -> int {
+    double e[4];
+    for (int i = 0; i < 4; ++i) e[i] = local[i] ? 1.0 : 0.0;
+    if (mig) XPIC_CALL(comm_allreduce_sum_host(c, e, 4));
+    for (int i = 0; i < 4; ++i)
+      if (e[i] != 0.0) {
+        set_error(std::string(what[i]) + (mig ? " (on " + std::to_string((int)e[i]) + " of the z-slabs)" : ""));
+        return 2;
+      }
+    return 0;
+  };
   int n_in = 0;
   if (mig) {
     Timed t(c, "migrate");
@@ -659,8 +739,6 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap)
     int hc[4];
     XPIC_HIP(hipMemcpyAsync(hc, s.mig_count, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
     XPIC_HIP(hipStreamSynchronize(c->stream));
-    XPIC_CHECK((hc[2] & 1) == 0, "a particle moved further than the neighbouring z-slab in one step");
-    XPIC_CHECK((hc[2] & 2) == 0, "particle migration buffer overflow");
     int* cnt = s.mig_count + 4; // [4],[5] = my down/up counts (copy), [6],[7] = from up / from down
     XPIC_HIP(hipMemcpyAsync(cnt, s.mig_count, sizeof(int) * 2, hipMemcpyDeviceToDevice, c->stream));
     XPIC_CALL(comm_ring(c, cnt, sizeof(int), cnt + 1, sizeof(int), cnt + 2, sizeof(int), cnt + 3, sizeof(int)));
@@ -668,7 +746,12 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap)
     XPIC_HIP(hipMemcpyAsync(hin, cnt + 2, sizeof(int) * 2, hipMemcpyDeviceToHost, c->stream));
     XPIC_HIP(hipStreamSynchronize(c->stream));
     n_in = hin[0] + hin[1];
-    XPIC_CHECK(n_in <= s.mig_cap, "particle migration receive buffer overflow");
+    {
+      const bool bad[4] = {(hc[2] & 1) != 0, (hc[2] & 2) != 0, (long)hin[0] + hin[1] > s.mig_cap, false};
+      const char* const what[4] = {"a particle moved further than the neighbouring z-slab in one step",
+        "particle migration buffer overflow", "particle migration receive buffer overflow", ""};
+      XPIC_CALL(agree(bad, what));
+    }
     XPIC_CALL(comm_ring(c, s.mig_send[0], sizeof(double) * 6 * hc[0], s.mig_send[1], sizeof(double) * 6 * hc[1], s.mig_recv,
       sizeof(double) * 6 * hin[0], s.mig_recv + 6L * hin[0], sizeof(double) * 6 * hin[1]));
     if (n_in > 0) {
@@ -682,7 +765,17 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap)
     Timed t(c, "scan");
     XPIC_CALL(exclusive_scan(c, s.d.cell_count, c->ncell, s.d.cell_start, &total));
   }
-  XPIC_CHECK(total <= s.cap, "sort capacity exceeded by incoming particles");
+  {
+    int flags = 0; // bit 4: a received particle does not lie in this slab (k_bin_incoming)
+    if (mig && n_in > 0) {
+      XPIC_HIP(hipMemcpyAsync(&flags, s.mig_count + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      XPIC_HIP(hipStreamSynchronize(c->stream));
+    }
+    const bool bad[4] = {total > s.cap, (flags & 4) != 0, false, false};
+    const char* const what[4] = {"sort capacity exceeded by incoming particles",
+      "a particle received from a neighbouring z-slab does not lie in this slab", "", ""};
+    XPIC_CALL(agree(bad, what));
+  }
   if (s.n > 0) {
     Timed t(c, "scatter");
     const unsigned nb = pgrid(s.n);
@@ -744,17 +837,25 @@ int sort_download(xpic_ctx* c, Sort& s, double* pts6, int32_t* cell_of_out)
   return 0;
 }
 
-int sort_fill_synthetic(xpic_ctx* c, Sort& s, int ppc, double vth, uint64_t seed)
-{  s.prebinned = false;
-
+int sort_fill_synthetic(xpic_ctx* c, Sort& s, int ppc, double vth, uint64_t seed, bool regular)
+{
+  s.prebinned = false;
   const int64_t n = (int64_t)c->ncell * ppc;
   XPIC_CHECK(n <= s.cap, "sort capacity exceeded in fill_synthetic");
-  hipLaunchKernelGGL(k_synthetic, dim3(pgrid(n)), dim3(kBlock), 0, c->stream, c->g, s.d, n, ppc, vth, seed);
-  hipLaunchKernelGGL(k_fill_counts, dim3((unsigned)((c->ncell + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
-    s.d.cell_count, s.d.cell_start, (long)c->ncell, ppc);
+  if (regular) {
+    hipLaunchKernelGGL(k_synthetic<true>, dim3(pgrid(n)), dim3(kBlock), 0, c->stream, c->g, s.d, n, ppc, vth, seed);
+    hipLaunchKernelGGL(k_fill_counts, dim3((unsigned)((c->ncell + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
+      s.d.cell_count, s.d.cell_start, (long)c->ncell, ppc);
+    XPIC_HIP(hipGetLastError());
+    s.n = n;
+    return 0;
+  }
+  hipLaunchKernelGGL(k_synthetic<false>, dim3(pgrid(n)), dim3(kBlock), 0, c->stream, c->g, s.d, n, ppc, vth, seed);
   XPIC_HIP(hipGetLastError());
   s.n = n;
-  return 0;
+  // add_particle's binning (no wrap; nothing falls outside).  With z-neighbours this is collective like any re-bin;
+  // every generated point lies inside this slab, so nothing migrates.
+  return sort_rebin(c, s, 0.0, false);
 }
 
 // prebin: also bin the particles for the first_push + update_cells that opens the next ecsim step (sort_rebin with
@@ -826,6 +927,24 @@ int kinetic_sums_global(xpic_ctx* c, Sort& s, double* out5)
 {
   XPIC_CALL(kinetic_sums_host(c, s, out5));
   return comm_allreduce_sum_host(c, out5, 5);
+}
+
+// out6 = {Px, Py, Pz, QEx, QEy, QEz} of one sort, summed over the slabs (E must have its ghost planes filled)
+int momentum_sums_global(xpic_ctx* c, Sort& s, const double* E, double* out6)
+{
+  for (int i = 0; i < 6; ++i) out6[i] = 0;
+  if (s.n > 0) {
+    int nblocks = (int)pgrid(s.n, 4);
+    if (nblocks > kRedBlocks) nblocks = kRedBlocks;
+    hipLaunchKernelGGL(k_momentum, dim3(nblocks), dim3(kBlock), 0, c->stream, c->g, s.d, s.n, E, s.par.m / s.par.Np,
+      s.par.q / s.par.Np, c->red_partial, nblocks);
+    hipLaunchKernelGGL(k_sum_rows, dim3(6), dim3(kBlock), 0, c->stream, c->red_partial, nblocks, c->red_out);
+    XPIC_HIP(hipGetLastError());
+    XPIC_HIP(hipMemcpyAsync(c->red_host, c->red_out, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
+    XPIC_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 6; ++i) out6[i] = c->red_host[i];
+  }
+  return comm_allreduce_sum_host(c, out6, 6);
 }
 
 int sort_move(xpic_ctx* c, Sort& s, double step)

@@ -219,6 +219,7 @@ PetscErrorCode Simulation::initialize()
   // the always-on conservation diagnostic (simulation.cpp:39-50)
   diagnostics_.emplace_back(std::make_unique<Energy>(*this));
   diagnostics_.emplace_back(std::make_unique<ChargeConservation>(*this)); // simulation.cpp:52-53
+  diagnostics_.emplace_back(std::make_unique<MomentumConservation>(*this)); // simulation.cpp:55-56
 
   std::vector<std::unique_ptr<Command>> presets;
   XCALL(build_commands(*this, "Presets", presets));
@@ -690,6 +691,8 @@ PetscErrorCode SimulationBackup::save(PetscInt t)
   const std::string dir = out_dir_ + "/" + std::to_string(t);
   make_dirs(dir);
   const size_t n3 = (size_t)geom_nx * geom_ny * geom_nz * 3;
+  // the PETSc binary Vec header and the .numparts file carry 32-bit counts (PetscInt without --with-64-bit-indices)
+  if (n3 > (size_t)INT32_MAX) throw std::runtime_error("SimulationBackup: the Vec length exceeds the 32-bit PetscInt of the file format");
   std::vector<double> data(n3);
   for (const char* name : kBackupFields) { // save_fields :48-63, VecView of a DMDA vector = natural ordering
     HIPCALL(xpic_field_get(simulation.ctx, simulation.get_named_vector(name), data.data()));
@@ -702,6 +705,8 @@ PetscErrorCode SimulationBackup::save(PetscInt t)
     std::vector<Point> points;
     std::vector<int> cells;
     XCALL(sort->storage(points, cells));
+    if (points.size() > (size_t)INT32_MAX)
+      throw std::runtime_error("SimulationBackup: more particles than the 32-bit .numparts file can hold");
     const int32_t numparts = (int32_t)points.size();
     std::ofstream fn(dir + "/" + sort->parameters.sort_name + ".numparts", std::ios::binary);
     put_be(fn, &numparts, 4, 1);
@@ -846,6 +851,64 @@ PetscErrorCode ChargeConservation::add_columns(PetscInt t)
   }
   add(13, "N1dQ_tot", "% .6e", norm[2 * particles.size()]);
   add(13, "N2dQ_tot", "% .6e", norm[2 * particles.size() + 1]);
+  return 0;
+}
+
+// ---- MomentumConservation (src/diagnostics/momentum_conservation.cpp): dP/dt against the force q E on the particles
+MomentumConservation::MomentumConservation(interfaces::Simulation& simulation)
+  : TableDiagnostic(CONFIG().out_dir + "/temporal/momentum_conservation.txt"), simulation(simulation)
+{
+}
+
+PetscErrorCode MomentumConservation::calculate()
+{
+  const size_t n = simulation.particles_.size();
+  std::vector<double> sums(6 * n);
+  HIPCALL(xpic_momentum(simulation.ctx, sums.data()));
+  P1.resize(n);
+  QE.resize(n);
+  P0.resize(n);
+  for (size_t i = 0; i < n; ++i)
+    for (int c = 0; c < 3; ++c) {
+      P1[i][c] = sums[6 * i + c];
+      QE[i][c] = sums[6 * i + 3 + c];
+    }
+  return 0;
+}
+
+PetscErrorCode MomentumConservation::initialize()
+{
+  XCALL(calculate());
+  P0 = P1;
+  return 0;
+}
+
+PetscErrorCode MomentumConservation::add_columns(PetscInt t)
+{
+  XCALL(calculate());
+  add_int(6, "Time", t);
+  auto length = [](const Vector3R& v) { return std::sqrt(v.squared()); };
+  Vector3R total;
+  for (size_t i = 0; i < P1.size(); ++i) {
+    const std::string& name = simulation.particles_[i]->parameters.sort_name;
+    static const char* axis[3] = {"x_", "y_", "z_"};
+    for (int c = 0; c < 3; ++c) add(13, std::string("P") + axis[c] + name, "% .6e", P1[i][c]);
+    for (int c = 0; c < 3; ++c) add(13, std::string("QE") + axis[c] + name, "% .6e", QE[i][c]);
+    Vector3R defect, diff, mean;
+    for (int c = 0; c < 3; ++c) {
+      diff[c] = P1[i][c] - P0[i][c];
+      mean[c] = P1[i][c] + P0[i][c];
+      defect[c] = diff[c] / dt - QE[i][c]; // (p1 - p0) / dt - qe   :56
+      total[c] += defect[c];
+    }
+    PetscReal freq = 0;
+    if (const PetscReal denom = length(mean); std::abs(denom) > 1e-10 /* PETSC_SMALL */)
+      freq = (length(diff) / denom) / (0.5 * dt);
+    add(13, "N2dP_" + name, "% .6e", length(defect));
+    add(13, "fP_" + name, "% .6e", freq);
+    P0[i] = P1[i];
+  }
+  add(13, "N2dP", "% .6e", length(total));
   return 0;
 }
 

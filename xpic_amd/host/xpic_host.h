@@ -262,6 +262,18 @@ private:
   interfaces::Simulation& simulation;
 };
 
+class MomentumConservation : public TableDiagnostic { // src/diagnostics/momentum_conservation.cpp:7-131
+public:
+  explicit MomentumConservation(interfaces::Simulation& simulation);
+  PetscErrorCode initialize() override;
+  PetscErrorCode add_columns(PetscInt t) override;
+
+private:
+  PetscErrorCode calculate(); // P1, QE of every sort: the sums stay on the device (xpic_momentum)
+  interfaces::Simulation& simulation;
+  std::vector<Vector3R> P0, P1, QE;
+};
+
 PetscErrorCode build_diagnostics(interfaces::Simulation& simulation,
   std::vector<std::unique_ptr<interfaces::Diagnostic>>& result); // diagnostic_builder.cpp:16-75
 
