@@ -1,7 +1,7 @@
 # Builds the gfx950 shared library (product), the CPU oracle (test infrastructure) and the host executable.
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
-HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -munsafe-fp-atomics -Wall -Wno-unused-function
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -munsafe-fp-atomics -Wall -Wno-unused-function $(EXTRA)
 CSRC := xpic_amd/csrc
 SRCS := $(CSRC)/api.hip $(CSRC)/fields.hip $(CSRC)/particles.hip $(CSRC)/ecsim.hip $(CSRC)/esirkepov.hip $(CSRC)/krylov.hip $(CSRC)/comm.hip $(CSRC)/eccapfim.hip
 OBJS := $(SRCS:.hip=.o)

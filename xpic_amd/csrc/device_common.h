@@ -29,7 +29,9 @@ struct W1 {
   double wn[3][2], ws[3][2];
   __device__ inline W1(const GridDev& g, double x, double y, double z)
   {
-    const double pn[3] = {x / g.dx, y / g.dy, z / g.dz};
+    // x / dx; spacings that are powers of two take the exact multiplication (wave-uniform choice)
+    const double pn[3] = {g.inv_exact[0] != 0.0 ? x * g.inv_exact[0] : x / g.dx,
+      g.inv_exact[1] != 0.0 ? y * g.inv_exact[1] : y / g.dy, g.inv_exact[2] != 0.0 ? z * g.inv_exact[2] : z / g.dz};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const double ps = pn[a] - 0.5;

@@ -5,20 +5,26 @@
 // 36 x 36 block  M = sum_p A_p * (s_p s_p^T) o matB_p  (the reference's 1296-entry COO block, :145-163)
 // and its contribution to currI is the 36-vector sum_p s_p o I_p.
 //
-// Work decomposition (v2, "pencil march"):
-//   * one workgroup (8 waves) owns one x-pencil of cells (fixed cy, cz) and marches along x in chunks of
-//     8 cells, one cell per wave;
-//   * per cell:  phase 1 (lane = particle)  CIC weights, B gather, b, I_p, A_p*matB -> the wave's LDS stage;
-//                phase 2 (lane = 4 x 6 tile) rank-1 updates out of LDS into 24 register accumulators;
-//   * per chunk: the 8 cell blocks are merged in an LDS window indexed [matL line][x] (a "line" is one
-//     (row component, row y/z offset, k) coefficient stream of the index-free matL), which sums the
-//     duplicates of x-neighbouring cells on chip; finished columns are streamed out with plain,
-//     64-byte-aligned read-modify-write; two unfinished columns are carried to the next chunk;
+// Work decomposition ("pencil march"):
+//   * one workgroup (4 waves) owns one x-pencil of cells (fixed cy, cz) and marches along x in chunks of 4 cells,
+//     one cell per wave; a cell is staged in passes of at most kCP particles;
+//   * phase 1 (lane = particle): CIC weights, B gather out of the cell's 54-value LDS neighbourhood, b, I_p,
+//     A_p*matB.  The particle's half-cell octant (ox, oy, oz) fixes WHICH 8 of the 12 nodes per component it
+//     touches; its 24 non-zero weights + 9 + 3 values go to the wave's LDS stage, compacted by octant;
+//   * phase 2 (matrix cores): inside an octant the particle block is the dense 24 x 24 the reference fills
+//     (576 products, particles.cpp:149-166): per 4 particles nine v_mfma_f64_4x4x4_4b_f64 (36 blocks of 4 x 4) and
+//     two more for currI.  An accumulator belongs to one (component pair, octant bits of that pair): 36 per lane;
+//   * per chunk the 4 cell blocks are merged in an LDS window indexed [matL line][x] (a "line" is one
+//     (row component, row y/z offset, k) coefficient stream of the index-free matL), which sums the duplicates of
+//     x-neighbouring cells on chip; finished columns are streamed out with plain, aligned read-modify-write (first
+//     touch: plain stores); two unfinished columns are carried to the next chunk in registers;
 //   * pencils whose rows overlap (|dcy| <= 2 and |dcz| <= 2, periodically) never run in the same launch:
-//     launches are coloured by (cy mod 3, cz mod 3) (+ remainder colours), so the RMW needs no atomics and
+//     launches are coloured by (cy mod p, cz mod p) (+ remainder colours), so the RMW needs no atomics and
 //     the result is bitwise reproducible.  MatSetValuesCOO's duplicate summation (simulation.cpp:366) thus
 //     happens in LDS (x) and in launch order (y, z).
-// v1 flushed every cell block with ~1200 scattered fp64 atomics: 85 % of the kernel time at 256^3.
+// History: v1 flushed every cell block with ~1200 scattered fp64 atomics (85 % of the kernel time at 256^3); v2-v8
+// accumulated the padded dense 36 x 36 block of a cell (VALU rank-1 updates, then v_mfma_f64_16x16x4): 56 % of the
+// matrix-pipe cycles multiplied structural zeros.
 #include <algorithm>
 #include <array>
 #include <cstdint>
@@ -29,16 +35,49 @@
 #include "device_common.h"
 #include "lstencil.h"
 
+#ifndef FILL_EXP
+#define FILL_EXP 0 // experiments (tools/fill_exp.sh): 1 no phase 2, 6 neither phase 1 nor phase 2, 7 as 6 and no merge,
+                   // 8 as 7 and no flush, 10 staggered workgroup starts
+#endif
+
+#ifdef FILL_STAMPS
+// in-kernel section timers (experiment build only): s_memtime deltas of wave 0 summed per section over all workgroups
+__device__ unsigned long long g_fill_stamps[16];
+#define STAMP(k)                                                                       \
+  do {                                                                                 \
+    const unsigned long long now_ = __builtin_readcyclecounter();                      \
+    stamp_acc_[k] += now_ - stamp_t_;                                                  \
+    stamp_t_ = now_;                                                                   \
+  } while (0)
+extern "C" int xpic_debug_fill_stamps(double* out, int reset)
+{
+  unsigned long long h[16];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fill_stamps), sizeof(h)) != hipSuccess) return 1;
+  for (int i = 0; i < 16; ++i) out[i] = (double)h[i];
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_fill_stamps), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#else
+#define STAMP(k)
+#endif
+
 namespace xpic {
 
 namespace {
 
 constexpr int kW = 4;             // waves per workgroup = cells per chunk
-constexpr int kCP = 40;           // particles staged per pass and wave (cells of 64 +- 8 fit two passes)
-constexpr int kPadP = kCP + 2;    // LDS row pitch; 2 * 42 mod 64 = 20: the 16 rows of an MFMA operand fall in 16 distinct bank quads
-constexpr int kRows = 50;         // 36 weights + 9 A_p*matB + 3 I_p + a row of ones + a row of zeros
-constexpr int kStage = kRows * kPadP;
-constexpr int kRowOne = 48, kRowZero = 49;
+constexpr int kCP = 48;           // particles staged per pass and wave (Poisson(64) cells: two passes)
+// One stage slot = one particle: 24 weights [c][i][h] (i: the 2 x 2 nodes transverse to the component's staggered axis,
+// h: lower / upper node along it), 9 A_p*matB, 3 I_p.  Pitch 42 doubles = 84 dwords: the 16-byte stores of 8
+// consecutive slots fall in 8 distinct bank quads (84 l mod 32 = 0,20,8,28,16,4,24,12) and the operand reads of the
+// two particles that share an LDS cycle are 20 banks apart.
+constexpr int kPitch = 42;
+constexpr int kOffAB = 24; // [24, 33): A_p*matB row-major, [33, 36): I_p
+constexpr int kStage = kCP * kPitch;
+constexpr int kAcc = 36;          // accumulators per lane: 30 matL (component pair x octant bits of the pair) + 6 currI
 typedef double mfma_acc __attribute__((ext_vector_type(4)));
 constexpr int kMatLines = 816;    // distinct (c1, row dy, row dz, k) streams one pencil can touch
 constexpr int kCurLines = 16;     // (c, dy, dz) streams of currI
@@ -47,6 +86,27 @@ constexpr int kThreads = kW * 64;
 constexpr int kSlots = kW + 2;    // window columns: kW finished + 2 carried
 constexpr int kOwn = (kLines + kThreads - 1) / kThreads; // window lines owned by a thread (init, flush, carry)
 constexpr int kMaxNxLds = 1024;   // pencils up to this length keep their cell_start row in LDS
+
+// accumulator of the block (c1, c2) for a particle of octant o = ox | oy << 1 | oz << 2: the rows depend on the
+// octant bit of axis c1 only, the columns on that of axis c2
+__host__ __device__ constexpr int acc_main(int c1, int c2, int o)
+{
+  const int o1 = (o >> c1) & 1, o2 = (o >> c2) & 1;
+  if (c1 == c2) return c1 * 2 + o1;
+  const int pair = c1 * 2 + (c2 > c1 ? c2 - 1 : c2);
+  return 6 + pair * 4 + o1 * 2 + o2;
+}
+// currI: instruction 1 holds the X and Y rows (bits ox, oy), instruction 2 the Z rows (bit oz)
+__host__ __device__ constexpr int acc_cur1(int o) { return 30 + (o & 1) * 2 + ((o >> 1) & 1); }
+__host__ __device__ constexpr int acc_cur2(int o) { return 34 + ((o >> 2) & 1); }
+// row of the cell block (numbering of lstencil.h: block_node_offset) of node i of group g of component c; g = octant
+// bit + h is the node slot along the component's own axis
+__host__ __device__ constexpr int row_of(int c, int g, int i)
+{
+  if (c == 0) return i * 3 + g;                                  // i = k * 2 + j
+  if (c == 1) return 12 + ((i >> 1) * 3 + g) * 2 + (i & 1);      // i = k * 2 + ix
+  return 24 + (g * 2 + (i >> 1)) * 2 + (i & 1);                  // i = j * 2 + ix
+}
 
 static_assert(kLines * kSlots <= kW * kStage, "the merge window must fit in the (dead) staging area");
 
@@ -86,83 +146,34 @@ __device__ inline double load_bnb(const GridDev& g, const double* __restrict__ B
 }
 
 __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s, const double* __restrict__ B,
-  double* currI, double* matL, const int* __restrict__ etab, const int* __restrict__ linetab, const int* __restrict__ cowr, double q, double m,
+  double* currI, double* matL, const unsigned* __restrict__ dtab, const int* __restrict__ linetab, const int* __restrict__ cowr, double q, double m,
   double mpw, int cy0, int cystep, int ncy, int cz0, int czstep, int my_order, int ncol_y, int per_y, int per_z, int first_sort)
 {
   const int cy = cy0 + (int)(blockIdx.x % ncy) * cystep;
   const int cz = cz0 + (int)(blockIdx.x / ncy) * czstep;
 
   __shared__ __attribute__((aligned(16))) double sh[kW * kStage];
+  __shared__ __attribute__((aligned(16))) double zslot[kPitch]; // the particle of weight zero that fills up a K = 4 step
+  __shared__ unsigned dsc[kAcc * 64]; // byte offset of lane's element of accumulator e inside the merge window
   __shared__ int cstart[kMaxNxLds + 2];
   __shared__ double bnb[kW][54];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double* st = sh + wave * kStage;
   const double dt = g.dt;
 
-  // Phase 2 runs on the matrix cores.  For a row component c1 the cell block is the GEMM
-  //   D_c1[12 x 36] = S_c1^T [12 x P] * ( S [P x 36] o matB_c1 )        (P = particles of the cell)
-  // over K = 4 particles per step.  Columns 0..31 go through v_mfma_f64_16x16x4_f64 (A = the 12 (+4 unused) rows of the
-  // component, B = two 16-column tiles): 6 instructions.  The last four columns 32..35 and the cell's currI
-  // (sum_p s_p I_p[c1], i.e. the product with the stage rows 45..47) would fill a third 16-column tile only to 5/16;
-  // they are 18 blocks of 4 x 4 instead and take 5 v_mfma_f64_4x4x4_4b_f64 (4 independent blocks each).
-  // 16x16x4 lane roles: operand element (i or j = lane & 15, k = lane >> 4); result rows (lane >> 4) + 4 r, r < 3.
-  // 4x4x4 lane roles (probed, tools/ubench/mfma_f64_4x4.hip): A[b][i][k], B[b][k][j] at lane 16 k + 4 b + (i or j);
-  // D[b][i][j] at lane 16 i + 4 b + j.
-  const int mj = lane & 15, mk = lane >> 4;
-  const double* a_ptr = st + min(mj, 11) * kPadP + mk;                 // + c1 * 12 rows
-  const double* b_ptr = st + mj * kPadP + mk;                          // + t * 16 rows
-  const double* m0_ptr = st + (36 + (mj < 12 ? 0 : 1)) * kPadP + mk;  // tile 0: columns 0..15   (+ c1 * 3 rows)
-  const double* m1_ptr = st + (36 + (mj < 8 ? 1 : 2)) * kPadP + mk;   // tile 1: columns 16..31
-  // 4x4x4 instructions n = 0..4, block b = (lane >> 2) & 3 of each:
-  //   n = 0, 1: row blocks 4 n + b, columns 32..35          n = 2, 3: row blocks 4 (n - 2) + b, currI
-  //   n = 4   : b = 0: row block 8, columns 32..35;  b = 1: row block 8, currI;  b = 2, 3: idle (zeros)
-  const int qb = (lane >> 2) & 3, qj = lane & 3;
-  const double* a4_ptr[3] = {st + mj * kPadP + mk, st + (16 + mj) * kPadP + mk, st + (32 + qj) * kPadP + mk};
-  const double* x4_ptr[5]; // first factor of B
-  const double* y4_ptr[3]; // second factor of B for n = 0, 1, 4 (the currI operands need none)
-#pragma unroll
-  for (int n = 0; n < 2; ++n) {
-    const int c1n = (4 * n + qb) / 3; // row component of this block's rows
-    x4_ptr[n] = st + (32 + qj) * kPadP + mk;
-    y4_ptr[n] = st + (36 + 3 * c1n + 2) * kPadP + mk;
-    x4_ptr[2 + n] = st + (qj == c1n ? 45 + qj : kRowZero) * kPadP + mk;
-  }
-  x4_ptr[4] = st + (qb == 0 ? 32 + qj : (qb == 1 && qj == 2 ? 47 : kRowZero)) * kPadP + mk;
-  y4_ptr[2] = st + (qb == 0 ? 44 : (qb == 1 ? kRowOne : kRowZero)) * kPadP + mk;
+  // Phase 2 runs on the matrix cores.  All particles of one octant touch the same 3 x 8 nodes: their block is the
+  // dense 24 x 24  D[(c1,n1)][(c2,n2)] = sum_p s_p[c1][n1] * s_p[c2][n2] * (A_p matB_p)[c1][c2],  cut into 36 blocks of
+  // 4 x 4 (component pair x (h1, h2)) and issued as nine v_mfma_f64_4x4x4_4b_f64 over K = 4 particles: instruction
+  // (c1, c2), block b = (h1, h2).  Lane roles (probed, tools/ubench/mfma_f64_4x4.hip): A[b][i][k], B[b][k][j] at lane
+  // 16 k + 4 b + (i or j); D[b][i][j] at lane 16 i + 4 b + j.  Two more instructions give the cell's
+  // currI = sum_p s_p[c][n] I_p[c]: blocks (X,h), (Y,h) resp. (Z,h) with the multiplier I_p[c] in column j = 0.
+  const int kk = lane >> 4, qb = (lane >> 2) & 3, qj = lane & 3;
+  const int offA = qj * 2 + (qb >> 1);                   // + c1 * 8: row weights s[c1][i = qj][h1]
+  const int offB = qj * 2 + (qb & 1);                    // + c2 * 8: column weights s[c2][j = qj][h2]
+  const bool cur1_lane = qj == 0, cur2_lane = qj == 0 && qb < 2;
 
-  // per-lane flush descriptors (line << 2 | row x offset + 1) of the 18 + 5 results, constant over the march; two
-  // 16-bit descriptors per register, 0xffff = nothing to add (structural zero, unused row, idle block)
-  auto curdesc = [&](int row) {
-    const int c = row / 12;
-    int o[3];
-    block_node_offset(c, row % 12, o);
-    const int id = c == 0 ? o[2] * 2 + o[1] : (c == 1 ? 4 + o[2] * 3 + (o[1] + 1) : 10 + (o[2] + 1) * 2 + o[1]);
-    return ((kMatLines + id) << 2) | (o[0] + 1);
-  };
-  constexpr int kDesc = 18 + 5;
-  unsigned edesc[(kDesc + 1) / 2];
-#pragma unroll
-  for (int e = 0; e < (kDesc + 1) / 2; ++e) edesc[e] = 0xffffffffu;
-  auto set_desc = [&](int e, int d) {
-    edesc[e / 2] = (edesc[e / 2] & ~(0xffffu << (16 * (e & 1)))) | (((unsigned)d & 0xffffu) << (16 * (e & 1)));
-  };
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 3; ++r) set_desc((c * 2 + t) * 3 + r, etab[(12 * c + mk + 4 * r) * 36 + 16 * t + mj]);
-  {
-    const int di = lane >> 4; // D[b][i][j]: i = lane >> 4
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      const int row = 4 * (4 * n + qb) + di;
-      set_desc(18 + n, etab[row * 36 + 32 + qj]);
-      set_desc(18 + 2 + n, qj == row / 12 ? curdesc(row) : -1);
-    }
-    const int row8 = 32 + di;
-    set_desc(18 + 4, qb == 0 ? etab[row8 * 36 + 32 + qj] : (qb == 1 && qj == 2 ? curdesc(row8) : -1));
-  }
+  for (int i = threadIdx.x; i < kAcc * 64; i += kThreads) dsc[i] = dtab[i];
+  if (threadIdx.x < kPitch) zslot[threadIdx.x] = 0.0;
 
   const long pencil0 = ((long)cz * g.ny + cy) * g.nx;
   const bool cs_lds = g.nx <= kMaxNxLds;
@@ -207,6 +218,11 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
 
   // cstart is read by other threads from the first chunk on
   __syncthreads();
+#if FILL_EXP == 10
+  // stagger: the workgroups of a launch start together and would march in step chip-wide (all compute, then all
+  // flush); spread their phases over one chunk period
+  for (int d = (int)((blockIdx.x * 2654435761u) >> 29); d > 0; --d) __builtin_amdgcn_s_sleep(78);
+#endif
 
   // cells are visited in the order 1, 2, ..., nx-1, 0 so that finished columns start 64-byte aligned
   auto cell_x = [&](int i) { return (i + 1 == g.nx) ? 0 : i + 1; };
@@ -236,17 +252,19 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
 #pragma unroll
   for (int mm = 0; mm < kOwn; ++mm) carry[mm][0] = carry[mm][1] = 0.0;
 
+#ifdef FILL_STAMPS
+  unsigned long long stamp_t_ = __builtin_readcyclecounter();
+  unsigned long long stamp_acc_[9] = {};
+#endif
   const int nch = (g.nx + kW - 1) / kW;
   for (int j = 0; j < nch; ++j) {
+    STAMP(0);
     const int i = j * kW + wave;
     const bool active = i < g.nx;
 
-    mfma_acc acc[3][2];
+    double acc[kAcc];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) acc[c][t] = mfma_acc{0.0, 0.0, 0.0, 0.0};
-    double acc4[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int e = 0; e < kAcc; ++e) acc[e] = 0.0;
 
     if (active) {
       const int start = pf.start, cnt = pf.cnt;
@@ -254,19 +272,56 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
       double cur[6];
 #pragma unroll
       for (int a = 0; a < 6; ++a) cur[a] = pf.p[a];
+      // particles.cpp:107-115: the factors that do not depend on the particle
+      const double fb = (0.5 * dt) * q / m;
+      const double qw = q * mpw;                          // iq  = q * mpw / (1 + b^2)
+      const double Aq = 0.5 * dt * dt * mpw * q * q / m;  // A_p = 0.5 dt^2 mpw q^2 / m / (1 + b^2)
+#if FILL_EXP >= 6 && FILL_EXP <= 8
+      for (int e = 0; e < kAcc; ++e) acc[e] = 1.0 + lane;
+#endif
       for (int base = 0; base < cnt; base += kCP) {
         const int mcnt = min(kCP, cnt - base);
-        wave_sync();
-        if (lane < ((mcnt + 3) & ~3)) {
-          // a pass is padded to whole K = 4 steps with particles of zero weight at the origin: all their A_p*matB
-          // and I_p rows are exact zeros
-          const bool real = lane < mcnt;
-          const double mpw_p = real ? mpw : 0.0;
-          const double v[3] = {real ? cur[3] : 0.0, real ? cur[4] : 0.0, real ? cur[5] : 0.0};
-          const W1 w(g, real ? cur[0] : 0.0, real ? cur[1] : 0.0, real ? cur[2] : 0.0);
+#if FILL_EXP >= 6 && FILL_EXP <= 8
+        const bool real = false;
+#else
+        const bool real = lane < mcnt;
+#endif
+        wave_sync(); // the previous pass's operand reads (and the neighbourhood store) are done
+        // CIC weights and the half-cell octant first: the octant decides the particle's stage slot
+        const W1 w(g, real ? cur[0] : 0.0, real ? cur[1] : 0.0, real ? cur[2] : 0.0);
+        const int ox = w.is[0] - w.in[0] + 1, oy = w.is[1] - w.in[1] + 1, oz = w.is[2] - w.in[2] + 1;
+        const int oct = real ? (ox | (oy << 1) | (oz << 2)) : 8;
+        // compaction by octant: the particles of octant o take the stage slots ooff[o] .. ooff[o] + ocnt[o] - 1
+        int ocnt[8], ooff[8], slot = 0;
+        {
+          int run = 0;
+#pragma unroll
+          for (int o = 0; o < 8; ++o) {
+            const unsigned long long mk = __ballot(oct == o);
+            ocnt[o] = __popcll(mk);
+            ooff[o] = run;
+            if (oct == o) slot = run + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+            run += ocnt[o];
+          }
+        }
+        if (real) {
+          double2* dst = (double2*)(st + slot * kPitch);
+          // the 8 weights per component (:138-140, :145-147), [i][h]: i = the 2 x 2 transverse nodes, h = lower /
+          // upper node along the component's staggered axis; stored as they are formed
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+              const double tx = w.wn[2][a] * w.wn[1][bb];  // X: i = k * 2 + j
+              dst[0 + a * 2 + bb] = double2{tx * w.ws[0][0], tx * w.ws[0][1]};
+              // Y: i = k * 2 + ix, s = wnz[k] * wsy[h] * wnx[ix] in the reference's product order
+              dst[4 + a * 2 + bb] = double2{w.wn[2][a] * w.ws[1][0] * w.wn[0][bb], w.wn[2][a] * w.ws[1][1] * w.wn[0][bb]};
+              // Z: i = j * 2 + ix, s = wsz[h] * wny[j] * wnx[ix]
+              dst[8 + a * 2 + bb] = double2{w.ws[2][0] * w.wn[1][a] * w.wn[0][bb], w.ws[2][1] * w.wn[1][a] * w.wn[0][bb]};
+            }
+          const double v[3] = {cur[3], cur[4], cur[5]};
           // interpolate_B_s1 (ecsim/simulation.cpp:64-118) out of the cell's LDS neighbourhood, same loop
           // and product order as the global-memory gather
-          const int ox = w.is[0] - w.in[0] + 1, oy = w.is[1] - w.in[1] + 1, oz = w.is[2] - w.in[2] + 1;
           double Bp[3] = {0.0, 0.0, 0.0};
           const double* nb = bnb[wave];
 #pragma unroll
@@ -279,56 +334,20 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
                 Bp[1] += nb[18 + ((oz + k) * 2 + jj) * 3 + (ox + ii)] * (w.ws[2][k] * w.wn[1][jj] * w.ws[0][ii]);
                 Bp[2] += nb[36 + (k * 3 + (oy + jj)) * 3 + (ox + ii)] * (w.wn[2][k] * w.ws[1][jj] * w.ws[0][ii]);
               }
-          // particles.cpp:107-115
-          const double f = (0.5 * dt) * q / m;
-          const double bx = Bp[0] * f, by = Bp[1] * f, bz = Bp[2] * f;
+          const double bx = Bp[0] * fb, by = Bp[1] * fb, bz = Bp[2] * fb;
           const double b2 = bx * bx + by * by + bz * bz;
           const double vb = v[0] * bx + v[1] * by + v[2] * bz;
           const double cxv = +(v[1] * bz - v[2] * by), cyv = -(v[0] * bz - v[2] * bx), czv = +(v[0] * by - v[1] * bx);
-          const double iq = q * mpw_p / (1. + b2);
-          const double Ip[3] = {iq * (v[0] + cxv + vb * bx), iq * (v[1] + cyv + vb * by), iq * (v[2] + czv + vb * bz)};
-          const double A_p = 0.5 * dt * dt * mpw_p * q * q / m / (1 + b2);
-          const double AB[9] = {
-            A_p * (1.0 + bx * bx), A_p * (+bz + bx * by), A_p * (-by + bx * bz),
-            A_p * (-bz + by * bx), A_p * (1.0 + by * by), A_p * (+bx + by * bz),
-            A_p * (+by + bz * bx), A_p * (-bx + bz * by), A_p * (1.0 + bz * bz)};
-          // staggered-axis weights spread over the cell's 3 node slots (slot = node - cell + 1), :87-89
-          double w3[3][3];
-#pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            const int o = w.is[a] - w.in[a] + 1; // ox, oy, oz in {0, 1}
-            w3[a][0] = o == 0 ? w.ws[a][0] : 0.0;
-            w3[a][1] = o == 0 ? w.ws[a][1] : w.ws[a][0];
-            w3[a][2] = o == 0 ? 0.0 : w.ws[a][1];
-          }
-          double* col = st + lane;
-          // X rows: (k*2 + j)*3 + l ; s = wnz[k]*wny[j]*wsx[.]   (:138, :145)
-#pragma unroll
-          for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-              for (int l = 0; l < 3; ++l) col[((k * 2 + jj) * 3 + l) * kPadP] = w.wn[2][k] * w.wn[1][jj] * w3[0][l];
-          // Y rows: 12 + (k*3 + l)*2 + i ; s = wnz[k]*wsy[.]*wnx[i]   (:139, :146)
-#pragma unroll
-          for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int l = 0; l < 3; ++l)
-#pragma unroll
-              for (int ii = 0; ii < 2; ++ii) col[(12 + (k * 3 + l) * 2 + ii) * kPadP] = w.wn[2][k] * w3[1][l] * w.wn[0][ii];
-          // Z rows: 24 + (l*2 + j)*2 + i ; s = wsz[.]*wny[j]*wnx[i]   (:140, :147)
-#pragma unroll
-          for (int l = 0; l < 3; ++l)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-              for (int ii = 0; ii < 2; ++ii) col[(24 + (l * 2 + jj) * 2 + ii) * kPadP] = w3[2][l] * w.wn[1][jj] * w.wn[0][ii];
-#pragma unroll
-          for (int e = 0; e < 9; ++e) col[(36 + e) * kPadP] = AB[e];
-#pragma unroll
-          for (int e = 0; e < 3; ++e) col[(45 + e) * kPadP] = Ip[e];
-          col[kRowOne * kPadP] = 1.0;
-          col[kRowZero * kPadP] = 0.0;
+          // one division for both factors (the reference divides twice: :112, :116; one rounding apart)
+          const double rb = 1.0 / (1. + b2);
+          const double iq = qw * rb;
+          const double A_p = Aq * rb;
+          dst[12] = double2{A_p * (1.0 + bx * bx), A_p * (+bz + bx * by)};
+          dst[13] = double2{A_p * (-by + bx * bz), A_p * (-bz + by * bx)};
+          dst[14] = double2{A_p * (1.0 + by * by), A_p * (+bx + by * bz)};
+          dst[15] = double2{A_p * (+by + bz * bx), A_p * (-bx + bz * by)};
+          dst[16] = double2{A_p * (1.0 + bz * bz), iq * (v[0] + cxv + vb * bx)};
+          dst[17] = double2{iq * (v[1] + cyv + vb * by), iq * (v[2] + czv + vb * bz)};
         }
         // next pass of this cell: loads in flight during this pass's phase 2
         if (base + kCP + lane < cnt) {
@@ -337,56 +356,53 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
           for (int a = 0; a < 3; ++a) { cur[a] = s.r[a][p]; cur[3 + a] = s.v[a][p]; }
         }
         wave_sync();
+            STAMP(1);
 
-        {
-          // K = 4 particles per step: 22 operands, 9 products, 6 + 5 MFMAs; the operands of step s+1 are requested
-          // before the MFMAs of step s
-          struct Operands { double a[3], b[2], m[6], a4[3], x4[5], y4[3]; };
-          auto load = [&](Operands& o, int p0) {
+        // ---- phase 2: octant by octant (compile-time octant = compile-time accumulators), K = 4 particles per step;
+        // a step beyond the octant's last particle reads the zero slot
+#if FILL_EXP != 1 && !(FILL_EXP >= 6 && FILL_EXP <= 8)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) o.a[c] = a_ptr[c * 12 * kPadP + p0];
+        for (int o = 0; o < 8; ++o) {
+          const int no = ocnt[o];
+          const double* seg = st + ooff[o] * kPitch;
+          for (int t = 0; 4 * t < no; ++t) {
+            const int r = 4 * t + kk;
+            const double* sp = r < no ? seg + r * kPitch : zslot;
+            double a[3], b[3];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) o.b[t] = b_ptr[t * 16 * kPadP + p0];
+            for (int c = 0; c < 3; ++c) { a[c] = sp[c * 8 + offA]; b[c] = sp[c * 8 + offB]; }
+            // the step's 9 A_p*matB and 3 I_p per particle: the same 96 bytes for the 16 lanes of a particle (a DPP row
+            // broadcast of one 8-byte read per lane was measured 6 % slower: the VALU is the scarcer resource here)
+            const double2* u = (const double2*)(sp + kOffAB);
+            const double2 u0 = u[0], u1 = u[1], u2 = u[2], u3 = u[3], u4 = u[4], u5 = u[5];
+            const double ab[9] = {u0.x, u0.y, u1.x, u1.y, u2.x, u2.y, u3.x, u3.y, u4.x};
+            // the nine column operands first, then the matrix instructions back to back: a product issued between two
+            // MFMAs waits for the fp64 pipe to drain and the next MFMA waits for the product
+            double bm[9];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              o.m[c * 2 + 0] = m0_ptr[c * 3 * kPadP + p0];
-              o.m[c * 2 + 1] = m1_ptr[c * 3 * kPadP + p0];
-            }
+            for (int e = 0; e < 9; ++e) bm[e] = b[e % 3] * ab[e];
+            // currI operands: block b of instruction 1 is (X or Y, h = b & 1), of instruction 2 (Z, h = b & 1): their
+            // row weights are column weights already loaded; the multiplier I_p[c] sits in column j = 0
+            const double ai1 = qb < 2 ? b[0] : b[1], ai2 = b[2];
+            const double ip01 = qb < 2 ? u4.y : u5.x;
+            const double bi1 = cur1_lane ? ip01 : 0.0, bi2 = cur2_lane ? u5.y : 0.0;
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int n = 0; n < 3; ++n) { o.a4[n] = a4_ptr[n][p0]; o.y4[n] = y4_ptr[n][p0]; }
+            for (int c1 = 0; c1 < 3; ++c1)
 #pragma unroll
-            for (int n = 0; n < 5; ++n) o.x4[n] = x4_ptr[n][p0];
-          };
-          auto gemm = [&](const Operands& o) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-              for (int t = 0; t < 2; ++t)
-                acc[c][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[c], o.b[t] * o.m[c * 2 + t], acc[c][t], 0, 0, 0);
-            acc4[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a4[0], o.x4[0] * o.y4[0], acc4[0], 0, 0, 0);
-            acc4[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a4[1], o.x4[1] * o.y4[1], acc4[1], 0, 0, 0);
-            acc4[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a4[0], o.x4[2], acc4[2], 0, 0, 0);
-            acc4[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a4[1], o.x4[3], acc4[3], 0, 0, 0);
-            acc4[4] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a4[2], o.x4[4] * o.y4[2], acc4[4], 0, 0, 0);
-          };
-          const int nks = (mcnt + 3) >> 2;
-          Operands A, Bo;
-          load(A, 0);
-          // fully unrolled: every operand address is a base register plus an immediate.  Requests run one step
-          // ahead unconditionally (a step past the pass reads stale columns of the stage that nothing consumes).
-#pragma unroll
-          for (int ks = 0; ks < kCP / 4; ks += 2) {
-            if (ks >= nks) break;
-            if (ks + 1 < kCP / 4) load(Bo, 4 * (ks + 1));
-            gemm(A);
-            if (ks + 1 >= nks) break;
-            if (ks + 2 < kCP / 4) load(A, 4 * (ks + 2));
-            gemm(Bo);
+              for (int c2 = 0; c2 < 3; ++c2)
+                acc[acc_main(c1, c2, o)] =
+                  __builtin_amdgcn_mfma_f64_4x4x4f64(a[c1], bm[c1 * 3 + c2], acc[acc_main(c1, c2, o)], 0, 0, 0);
+            acc[acc_cur1(o)] = __builtin_amdgcn_mfma_f64_4x4x4f64(ai1, bi1, acc[acc_cur1(o)], 0, 0, 0);
+            acc[acc_cur2(o)] = __builtin_amdgcn_mfma_f64_4x4x4f64(ai2, bi2, acc[acc_cur2(o)], 0, 0, 0);
           }
         }
+#endif
+        STAMP(2);
       }
     }
 
+    STAMP(2);
     // next chunk's cell: particle data and B neighbourhood travel while this chunk is merged and flushed
     prefetch_cell(i + kW, pf);
 
@@ -408,7 +424,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
       ptr[mm] = lb ? (double*)(lb & ~(uintptr_t)1) + (long)j * (line < kMatLines ? kLBlock : kW) : nullptr;
 #pragma unroll
       for (int c = 0; c < kW; ++c) old[mm][c] = 0.0;
-      if (ptr[mm] && !fst[mm]) {
+      if (ptr[mm] && !fst[mm] && FILL_EXP != 8) {
         if (vec) {
 #pragma unroll
           for (int c = 0; c < kW; c += 2) {
@@ -427,7 +443,12 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
     // ---- merge the chunk's cell blocks in the window (aliased over the now dead stages).  A thread owns kOwn
     // lines of the window: it seeds them with the two columns it carried over, and after the merge it streams
     // the finished columns out and keeps the last two in registers.
+    unsigned wdst[kAcc]; // requested now, used after the window is seeded
+#pragma unroll
+    for (int e = 0; e < kAcc; ++e) wdst[e] = dsc[e * 64 + lane];
+    STAMP(3);
     lds_barrier();
+    STAMP(4);
     double* win = sh; // [kLines][kSlots]
 #pragma unroll
     for (int mm = 0; mm < kOwn; ++mm) {
@@ -440,22 +461,17 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
       }
     }
     lds_barrier();
-    if (active) {
-      // row node x of cell (unwrapped) u = i+1 with offset o is column u+o; window column 0 is kW*j
-      auto add = [&](int e, double val) {
-        const unsigned d = (edesc[e / 2] >> (16 * (e & 1))) & 0xffffu;
-        if (d != 0xffffu) unsafeAtomicAdd(&win[(d >> 2) * kSlots + wave + (d & 3)], val);
-      };
+    STAMP(5);
+    if (active && !(FILL_EXP >= 7 && FILL_EXP <= 8)) {
+      // row node x of cell (unwrapped) u = i+1 with offset o is column u+o; window column 0 is kW*j: the lane's element
+      // of accumulator e goes to window byte wdst[e] (+ 8 * wave); elements without a target (currI instructions,
+      // idle blocks) add into a per-lane dummy double behind the window.  No branches, no waits between the atomics.
+      double* wv = win + wave;
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 3; ++r) add((c * 2 + t) * 3 + r, acc[c][t][r]);
-#pragma unroll
-      for (int n = 0; n < 5; ++n) add(18 + n, acc4[n]);
+      for (int e = 0; e < kAcc; ++e) unsafeAtomicAdd((double*)((char*)wv + wdst[e]), acc[e]);
     }
     lds_barrier();
+    STAMP(6);
     // ---- stream out the finished columns (plain RMW, kW consecutive doubles per line), keep 2 in registers
 #pragma unroll
     for (int mm = 0; mm < kOwn; ++mm) {
@@ -469,6 +485,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
         bool any = fst[mm];
 #pragma unroll
         for (int c = 0; c < kW; ++c) any = any || (c < ndone && w[c] != 0.0);
+#if FILL_EXP == 8
+        any = false;
+#endif
         if (any) {
           if (vec) {
 #pragma unroll
@@ -490,8 +509,14 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
         }
       }
     }
+    STAMP(7);
     lds_barrier();
+    STAMP(8);
   }
+#ifdef FILL_STAMPS
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 9; ++k) atomicAdd(&g_fill_stamps[k], stamp_acc_[k]);
+#endif
 
   // ---- the two columns still carried are x = nx, nx+1 = 0, 1 (periodic): columns this workgroup has
   // already written, so they are added with atomics (2 of nx columns)
@@ -513,6 +538,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
 // ecsim::Simulation::fill_matrix_indices (src/impls/ecsim/simulation.cpp:408-464).
 //   etab[i36*36 + j36] = (line << 2) | (row x offset + 1), or -1 for a structural zero (|d| = 2, same comp.)
 //   linetab[line]      = c | (row dy + 1) << 2 | (row dz + 1) << 4 | k << 6
+//   dtab[e*64 + lane]  = where the kernel's merge adds lane's element of accumulator e: byte offset inside the window
 int build_ltab(xpic_ctx* c)
 {
   std::vector<int> etab(36 * 36, -1), linetab(kLines, 0);
@@ -573,11 +599,49 @@ int build_ltab(xpic_ctx* c)
       cowr[l * 8 + n++] = (oy + 8) | ((oz + 8) << 8);
     }
   }
-  const size_t total = etab.size() + linetab.size() + cowr.size();
+  // per-lane flush descriptors of the 36 accumulators: D[b][i][j] of a 4x4x4 instruction sits at lane 16 i + 4 b + j
+  auto curdesc = [&](int row) {
+    const int cc = row / 12;
+    int o[3];
+    block_node_offset(cc, row % 12, o);
+    const int id = cc == 0 ? o[2] * 2 + o[1] : (cc == 1 ? 4 + o[2] * 3 + (o[1] + 1) : 10 + (o[2] + 1) * 2 + o[1]);
+    return ((kMatLines + id) << 2) | (o[0] + 1);
+  };
+  // stored as the byte offset inside the merge window [kLines][kSlots] (column = row x offset + 1, the wave adds its
+  // own cell's column); elements without a target point at a per-lane dummy double behind the window
+  std::vector<unsigned> dtab(kAcc * 64);
+  for (int e = 0; e < kAcc; ++e)
+    for (int lane = 0; lane < 64; ++lane) dtab[e * 64 + lane] = 8u * (unsigned)(kLines * kSlots + lane);
+  auto wbyte = [](int d) { return 8u * (unsigned)((d >> 2) * kSlots + (d & 3)); };
+  std::vector<int> seen(kAcc, 0);
+  for (int o = 0; o < 8; ++o) {
+    const int ob[3] = {o & 1, (o >> 1) & 1, (o >> 2) & 1};
+    for (int lane = 0; lane < 64; ++lane) {
+      const int i = lane >> 4, b = (lane >> 2) & 3, j = lane & 3;
+      for (int c1 = 0; c1 < 3; ++c1)
+        for (int c2 = 0; c2 < 3; ++c2) {
+          const int row = row_of(c1, ob[c1] + (b >> 1), i), col = row_of(c2, ob[c2] + (b & 1), j);
+          const int d = etab[row * 36 + col];
+          XPIC_CHECK(d >= 0 && d < 0xffff, "an octant block entry has no matL line");
+          const int e = acc_main(c1, c2, o);
+          XPIC_CHECK(!seen[e] || dtab[e * 64 + lane] == wbyte(d), "accumulator variants are inconsistent");
+          dtab[e * 64 + lane] = wbyte(d);
+        }
+      if (j == 0) {
+        const int c1 = b >> 1;
+        dtab[acc_cur1(o) * 64 + lane] = wbyte(curdesc(row_of(c1, ob[c1] + (b & 1), i)));
+        if (b < 2) dtab[acc_cur2(o) * 64 + lane] = wbyte(curdesc(row_of(2, ob[2] + b, i)));
+      }
+    }
+    for (int c1 = 0; c1 < 3; ++c1)
+      for (int c2 = 0; c2 < 3; ++c2) seen[acc_main(c1, c2, o)] = 1;
+  }
+  static_assert((kLines * kSlots + 64) <= kW * kStage, "the dummy doubles must lie inside the stage area");
+  const size_t total = linetab.size() + cowr.size() + dtab.size();
   XPIC_HIP(hipMalloc(&c->ltab, sizeof(int) * total));
-  XPIC_HIP(hipMemcpy(c->ltab, etab.data(), sizeof(int) * etab.size(), hipMemcpyHostToDevice));
-  XPIC_HIP(hipMemcpy(c->ltab + etab.size(), linetab.data(), sizeof(int) * linetab.size(), hipMemcpyHostToDevice));
-  XPIC_HIP(hipMemcpy(c->ltab + etab.size() + linetab.size(), cowr.data(), sizeof(int) * cowr.size(), hipMemcpyHostToDevice));
+  XPIC_HIP(hipMemcpy(c->ltab, linetab.data(), sizeof(int) * linetab.size(), hipMemcpyHostToDevice));
+  XPIC_HIP(hipMemcpy(c->ltab + linetab.size(), cowr.data(), sizeof(int) * cowr.size(), hipMemcpyHostToDevice));
+  XPIC_HIP(hipMemcpy(c->ltab + linetab.size() + cowr.size(), dtab.data(), sizeof(unsigned) * dtab.size(), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -615,7 +679,7 @@ int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, d
       if (ncy == 0 || ncz == 0) continue;
       Timed t(c, "fill_current"); // one entry per colour launch: the average is the kernel's own launch duration
       hipLaunchKernelGGL(k_ecsim_fill, dim3((unsigned)(ncy * ncz)), dim3(kThreads), 0, c->stream, g, s.d, B,
-        currI_sort, matL, c->ltab, c->ltab + 36 * 36, c->ltab + 36 * 36 + kLines, s.par.q, s.par.m,
+        currI_sort, matL, (const unsigned*)(c->ltab + kLines + kLines * 8), c->ltab, c->ltab + kLines, s.par.q, s.par.m,
         s.par.n / (double)s.par.Np, cy0, cys, ncy, cz0, czs, b * ncol_y + a, ncol_y, per_y, per_z, first_sort ? 1 : 0);
     }
   XPIC_HIP(hipGetLastError());
