@@ -5,17 +5,21 @@
 // with Shape (src/utils/shape.cpp:31-80), SimpleInterpolation (src/algorithms/simple_interpolation.cpp:8-38)
 // and EsirkepovDecomposition (src/algorithms/esirkepov_decomposition.cpp:20-103) for cell-sorted SoA particles.
 //
-// A workgroup owns 4 consecutive cells in x (one wave per cell).  A particle that starts in cell c and moves
-// at most one cell (the reference's own limit: a larger move overflows its shape[384] scratch, shape.h:18,91-92)
-// touches nodes c-2 .. c+3 per axis only, so
-//   * the E/B nodes the 2nd-order gather can need are staged once per workgroup in an LDS tile (9 x 6 x 6 nodes);
-//   * phase 1 (lane = particle) moves/pushes the particle and stages its 1-D old/new spline values on those
-//     6 nodes per axis (zero outside the support, exactly as spline_of_2nd_order returns);
-//   * phase 2 (lane = two of the 108 "lines" of the cell: a line is one (component, two transverse node
-//     indices) and runs along the component's own axis) rebuilds the reference's running sums
-//     temp_j[line] = temp_j[line] + W (:57-103) in registers, particle after particle: the J of the whole cell
-//     accumulates with no atomics at all;
-//   * the 4 cells' lines are merged in an LDS J tile and leave with one fp64 atomic per tile node, in x-runs.
+// A workgroup owns 4 consecutive cells in x (one wave per cell).
+//   * phase 1 (lane = particle) moves / pushes the particle.  MODE 0 gathers E, B with the 2nd-order shape out of an
+//     LDS tile of the 9 x 6 x 6 nodes the workgroup's particles can reach at mid-step (only the three nodes per axis
+//     and weight type that spline_of_2nd_order does not return as exact zeros: the sums are bitwise those of the
+//     reference's loop over its 3..4-wide box); MODE 2 gathers with the CIC weights out of the cell's 36 + 54 value
+//     neighbourhood in LDS, like k_second_push.
+//   * A particle that starts in cell c and ends less than about half a cell away (every particle of the BASELINE
+//     workloads) has old and new spline supports inside the nodes c-1 .. c+2 of each axis.  For those the deposit is
+//     the dense 4 x 4 x 4 box per component: phase 1 stages the 1-D old / new spline values and the prefix sums of
+//     their differences on these 4 nodes; in phase 2 lane = one of the 48 "lines" of the cell (component, two
+//     transverse node indices), which adds  P_c[t] * T  to its 4 nodes particle after particle -- the reference's
+//     running sum temp_j += W (:57-103) with the sum over the line taken first.  No atomics inside a cell.
+//   * A particle that moves further (up to the reference's own limit of one cell, shape.h:18,91-92) deposits its box
+//     directly with fp64 atomics (slow path, same arithmetic as the reference's loop).
+//   * The 4 cells' lines are merged in an LDS J tile (7 x 4 x 4 nodes) and leave with one fp64 atomic per tile node.
 #include <cstring>
 
 #include "common.h"
@@ -28,11 +32,15 @@ namespace {
 constexpr int kBW = 4;            // cells (waves) per workgroup along x
 constexpr int kBC = 32;           // particles staged per pass and wave
 constexpr int kBPad = kBC + 1;
-constexpr int kT = 6;             // nodes per axis a cell's particles can touch: c-2 .. c+3
-constexpr int kTX = kBW + kT - 1; // tile nodes along x
-constexpr int kSRows = 54;        // So[3][6], Sn[3][6], D[3][6]
+constexpr int kD = 4;             // deposit box per axis: nodes c-1 .. c+2
+constexpr int kJX = kBW + kD - 1; // J tile nodes along x
+constexpr int kJN = kJX * kD * kD;
+constexpr int kSRows = 36;        // So[3][4], Sn[3][4], P[3][4]
+constexpr int kT = 6;             // gather tile per axis (MODE 0): nodes c-2 .. c+3
+constexpr int kTX = kBW + kT - 1;
+constexpr int kTileN = kTX * kT * kT;
 constexpr int kThreadsB = kBW * 64;
-constexpr int kTileN = kTX * kT * kT; // nodes of the workgroup tile
+constexpr int kLinesB = 3 * kD * kD; // 48 lines of 4 nodes
 
 __device__ inline void wave_sync_b()
 {
@@ -55,6 +63,15 @@ __device__ inline double wave_sum_b(double v)
   return v;
 }
 
+// value of lane `src` (wave-uniform) for every lane: v_readlane on the two halves
+__device__ inline double lane_value(double v, int src)
+{
+  const long long x = __builtin_bit_cast(long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)x, src);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(x >> 32), src);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | lo);
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(kThreadsB) k_esirkepov_push(GridDev g, SortDev s, const double* __restrict__ E,
   const double* __restrict__ B, double* __restrict__ J, double qm, double alpha, double qn_Np, double* pred_w,
@@ -71,10 +88,12 @@ __global__ void __launch_bounds__(kThreadsB) k_esirkepov_push(GridDev g, SortDev
   const bool active = cx < g.nx;
 
   __shared__ double stage[kBW][kSRows * kBPad];
-  __shared__ double jtile[3 * kTileN];
-  __shared__ double ftile[MODE == 0 ? 6 * kTileN : 1]; // Ex,Ey,Ez,Bx,By,Bz on the tile nodes (basic only)
+  __shared__ double jtile[3 * kJN];
+  __shared__ double ftile[MODE == 0 ? 6 * kTileN : 1];   // Ex,Ey,Ez,Bx,By,Bz on the gather tile (basic only)
+  __shared__ double nbE[MODE == 2 ? kBW : 1][36], nbB[MODE == 2 ? kBW : 1][54]; // CIC neighbourhoods (second_push only)
+  __shared__ double pwsum[kBW];
 
-  for (int t = threadIdx.x; t < 3 * kTileN; t += kThreadsB) jtile[t] = 0.0;
+  for (int t = threadIdx.x; t < 3 * kJN; t += kThreadsB) jtile[t] = 0.0;
   if (MODE == 0) {
     // DMGlobalToLocal(E), (B) (basic/simulation.cpp:56-57) for just the nodes this workgroup can gather from
     for (int t = threadIdx.x; t < 6 * kTileN; t += kThreadsB) {
@@ -84,13 +103,27 @@ __global__ void __launch_bounds__(kThreadsB) k_esirkepov_push(GridDev g, SortDev
       ftile[t] = F[g.nodew(cx0 - 2 + tx, cy - 2 + ty, cz - 2 + tz)];
     }
   }
+  if (MODE == 2 && active) {
+    // the cell's 36 E and 54 B values of interpolate_E_s1 / interpolate_B_s1 (numbering as in k_second_push)
+    if (lane < 36) {
+      const int ec = lane / 12, l = lane % 12;
+      int eo[3];
+      if (ec == 0) { eo[0] = l % 3 - 1; eo[1] = (l / 3) % 2; eo[2] = l / 6; }
+      else if (ec == 1) { eo[0] = l % 2; eo[1] = (l / 2) % 3 - 1; eo[2] = l / 6; }
+      else { eo[0] = l % 2; eo[1] = (l / 2) % 2; eo[2] = l / 4 - 1; }
+      nbE[wave][lane] = E[ec * g.cstride + g.nodew(cx + eo[0], cy + eo[1], cz + eo[2])];
+    }
+    if (lane < 54) {
+      int bc, bo[3];
+      if (lane < 18) { bc = 0; bo[0] = lane % 2; bo[1] = (lane / 2) % 3 - 1; bo[2] = lane / 6 - 1; }
+      else if (lane < 36) { const int l = lane - 18; bc = 1; bo[0] = l % 3 - 1; bo[1] = (l / 3) % 2; bo[2] = l / 6 - 1; }
+      else { const int l = lane - 36; bc = 2; bo[0] = l % 3 - 1; bo[1] = (l / 3) % 3 - 1; bo[2] = l / 9; }
+      nbB[wave][lane] = B[bc * g.cstride + g.nodew(cx + bo[0], cy + bo[1], cz + bo[2])];
+    }
+  }
   __syncthreads();
 
-  double acc[2][kT];
-#pragma unroll
-  for (int r = 0; r < 2; ++r)
-#pragma unroll
-    for (int t = 0; t < kT; ++t) acc[r][t] = 0.0;
+  double acc[kD] = {0.0, 0.0, 0.0, 0.0};
   double pw = 0.0;
   int bad = 0;
   double* st = stage[wave];
@@ -98,16 +131,18 @@ __global__ void __launch_bounds__(kThreadsB) k_esirkepov_push(GridDev g, SortDev
   const double dd[3] = {g.dx, g.dy, g.dz};
   const int cc[3] = {cx, cy, cz + g.z0};
 
-  // the two lines of this lane
-  int lcomp[2], lu[2], lw[2];
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int l = lane + r * 54;
-    lcomp[r] = l / 36;
-    lu[r] = (l % 36) % kT;
-    lw[r] = (l % 36) / kT;
-  }
-  const bool has_lines = lane < 54;
+  // the line of this lane: component c along its own axis; transverse axes (A, B) with the reference's roles
+  //   X: A = y, B = z   get_jx :57-71      Y: A = x, B = z   get_jy :73-87      Z: A = y, B = x   get_jz :89-103
+  const bool has_line = lane < kLinesB;
+  const int lc = has_line ? lane / (kD * kD) : 0;
+  const int liA = (lane % (kD * kD)) % kD, liB = (lane % (kD * kD)) / kD;
+  const int axA = lc == 1 ? 0 : 1, axB = lc == 2 ? 0 : 2;
+  const double qd = alpha * (lc == 0 ? g.dx : (lc == 1 ? g.dy : g.dz));
+  const double* soA = st + (axA * kD + liA) * kBPad;
+  const double* snA = st + (12 + axA * kD + liA) * kBPad;
+  const double* soB = st + (axB * kD + liB) * kBPad;
+  const double* snB = st + (12 + axB * kD + liB) * kBPad;
+  const double* pC = st + (24 + lc * kD) * kBPad;
 
   if (active) {
     const long cell = ((long)cz * g.ny + cy) * g.nx + cx;
@@ -116,6 +151,10 @@ __global__ void __launch_bounds__(kThreadsB) k_esirkepov_push(GridDev g, SortDev
     for (int base = 0; base < cnt; base += kBC) {
       const int mcnt = min(kBC, cnt - base);
       wave_sync_b();
+      // a particle whose old / new supports leave the cell's 4-node box: deposited by the whole wave further down
+      bool slow = false;
+      double po[3] = {0, 0, 0}, pn[3] = {0, 0, 0};
+      int sst[3] = {0, 0, 0}, ssz[3] = {0, 0, 0};
       if (lane < mcnt) {
         const long p = (long)start + base + lane;
         double r[3] = {s.r[0][p], s.r[1][p], s.r[2][p]};
@@ -127,42 +166,44 @@ __global__ void __launch_bounds__(kThreadsB) k_esirkepov_push(GridDev g, SortDev
           // push.update_r(dt / 2) ; shape.setup(point.r) ; interpolation.process   (basic/particles.cpp:31-38)
 #pragma unroll
           for (int a = 0; a < 3; ++a) r[a] += v[a] * (dt / 2.0);
-          int sst[3], ssz[3];
-          double No[3][4], Sh[3][4];
+          // Shape::make_start / make_end (shape.cpp:12-28) give the box [sst, sst + ssz), ssz = 3 or 4.  Inside it
+          // spline_of_2nd_order is an exact zero outside three nodes: for the node-centred weights ("No") those are
+          // sst + nN .. sst + nN + 2 with nN = 0 or 1, for the half-shifted ones ("Sh") always sst .. sst + 2.
+          int off[3], nN[3];
+          double No[3][3], Sh[3][3];
           bool inside = true;
 #pragma unroll
           for (int a = 0; a < 3; ++a) {
             const double pr = r[a] / dd[a];
-            sst[a] = (int)round(pr - 1.5);               // Shape::make_start, shape.cpp:12-19
-            ssz[a] = (int)floor(pr + 1.5) + 1 - sst[a];  // Shape::make_end, :21-28
-            inside = inside && sst[a] >= cc[a] - 2 && sst[a] + ssz[a] <= cc[a] + 4;
+            const int sst = (int)round(pr - 1.5);
+            const int ssz = (int)floor(pr + 1.5) + 1 - sst;
+            inside = inside && sst >= cc[a] - 2 && sst + ssz <= cc[a] + 4;
+            nN[a] = (pr - (double)sst) < 1.5 ? 0 : 1; // node sst has |pr - sst| < 1.5, or node sst + 3 may have
+            off[a] = sst - (cc[a] - 2);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const double gx = (double)(sst[a] + t);
-              No[a][t] = spline2(pr - gx);               // Shape::fill, :57-80
-              Sh[a][t] = spline2(pr - (gx + 0.5));
+            for (int t = 0; t < 3; ++t) {
+              No[a][t] = spline2(pr - (double)(sst + nN[a] + t));  // Shape::fill, :57-80
+              Sh[a][t] = spline2(pr - ((double)(sst + t) + 0.5));
             }
           }
           if (inside) {
-            const int ox = sst[0] - (cx0 - 2), oy = sst[1] - (cy - 2), oz = sst[2] - (cz + g.z0 - 2);
-            // the reference's loop order (x fastest, then y, z); at most 4 nodes per axis, fully unrolled so that
-            // the weight arrays stay in registers
+            off[0] += wave; // tile x origin is cx0 - 2, the cell's own is cx - 2
+            // the reference's loop order (x fastest, then y, z), zero terms left out
+            const int bN[3] = {off[0] + nN[0], off[1] + nN[1], off[2] + nN[2]};
 #pragma unroll
-            for (int kz = 0; kz < 4; ++kz)
+            for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
-              for (int jy = 0; jy < 4; ++jy)
+              for (int jy = 0; jy < 3; ++jy)
 #pragma unroll
-                for (int ix = 0; ix < 4; ++ix) {
-                  if (kz < ssz[2] && jy < ssz[1] && ix < ssz[0]) {
-                    const int n = ((oz + kz) * kT + (oy + jy)) * kTX + (ox + ix);
-                    // Shape::electric / magnetic (shape.h:54-72)
-                    Ep[0] += ftile[0 * kTileN + n] * (No[2][kz] * No[1][jy] * Sh[0][ix]);
-                    Ep[1] += ftile[1 * kTileN + n] * (No[2][kz] * Sh[1][jy] * No[0][ix]);
-                    Ep[2] += ftile[2 * kTileN + n] * (Sh[2][kz] * No[1][jy] * No[0][ix]);
-                    Bp[0] += ftile[3 * kTileN + n] * (Sh[2][kz] * Sh[1][jy] * No[0][ix]);
-                    Bp[1] += ftile[4 * kTileN + n] * (Sh[2][kz] * No[1][jy] * Sh[0][ix]);
-                    Bp[2] += ftile[5 * kTileN + n] * (No[2][kz] * Sh[1][jy] * Sh[0][ix]);
-                  }
+                for (int ix = 0; ix < 3; ++ix) {
+                  // Shape::electric / magnetic (shape.h:54-72): each component has its own three nodes per axis
+                  const int zN = bN[2] + kz, zS = off[2] + kz, yN = bN[1] + jy, yS = off[1] + jy, xN = bN[0] + ix, xS = off[0] + ix;
+                  Ep[0] += ftile[0 * kTileN + (zN * kT + yN) * kTX + xS] * (No[2][kz] * No[1][jy] * Sh[0][ix]);
+                  Ep[1] += ftile[1 * kTileN + (zN * kT + yS) * kTX + xN] * (No[2][kz] * Sh[1][jy] * No[0][ix]);
+                  Ep[2] += ftile[2 * kTileN + (zS * kT + yN) * kTX + xN] * (Sh[2][kz] * No[1][jy] * No[0][ix]);
+                  Bp[0] += ftile[3 * kTileN + (zS * kT + yS) * kTX + xN] * (Sh[2][kz] * Sh[1][jy] * No[0][ix]);
+                  Bp[1] += ftile[4 * kTileN + (zS * kT + yN) * kTX + xS] * (Sh[2][kz] * No[1][jy] * Sh[0][ix]);
+                  Bp[2] += ftile[5 * kTileN + (zN * kT + yS) * kTX + xS] * (No[2][kz] * Sh[1][jy] * Sh[0][ix]);
                 }
           }
           // else: the particle moved further than the reference itself supports; flagged by the range test below
@@ -175,10 +216,26 @@ __global__ void __launch_bounds__(kThreadsB) k_esirkepov_push(GridDev g, SortDev
           for (int a = 0; a < 3; ++a) r[a] += v[a] * (0.5 * dt); // BorisPush::update_r(0.5 * dt)  ecsimcorr/particles.cpp:39
         }
         else {
-          // interpolate_E_s1 / interpolate_B_s1 ; update_vEB(dt) ; update_r(0.5 dt)   (:64-69)
+          // interpolate_E_s1 / interpolate_B_s1 ; update_vEB(dt) ; update_r(0.5 dt)   (:64-69), gathers out of the
+          // cell's LDS neighbourhood in the loop and product order of ecsim/simulation.cpp:8-118
           const double old_v[3] = {v[0], v[1], v[2]};
           const W1 w(g, r[0], r[1], r[2]);
-          gather_s1(g, E, B, w, Ep, Bp);
+          const int ox = w.is[0] - w.in[0] + 1, oy = w.is[1] - w.in[1] + 1, oz = w.is[2] - w.in[2] + 1;
+          const double* eE = nbE[MODE == 2 ? wave : 0];
+          const double* eB = nbB[MODE == 2 ? wave : 0];
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int i = 0; i < 2; ++i) {
+                Ep[0] += eE[(k * 2 + j) * 3 + (ox + i)] * (w.wn[2][k] * w.wn[1][j] * w.ws[0][i]);
+                Ep[1] += eE[12 + (k * 3 + (oy + j)) * 2 + i] * (w.wn[2][k] * w.ws[1][j] * w.wn[0][i]);
+                Ep[2] += eE[24 + ((oz + k) * 2 + j) * 2 + i] * (w.ws[2][k] * w.wn[1][j] * w.wn[0][i]);
+                Bp[0] += eB[((oz + k) * 3 + (oy + j)) * 2 + i] * (w.ws[2][k] * w.ws[1][j] * w.wn[0][i]);
+                Bp[1] += eB[18 + ((oz + k) * 2 + j) * 3 + (ox + i)] * (w.ws[2][k] * w.wn[1][j] * w.ws[0][i]);
+                Bp[2] += eB[36 + (k * 3 + (oy + j)) * 3 + (ox + i)] * (w.wn[2][k] * w.ws[1][j] * w.ws[0][i]);
+              }
           update_vEB(dt, qm, Ep, Bp, v);
 #pragma unroll
           for (int a = 0; a < 3; ++a) r[a] += v[a] * (0.5 * dt);
@@ -191,101 +248,136 @@ __global__ void __launch_bounds__(kThreadsB) k_esirkepov_push(GridDev g, SortDev
           if (MODE != 1) s.v[a][p] = v[a];
         }
 
-        // Shape::setup(old_r, new_r) (shape.cpp:43-54): range test, then the 1-D spline values on the 6 tile nodes
-        bool ok = true;
-        double* col = st + lane;
+        // Shape::setup(old_r, new_r) (shape.cpp:43-54): the box [sst, send) of the pair per axis
+        bool ok = true, fast = true;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-          const double po = old_r[a] / dd[a], pn = r[a] / dd[a];
-          const int sst = (int)round(fmin(po, pn) - 1.5);
-          const int send = (int)floor(fmax(po, pn) + 1.5) + 1;
-          ok = ok && (send - sst <= 4) && sst >= cc[a] - 2 && send <= cc[a] + 4;
+          po[a] = old_r[a] / dd[a];
+          pn[a] = r[a] / dd[a];
+          sst[a] = (int)round(fmin(po[a], pn[a]) - 1.5);
+          const int send = (int)floor(fmax(po[a], pn[a]) + 1.5) + 1;
+          ssz[a] = send - sst[a];
+          ok = ok && ssz[a] <= 4;                                       // the reference's Shape::shape[] limit
+          fast = fast && sst[a] >= cc[a] - 1 && send <= cc[a] + 3;      // inside the cell's dense 4-node box
+        }
+        double* col = st + lane;
+        if (ok && fast) {
+          // old / new spline values on the nodes c-1 .. c+2 (exact zeros outside the support, as the reference's loop
+          // sees them) and the prefix sums of their differences along each axis
 #pragma unroll
-          for (int t = 0; t < kT; ++t) {
-            const double gx = (double)(cc[a] - 2 + t);
-            const double so = spline2(po - gx), sn = spline2(pn - gx);
-            col[(a * kT + t) * kBPad] = so;
-            col[(18 + a * kT + t) * kBPad] = sn;
-            col[(36 + a * kT + t) * kBPad] = sn - so;
+          for (int a = 0; a < 3; ++a) {
+            double run = 0.0;
+#pragma unroll
+            for (int t = 0; t < kD; ++t) {
+              const double gx = (double)(cc[a] - 1 + t);
+              const double so = spline2(po[a] - gx), sn = spline2(pn[a] - gx);
+              run += sn - so;
+              col[(a * kD + t) * kBPad] = so;
+              col[(12 + a * kD + t) * kBPad] = sn;
+              col[(24 + a * kD + t) * kBPad] = run;
+            }
           }
         }
-        if (!ok) {
-          // the reference would overflow Shape::shape here; deposit nothing and report
-          ++bad;
+        else {
 #pragma unroll
-          for (int e = 0; e < kSRows; ++e) col[e * kBPad] = 0.0;
+          for (int e = 0; e < kSRows; ++e) col[e * kBPad] = 0.0; // nothing for phase 2
+          if (ok) slow = true;
+          else ++bad; // the reference would overflow Shape::shape here; deposit nothing and report
+        }
+      }
+      // ---- slow path (rare): EsirkepovDecomposition::process of ONE particle by the 48 line lanes, on the particle's
+      // own box [sst, sst + ssz) (Shape::setup(old, new), shape.cpp:43-54), straight to the global J with fp64 atomics.
+      // Same terms and running sums as :57-103.
+      for (unsigned long long sm = __ballot(slow); sm; sm &= sm - 1) {
+        const int src = __ffsll((long long)sm) - 1;
+        double qo[3], qn[3];
+        int qs[3], qz[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          qo[a] = lane_value(po[a], src);
+          qn[a] = lane_value(pn[a], src);
+          qs[a] = __builtin_amdgcn_readlane(sst[a], src);
+          qz[a] = __builtin_amdgcn_readlane(ssz[a], src);
+        }
+        if (has_line && liA < qz[axA] && liB < qz[axB]) {
+          const double gA = (double)(qs[axA] + liA), gB = (double)(qs[axB] + liB);
+          const double sA_o = spline2(qo[axA] - gA), sA_n = spline2(qn[axA] - gA);
+          const double sB_o = spline2(qo[axB] - gB), sB_n = spline2(qn[axB] - gB);
+          const double T = sA_n * (2.0 * sB_n + sB_o) + sA_o * (2.0 * sB_o + sB_n);
+          double run = 0.0;
+          for (int t = 0; t < qz[lc]; ++t) {
+            const double gC = (double)(qs[lc] + t);
+            run = run + (-qd * (spline2(qn[lc] - gC) - spline2(qo[lc] - gC)) * T);
+            int n[3];
+            n[lc] = qs[lc] + t; n[axA] = qs[axA] + liA; n[axB] = qs[axB] + liB;
+            if (run != 0.0) unsafeAtomicAdd(&J[lc * g.cstride + g.nodew(n[0], n[1], n[2] - g.z0)], run);
+          }
         }
       }
       wave_sync_b();
 
-      if (has_lines) {
+      if (has_line) {
+        // J_c[t][iA][iB] += P_c[t] * T,  T = -qd (Sn_A (2 Sn_B + So_B) + So_A (2 So_B + Sn_B))
+#pragma unroll 4
+        for (int p = 0; p < mcnt; ++p) {
+          const double T = -qd * (snA[p] * (2.0 * snB[p] + soB[p]) + soA[p] * (2.0 * soB[p] + snB[p]));
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-          // component c runs along its own axis c; transverse axes (A, B) with the reference's roles:
-          //   X: A = y (index u), B = z (index w)   get_jx :57-71
-          //   Y: A = x (index u), B = z (index w)   get_jy :73-87
-          //   Z: A = y (index w), B = x (index u)   get_jz :89-103
-          const int c = lcomp[rr];
-          const int axA = c == 1 ? 0 : 1, axB = c == 2 ? 0 : 2;
-          const int iA = c == 2 ? lw[rr] : lu[rr], iB = c == 2 ? lu[rr] : lw[rr];
-          const double qd = alpha * (c == 0 ? g.dx : (c == 1 ? g.dy : g.dz));
-          const double* soA = st + (axA * kT + iA) * kBPad;
-          const double* snA = st + (18 + axA * kT + iA) * kBPad;
-          const double* soB = st + (axB * kT + iB) * kBPad;
-          const double* snB = st + (18 + axB * kT + iB) * kBPad;
-          const double* dC = st + (36 + c * kT) * kBPad;
-          for (int p = 0; p < mcnt; ++p) {
-            // W = -qd * D_c[t] * T with T = Sn_A (2 Sn_B + So_B) + So_A (2 So_B + Sn_B): the factor common to the six
-            // nodes of the line is formed once (one rounding apart from the reference's (-qd * D) * T)
-            const double T = -qd * (snA[p] * (2.0 * snB[p] + soB[p]) + soA[p] * (2.0 * soB[p] + snB[p]));
-            double run = 0.0;
-#pragma unroll
-            for (int t = 0; t < kT; ++t) {
-              run = run + dC[t * kBPad + p] * T; // temp_j = temp_j + w_p
-              acc[rr][t] += run;
-            }
-          }
+          for (int t = 0; t < kD; ++t) acc[t] += pC[t * kBPad + p] * T;
         }
       }
     }
   }
 
+  if (MODE == 2) {
+    pw = wave_sum_b(pw);
+    if (lane == 0) pwsum[wave] = pw;
+  }
   // ---- merge the workgroup's cells in the LDS J tile, then one atomic per tile node
-  __syncthreads();
-  if (active && has_lines) {
+  if (active && has_line) {
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const int c = lcomp[rr];
-#pragma unroll
-      for (int t = 0; t < kT; ++t) {
-        int tx, ty, tz;
-        if (c == 0) { tx = wave + t; ty = lu[rr]; tz = lw[rr]; }
-        else if (c == 1) { tx = wave + lu[rr]; ty = t; tz = lw[rr]; }
-        else { tx = wave + lu[rr]; ty = lw[rr]; tz = t; }
-        if (acc[rr][t] != 0.0) unsafeAtomicAdd(&jtile[c * kTileN + (tz * kT + ty) * kTX + tx], acc[rr][t]);
-      }
+    for (int t = 0; t < kD; ++t) {
+      int tx, ty, tz;
+      if (lc == 0) { tx = wave + t; ty = liA; tz = liB; }
+      else if (lc == 1) { tx = wave + liA; ty = t; tz = liB; }
+      else { tx = wave + liB; ty = liA; tz = t; }
+      if (acc[t] != 0.0) unsafeAtomicAdd(&jtile[lc * kJN + (tz * kD + ty) * kJX + tx], acc[t]);
     }
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < 3 * kTileN; t += kThreadsB) {
+  for (int t = threadIdx.x; t < 3 * kJN; t += kThreadsB) {
     const double val = jtile[t];
     if (val == 0.0) continue;
-    const int c = t / kTileN, n = t % kTileN;
-    const int tx = n % kTX, ty = (n / kTX) % kT, tz = n / (kTX * kT);
-    unsafeAtomicAdd(&J[c * g.cstride + g.nodew(cx0 - 2 + tx, cy - 2 + ty, cz - 2 + tz)], val);
+    const int c = t / kJN, n = t % kJN;
+    const int tx = n % kJX, ty = (n / kJX) % kD, tz = n / (kJX * kD);
+    unsafeAtomicAdd(&J[c * g.cstride + g.nodew(cx0 - 1 + tx, cy - 1 + ty, cz - 1 + tz)], val);
   }
-  if (MODE == 2) {
-    pw = wave_sum_b(pw);
-    if (lane == 0 && pw != 0.0) unsafeAtomicAdd(pred_w, pw);
-  }
+  // pred_w: one partial per workgroup, summed by k_sum_partials in a fixed order (2 M atomics on one address would
+  // cost more than the whole push)
+  if (MODE == 2 && threadIdx.x == 0) pred_w[blockIdx.x] = (pwsum[0] + pwsum[1]) + (pwsum[2] + pwsum[3]);
   if (bad) atomicAdd(bad_count, bad);
+}
+
+// deterministic sum of n doubles by one workgroup
+__global__ void __launch_bounds__(1024) k_sum_partials(const double* __restrict__ part, long n, double* out)
+{
+  double v = 0.0;
+  for (long i = threadIdx.x; i < n; i += 1024) v += part[i];
+  __shared__ double sm[16];
+  v = wave_sum_b(v);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += sm[w];
+    *out = t;
+  }
 }
 
 }  // namespace
 
 int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double* B, double* J, double* pred_w_host)
-{  s.prebinned = false;
-
+{
+  s.prebinned = false;
   if (pred_w_host) *pred_w_host = 0.0;
   if (s.n == 0) {
     // an empty slab still takes part in the collective (pred_w and the error count)
@@ -314,7 +406,12 @@ int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double
     dim3 grid((unsigned)nblocks), block(kThreadsB);
     if (mode == 0) hipLaunchKernelGGL(k_esirkepov_push<0>, grid, block, 0, c->stream, g, s.d, E, B, J, qm, alpha, qn_Np, scal, (int*)(scal + 1));
     else if (mode == 1) hipLaunchKernelGGL(k_esirkepov_push<1>, grid, block, 0, c->stream, g, s.d, E, B, J, qm, alpha, qn_Np, scal, (int*)(scal + 1));
-    else hipLaunchKernelGGL(k_esirkepov_push<2>, grid, block, 0, c->stream, g, s.d, E, B, J, qm, alpha, qn_Np, scal, (int*)(scal + 1));
+    else {
+      // per-workgroup pred_w partials go to the (idle) Krylov work vector: nblocks <= cells < 3 * cells doubles
+      XPIC_CHECK(c->kry_w, "second_push needs the ecsimcorr scheme's work vectors");
+      hipLaunchKernelGGL(k_esirkepov_push<2>, grid, block, 0, c->stream, g, s.d, E, B, J, qm, alpha, qn_Np, c->kry_w, (int*)(scal + 1));
+      hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, c->stream, c->kry_w, nblocks, scal);
+    }
     XPIC_HIP(hipGetLastError());
   }
   XPIC_HIP(hipMemcpyAsync(c->red_host, scal, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
