@@ -266,9 +266,11 @@ int xpic_create(const xpic_geometry* geom, int scheme, xpic_ctx** out)
   g.G = (geom->nranks > 1 || geom->self_ring) ? 3 : 0;
   g.nzs = g.nzl + 2 * g.G;
   g.dx = geom->d[0]; g.dy = geom->d[1]; g.dz = geom->d[2]; g.dt = geom->dt;
+  g.pow2 = 1;
   for (int a = 0; a < 3; ++a) {
     int ex;
-    g.inv_exact[a] = std::frexp(geom->d[a], &ex) == 0.5 ? 1.0 / geom->d[a] : 0.0;
+    g.inv[a] = 1.0 / geom->d[a];
+    if (std::frexp(geom->d[a], &ex) != 0.5) g.pow2 = 0;
   }
   g.Lx = g.nx * g.dx; g.Ly = g.ny * g.dy; g.Lz = g.nzg * g.dz;
   g.plane = (long)g.nx * g.ny;

@@ -57,9 +57,10 @@ struct GridDev {
   int G;           // ghost planes on each side
   int nzs;         // stored planes
   double dx, dy, dz, dt;
-  // 1 / spacing where that is exact (the spacing is a power of two: x * inv == x / d bit for bit), else 0: lets the
-  // particle kernels replace the three fp64 divisions per particle by multiplications without changing a result
-  double inv_exact[3];
+  // all three spacings are powers of two: x * inv[a] == x / d[a] bit for bit, and the particle kernels take the
+  // multiplications (a wave-uniform branch) instead of three fp64 divisions per position without changing a result
+  double inv[3];
+  int pow2;
   double Lx, Ly, Lz; // global box (World::set_geometry: geom = n * d, world.cpp:80-91)
   long plane;        // nx*ny
   long cstride;      // nzs*plane

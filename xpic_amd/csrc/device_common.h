@@ -13,25 +13,38 @@ __device__ inline double bound_periodic(double s, double L)
   return s;
 }
 
+// (x / dx, y / dy, z / dz).  P2: all three spacings are powers of two (GridDev::pow2) and the hot kernels are
+// instantiated for that case with the exact multiplication by the reciprocal: the same bits at a fraction of the cost
+// of three fp64 divisions per position.
+template <bool P2 = false>
+__device__ inline void scaled_position(const GridDev& g, double x, double y, double z, double* pn)
+{
+  if (P2) { pn[0] = x * g.inv[0]; pn[1] = y * g.inv[1]; pn[2] = z * g.inv[2]; }
+  else { pn[0] = x / g.dx; pn[1] = y / g.dy; pn[2] = z / g.dz; }
+}
+
 // Local cell of a position: FLOOR_STEP(s, ds) = floor(s / ds) (src/utils/utils.h:78), bounds test of
 // update_cells_seq / add_particle (src/interfaces/particles.cpp:47-67, 90-104).  -1 = outside: dropped.
+template <bool P2 = false>
 __device__ inline int cell_of(const GridDev& g, double x, double y, double z)
 {
-  int cx = (int)floor(x / g.dx), cy = (int)floor(y / g.dy), cz = (int)floor(z / g.dz) - g.z0;
+  double pn[3];
+  scaled_position<P2>(g, x, y, z, pn);
+  int cx = (int)floor(pn[0]), cy = (int)floor(pn[1]), cz = (int)floor(pn[2]) - g.z0;
   if (cx < 0 || cx >= g.nx || cy < 0 || cy >= g.ny || cz < 0 || cz >= g.nzl) return -1;
   return (cz * g.ny + cy) * g.nx + cx;
 }
 
 // ---- CIC weights of ecsim (src/impls/ecsim/simulation.cpp:12-45): node index floor(x/dx), half-shifted
 // index floor(x/dx - 1/2), weights of the upper neighbour = fractional part.
-struct W1 {
+template <bool P2>
+struct W1T {
   int in[3], is[3];
   double wn[3][2], ws[3][2];
-  __device__ inline W1(const GridDev& g, double x, double y, double z)
+  __device__ inline W1T(const GridDev& g, double x, double y, double z)
   {
-    // x / dx; spacings that are powers of two take the exact multiplication (wave-uniform choice)
-    const double pn[3] = {g.inv_exact[0] != 0.0 ? x * g.inv_exact[0] : x / g.dx,
-      g.inv_exact[1] != 0.0 ? y * g.inv_exact[1] : y / g.dy, g.inv_exact[2] != 0.0 ? z * g.inv_exact[2] : z / g.dz};
+    double pn[3];
+    scaled_position<P2>(g, x, y, z, pn);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const double ps = pn[a] - 0.5;
@@ -46,10 +59,12 @@ struct W1 {
     is[2] -= g.z0;
   }
 };
+using W1 = W1T<false>;
 
 // interpolate_E_s1 / interpolate_B_s1 (src/impls/ecsim/simulation.cpp:8-62, 64-118), same loop order
+template <class W>
 __device__ inline void gather_s1(const GridDev& g, const double* __restrict__ E, const double* __restrict__ B,
-  const W1& w, double* Ep, double* Bp)
+  const W& w, double* Ep, double* Bp)
 {
   const double* Ex = E; const double* Ey = E + g.cstride; const double* Ez = E + 2 * g.cstride;
   const double* Bx = B; const double* By = B + g.cstride; const double* Bz = B + 2 * g.cstride;

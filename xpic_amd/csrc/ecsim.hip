@@ -69,7 +69,13 @@ namespace xpic {
 namespace {
 
 constexpr int kW = 4;             // waves per workgroup = cells per chunk
-constexpr int kCP = 48;           // particles staged per pass and wave (Poisson(64) cells: two passes)
+#ifndef FILL_KCP
+#define FILL_KCP 48
+#endif
+#ifndef FILL_OCC
+#define FILL_OCC 2
+#endif
+constexpr int kCP = FILL_KCP;      // particles staged per pass and wave (Poisson(64) cells: two passes)
 // One stage slot = one particle: 24 weights [c][i][h] (i: the 2 x 2 nodes transverse to the component's staggered axis,
 // h: lower / upper node along it), 9 A_p*matB, 3 I_p.  Pitch 42 doubles = 84 dwords: the 16-byte stores of 8
 // consecutive slots fall in 8 distinct bank quads (84 l mod 32 = 0,20,8,28,16,4,24,12) and the operand reads of the
@@ -85,7 +91,7 @@ constexpr int kLines = kMatLines + kCurLines;
 constexpr int kThreads = kW * 64;
 constexpr int kSlots = kW + 2;    // window columns: kW finished + 2 carried
 constexpr int kOwn = (kLines + kThreads - 1) / kThreads; // window lines owned by a thread (init, flush, carry)
-constexpr int kMaxNxLds = 1024;   // pencils up to this length keep their cell_start row in LDS
+constexpr int kMaxNxLds = 512;    // pencils up to this length keep their cell_start row in LDS
 
 // accumulator of the block (c1, c2) for a particle of octant o = ox | oy << 1 | oz << 2: the rows depend on the
 // octant bit of axis c1 only, the columns on that of axis c2
@@ -145,8 +151,9 @@ __device__ inline double load_bnb(const GridDev& g, const double* __restrict__ B
   return B[c * g.cstride + g.nodew(cx + ox, cy + oy, cz + oz)];
 }
 
-__global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s, const double* __restrict__ B,
-  double* currI, double* matL, const unsigned* __restrict__ dtab, const int* __restrict__ linetab, const int* __restrict__ cowr, double q, double m,
+template <bool P2>
+__global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, SortDev s, const double* __restrict__ B,
+  double* currI, double* matL, const unsigned short* __restrict__ dtab, const int* __restrict__ linetab, const int* __restrict__ cowr, double q, double m,
   double mpw, int cy0, int cystep, int ncy, int cz0, int czstep, int my_order, int ncol_y, int per_y, int per_z, int first_sort)
 {
   const int cy = cy0 + (int)(blockIdx.x % ncy) * cystep;
@@ -154,7 +161,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
 
   __shared__ __attribute__((aligned(16))) double sh[kW * kStage];
   __shared__ __attribute__((aligned(16))) double zslot[kPitch]; // the particle of weight zero that fills up a K = 4 step
-  __shared__ unsigned dsc[kAcc * 64]; // byte offset of lane's element of accumulator e inside the merge window
+  __shared__ unsigned short dsc[kAcc * 64]; // offset (in doubles) of lane's element of accumulator e inside the merge window
   __shared__ int cstart[kMaxNxLds + 2];
   __shared__ double bnb[kW][54];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -288,7 +295,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
 #endif
         wave_sync(); // the previous pass's operand reads (and the neighbourhood store) are done
         // CIC weights and the half-cell octant first: the octant decides the particle's stage slot
-        const W1 w(g, real ? cur[0] : 0.0, real ? cur[1] : 0.0, real ? cur[2] : 0.0);
+        const W1T<P2> w(g, real ? cur[0] : 0.0, real ? cur[1] : 0.0, real ? cur[2] : 0.0);
         const int ox = w.is[0] - w.in[0] + 1, oy = w.is[1] - w.in[1] + 1, oz = w.is[2] - w.in[2] + 1;
         const int oct = real ? (ox | (oy << 1) | (oz << 2)) : 8;
         // compaction by octant: the particles of octant o take the stage slots ooff[o] .. ooff[o] + ocnt[o] - 1
@@ -468,7 +475,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
       // idle blocks) add into a per-lane dummy double behind the window.  No branches, no waits between the atomics.
       double* wv = win + wave;
 #pragma unroll
-      for (int e = 0; e < kAcc; ++e) unsafeAtomicAdd((double*)((char*)wv + wdst[e]), acc[e]);
+      for (int e = 0; e < kAcc; ++e) unsafeAtomicAdd(wv + wdst[e], acc[e]);
     }
     lds_barrier();
     STAMP(6);
@@ -538,7 +545,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_ecsim_fill(GridDev g, SortDev s
 // ecsim::Simulation::fill_matrix_indices (src/impls/ecsim/simulation.cpp:408-464).
 //   etab[i36*36 + j36] = (line << 2) | (row x offset + 1), or -1 for a structural zero (|d| = 2, same comp.)
 //   linetab[line]      = c | (row dy + 1) << 2 | (row dz + 1) << 4 | k << 6
-//   dtab[e*64 + lane]  = where the kernel's merge adds lane's element of accumulator e: byte offset inside the window
+//   dtab[e*64 + lane]  = where the kernel's merge adds lane's element of accumulator e: offset inside the window
 int build_ltab(xpic_ctx* c)
 {
   std::vector<int> etab(36 * 36, -1), linetab(kLines, 0);
@@ -607,12 +614,12 @@ int build_ltab(xpic_ctx* c)
     const int id = cc == 0 ? o[2] * 2 + o[1] : (cc == 1 ? 4 + o[2] * 3 + (o[1] + 1) : 10 + (o[2] + 1) * 2 + o[1]);
     return ((kMatLines + id) << 2) | (o[0] + 1);
   };
-  // stored as the byte offset inside the merge window [kLines][kSlots] (column = row x offset + 1, the wave adds its
+  // stored as the offset in doubles inside the merge window [kLines][kSlots] (column = row x offset + 1, the wave adds its
   // own cell's column); elements without a target point at a per-lane dummy double behind the window
-  std::vector<unsigned> dtab(kAcc * 64);
+  std::vector<unsigned short> dtab(kAcc * 64);
   for (int e = 0; e < kAcc; ++e)
-    for (int lane = 0; lane < 64; ++lane) dtab[e * 64 + lane] = 8u * (unsigned)(kLines * kSlots + lane);
-  auto wbyte = [](int d) { return 8u * (unsigned)((d >> 2) * kSlots + (d & 3)); };
+    for (int lane = 0; lane < 64; ++lane) dtab[e * 64 + lane] = (unsigned short)(kLines * kSlots + lane);
+  auto wbyte = [](int d) { return (unsigned short)((d >> 2) * kSlots + (d & 3)); };
   std::vector<int> seen(kAcc, 0);
   for (int o = 0; o < 8; ++o) {
     const int ob[3] = {o & 1, (o >> 1) & 1, (o >> 2) & 1};
@@ -637,11 +644,11 @@ int build_ltab(xpic_ctx* c)
       for (int c2 = 0; c2 < 3; ++c2) seen[acc_main(c1, c2, o)] = 1;
   }
   static_assert((kLines * kSlots + 64) <= kW * kStage, "the dummy doubles must lie inside the stage area");
-  const size_t total = linetab.size() + cowr.size() + dtab.size();
+  const size_t total = linetab.size() + cowr.size() + (dtab.size() + 1) / 2;
   XPIC_HIP(hipMalloc(&c->ltab, sizeof(int) * total));
   XPIC_HIP(hipMemcpy(c->ltab, linetab.data(), sizeof(int) * linetab.size(), hipMemcpyHostToDevice));
   XPIC_HIP(hipMemcpy(c->ltab + linetab.size(), cowr.data(), sizeof(int) * cowr.size(), hipMemcpyHostToDevice));
-  XPIC_HIP(hipMemcpy(c->ltab + linetab.size() + cowr.size(), dtab.data(), sizeof(unsigned) * dtab.size(), hipMemcpyHostToDevice));
+  XPIC_HIP(hipMemcpy(c->ltab + linetab.size() + cowr.size(), dtab.data(), sizeof(unsigned short) * dtab.size(), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -678,8 +685,8 @@ int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, d
       else { cz0 = b; czs = 3; ncz = (g.nzl - b + 2) / 3; }
       if (ncy == 0 || ncz == 0) continue;
       Timed t(c, "fill_current"); // one entry per colour launch: the average is the kernel's own launch duration
-      hipLaunchKernelGGL(k_ecsim_fill, dim3((unsigned)(ncy * ncz)), dim3(kThreads), 0, c->stream, g, s.d, B,
-        currI_sort, matL, (const unsigned*)(c->ltab + kLines + kLines * 8), c->ltab, c->ltab + kLines, s.par.q, s.par.m,
+      hipLaunchKernelGGL(g.pow2 ? k_ecsim_fill<true> : k_ecsim_fill<false>, dim3((unsigned)(ncy * ncz)), dim3(kThreads), 0, c->stream, g, s.d, B,
+        currI_sort, matL, (const unsigned short*)(c->ltab + kLines + kLines * 8), c->ltab, c->ltab + kLines, s.par.q, s.par.m,
         s.par.n / (double)s.par.Np, cy0, cys, ncy, cz0, czs, b * ncol_y + a, ncol_y, per_y, per_z, first_sort ? 1 : 0);
     }
   XPIC_HIP(hipGetLastError());

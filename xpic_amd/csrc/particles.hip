@@ -20,9 +20,12 @@ inline unsigned pgrid(int64_t n, int per_thread = 1)
 // destination of a (moved, wrapped) position in the slab decomposition:
 //   >= 0 local cell, -1 dropped (outside the global box), -2 / -3 owned by the lower / upper z-neighbour,
 //   -4 further away than a neighbour (reported as an error)
+template <bool P2 = false>
 __device__ inline int dest_of(const GridDev& g, int rank, int nranks, double x, double y, double z)
 {
-  const int cx = (int)floor(x / g.dx), cy = (int)floor(y / g.dy), czg = (int)floor(z / g.dz);
+  double pn[3];
+  scaled_position<P2>(g, x, y, z, pn);
+  const int cx = (int)floor(pn[0]), cy = (int)floor(pn[1]), czg = (int)floor(pn[2]);
   if (cx < 0 || cx >= g.nx || cy < 0 || cy >= g.ny || czg < 0 || czg >= g.nzg) return -1;
   const int dest = czg / g.nzl;
   if (dest == rank) return ((czg - g.z0) * g.ny + cy) * g.nx + cx;
@@ -40,11 +43,11 @@ struct Migr {
 
 // New cell of a (moved, wrapped) particle and its arrival rank in that cell; with MIG also the send side of
 // update_cells_mpi.  Every live lane of the wave calls it together (ballots).
-template <bool MIG>
+template <bool MIG, bool P2 = false>
 __device__ __forceinline__ void bin_particle(const GridDev& g, const SortDev& s, int64_t p, double x, double y, double z,
   double vx, double vy, double vz, const Migr& mg)
 {
-  int c = MIG ? dest_of(g, mg.rank, mg.nranks, x, y, z) : cell_of(g, x, y, z);
+  int c = MIG ? dest_of<P2>(g, mg.rank, mg.nranks, x, y, z) : cell_of<P2>(g, x, y, z);
   if (MIG && c <= -2) {
     if (c == -4) { atomicOr(&mg.sendcount[2], 1); c = -1; }
     else {
@@ -245,7 +248,7 @@ struct PushPrefetch {
   double v[2][3];
 };
 
-template <bool PREBIN, bool MIG>
+template <bool PREBIN, bool MIG, bool P2>
 __global__ void __launch_bounds__(kSPW * 64) k_second_push(GridDev g, SortDev s, const double* __restrict__ E,
   const double* __restrict__ B, double qm, long ncell, long chunk, Migr mg)
 {
@@ -301,7 +304,7 @@ __global__ void __launch_bounds__(kSPW * 64) k_second_push(GridDev g, SortDev s,
   const double* eE = nbE[wave];
   const double* eB = nbB[wave];
   auto push = [&](long p, const double* r, double* v) {
-    const W1 w(g, r[0], r[1], r[2]);
+    const W1T<P2> w(g, r[0], r[1], r[2]);
     const int ox = w.is[0] - w.in[0] + 1, oy = w.is[1] - w.in[1] + 1, oz = w.is[2] - w.in[2] + 1;
     double Ep[3] = {0, 0, 0}, Bp[3] = {0, 0, 0};
 #pragma unroll
@@ -325,7 +328,7 @@ __global__ void __launch_bounds__(kSPW * 64) k_second_push(GridDev g, SortDev s,
       const double x = bound_periodic(r[0] + v[0] * g.dt, g.Lx);
       const double y = bound_periodic(r[1] + v[1] * g.dt, g.Ly);
       const double z = bound_periodic(r[2] + v[2] * g.dt, g.Lz);
-      bin_particle<MIG>(g, s, p, x, y, z, v[0], v[1], v[2], mg);
+      bin_particle<MIG, P2>(g, s, p, x, y, z, v[0], v[1], v[2], mg);
     }
   };
 
@@ -873,11 +876,18 @@ int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B, bo
     XPIC_HIP(hipMemsetAsync(s.d.cell_count, 0, sizeof(int) * (c->ncell + 1), c->stream));
     if (mig) XPIC_HIP(hipMemsetAsync(s.mig_count, 0, sizeof(int) * 4, c->stream));
   }
-#define LAUNCH(P, G) hipLaunchKernelGGL((k_second_push<P, G>), dim3((unsigned)(8 * chunk)), dim3(kSPW * 64), 0, c->stream, \
+#define LAUNCH(P, G, Q) hipLaunchKernelGGL((k_second_push<P, G, Q>), dim3((unsigned)(8 * chunk)), dim3(kSPW * 64), 0, c->stream, \
     c->g, s.d, E, B, s.par.q / s.par.m, (long)c->ncell, chunk, mg)
-  if (!prebin) LAUNCH(false, false);
-  else if (mig) LAUNCH(true, true);
-  else LAUNCH(true, false);
+  if (c->g.pow2) { // exact reciprocal spacings: no fp64 division per position (device_common.h: scaled_position)
+    if (!prebin) LAUNCH(false, false, true);
+    else if (mig) LAUNCH(true, true, true);
+    else LAUNCH(true, false, true);
+  }
+  else {
+    if (!prebin) LAUNCH(false, false, false);
+    else if (mig) LAUNCH(true, true, false);
+    else LAUNCH(true, false, false);
+  }
 #undef LAUNCH
   XPIC_HIP(hipGetLastError());
   if (prebin) { s.prebinned = true; s.prebinned_step = c->g.dt; s.prebinned_n = s.n; }
