@@ -240,3 +240,89 @@ def test_momentum_conservation_sums_on_device(oracle, scheme):
         if t < 2:
             assert o.step() >= 0
             g.step()
+
+
+def test_config1_size_properties_basic():
+    """BASELINE configs[1] at full size on its own scheme: `basic`, 128^3 cells, two electron species of 16 ppc (the
+    two-stream set-up: 67 M particles), dt = 0.1.  Size-independent properties only: no particle is lost by the periodic
+    re-binning, the Esirkepov current satisfies the discrete continuity equation to round-off (ChargeConservation,
+    charge_conservation.cpp:125-171), the explicit scheme's total energy stays within 1e-3 while the fields grow from the
+    particle noise (the scheme is not energy conserving: measured 1.6e-4 over these three steps)."""
+    import xpic_amd as X
+
+    n = (128, 128, 128)
+    g = X.Context("basic", n, (0.5, 0.5, 0.5), 0.1)
+    N = n[0] * n[1] * n[2]
+    sorts = [g.add_sort(16, 0.5, -1.0, 1.0, capacity=int(16 * N * 1.3)) for _ in range(2)]
+    for k, s in enumerate(sorts):
+        g.fill_synthetic(s, 16, 0.02, seed=21 + k)
+    assert [g.count(s) for s in sorts] == [16 * N, 16 * N]
+    g.charge_collect()
+    e0 = g.energy()
+    for t in range(3):
+        g.step()
+        q = g.charge_columns()
+        rho_scale = 0.5 * 16 / 0.1  # |q n| per cell / dt: the size of the two terms that cancel
+        assert q[-2] <= 1e-9 * rho_scale * N and q[-1] <= 1e-11 * rho_scale * np.sqrt(N), (t, q)
+    e1 = g.energy()
+    assert [g.count(s) for s in sorts] == [16 * N, 16 * N]
+    tot0 = e0[0] + e0[1] + e0[4] + e0[6]
+    tot1 = e1[0] + e1[1] + e1[4] + e1[6]
+    assert abs(tot1 - tot0) <= 1e-3 * tot0
+    assert e1[0] > 0
+    p = g.momentum()
+    assert p.shape == (2, 6) and np.isfinite(p).all()
+    g.close()
+
+
+def test_config4_size_properties_ecsimcorr():
+    """`ecsimcorr` at 128^3 x 32 ppc (67 M particles; one GPU's particle load of BASELINE configs[4] is 8x this on a
+    512 x 512 x 64 slab): no particle lost over the two re-binnings of a step, both solves converge within maxit, the
+    corrected scheme conserves the total energy to the accuracy of the solves and the Esirkepov current keeps the
+    continuity residual at round-off."""
+    import xpic_amd as X
+
+    n = (128, 128, 128)
+    g = X.Context("ecsimcorr", n, (0.5, 0.5, 0.5), 1.0)
+    N = n[0] * n[1] * n[2]
+    s = g.add_sort(32, 1.0, -1.0, 1.0, capacity=int(32 * N * 1.3))
+    g.fill_synthetic(s, 32, 0.014, seed=31)
+    B = np.zeros(g.fshape())
+    B[..., 2] = 0.2
+    g.set_field(X.B, B)
+    g.set_field(X.B0, B)
+    del B
+    g.charge_collect()
+    e0 = g.energy()
+    for t in range(2):
+        assert 0 < g.step() <= 200
+        q = g.charge_columns()
+        rho_scale = 32 / 1.0
+        assert q[-1] <= 1e-11 * rho_scale * np.sqrt(N), (t, q)
+    e1 = g.energy()
+    assert g.count(s) == 32 * N
+    tot0, tot1 = e0[0] + e0[1] + e0[4], e1[0] + e1[1] + e1[4]
+    assert abs(tot1 - tot0) <= 1e-7 * tot0
+    sc = g.ecsimcorr_scalars(s)
+    assert abs(sc["pred_dK"] - 1.0 * sc["pred_w"]) <= 1e-9 * abs(sc["energy"])
+    g.close()
+
+
+@pytest.mark.parametrize("nzl", [32, 64])
+def test_slab_shaped_boxes_ecsimcorr(oracle, nzl):
+    """The slab thicknesses of BASELINE configs[3] / [4] (32 and 64 planes) as single-slab boxes 16 x 12 x nzl against
+    the oracle: two ecsimcorr steps, fields to 1e-8, counts exactly (the z-slab runs of the same shapes are in
+    test_gpu_slabs.py)."""
+    import xpic_amd as X
+
+    n, d, dt = (16, 12, nzl), (0.5, 0.4, 0.25), 0.2
+    o, g = make_pair(oracle, "ecsimcorr", n, d, dt, [(6, 1.0, -1.0, 1.0)], B0=(0.0, 0.1, 0.3), vth=0.1)
+    for sim in (o, g):
+        sim.set_tolerances(1e-12, 1e-50, 400)
+    for _ in range(2):
+        assert o.step() > 0
+        g.step()
+    for name, fid in (("E", X.E), ("B", X.B)):
+        a, b = o.get_field(name), g.get_field(fid)
+        assert np.abs(a - b).max() <= 1e-8 * np.abs(a).max(), name
+    assert o.count(0) == g.count(0)
