@@ -151,7 +151,9 @@ __device__ inline double load_bnb(const GridDev& g, const double* __restrict__ B
   return B[c * g.cstride + g.nodew(cx + ox, cy + oy, cz + oz)];
 }
 
-template <bool P2>
+// P2: power-of-two spacings (exact reciprocals, device_common.h); FX: nx is a multiple of the chunk width, so every
+// chunk is full and its flush is the aligned 32-byte form (the partial-chunk code paths compile away)
+template <bool P2, bool FX>
 __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, SortDev s, const double* __restrict__ B,
   double* currI, double* matL, const unsigned short* __restrict__ dtab, const int* __restrict__ linetab, const int* __restrict__ cowr, double q, double m,
   double mpw, int cy0, int cystep, int ncy, int cz0, int czstep, int my_order, int ncol_y, int per_y, int per_z, int first_sort)
@@ -415,10 +417,10 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
 
     // ---- the finished columns of this chunk leave by read-modify-write: request their current values NOW, so
     // that the HBM latency runs under the merge below (addresses depend only on the chunk, not on the data)
-    const int ndone = min(kW, g.nx - j * kW);
+    const int ndone = FX ? kW : min(kW, g.nx - j * kW);
     // matL lines: the kW finished columns are the x-block j of the row, 32 contiguous, aligned bytes;
     // currI lines: kW consecutive doubles, 16-byte aligned when nx is even
-    const bool vecL = ndone == kW, vecI = vecL && (g.nx & 1) == 0;
+    const bool vecL = FX || ndone == kW, vecI = FX || (vecL && (g.nx & 1) == 0);
     double old[kOwn][kW];
     double* ptr[kOwn];
     bool fst[kOwn];
@@ -489,7 +491,9 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
 #pragma unroll
         for (int c = 0; c < kSlots / 2; ++c) { const double2 v = wp[c]; w[2 * c] = v.x; w[2 * c + 1] = v.y; }
         const bool vec = line < kMatLines ? vecL : vecI;
-        bool any = fst[mm];
+        // lines without a contribution from this chunk are left alone (vacuum stays exactly zero and costs no write);
+        // the full-chunk instantiation skips the test: in a plasma every line has one
+        bool any = FX || fst[mm];
 #pragma unroll
         for (int c = 0; c < kW; ++c) any = any || (c < ndone && w[c] != 0.0);
 #if FILL_EXP == 8
@@ -685,7 +689,10 @@ int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, d
       else { cz0 = b; czs = 3; ncz = (g.nzl - b + 2) / 3; }
       if (ncy == 0 || ncz == 0) continue;
       Timed t(c, "fill_current"); // one entry per colour launch: the average is the kernel's own launch duration
-      hipLaunchKernelGGL(g.pow2 ? k_ecsim_fill<true> : k_ecsim_fill<false>, dim3((unsigned)(ncy * ncz)), dim3(kThreads), 0, c->stream, g, s.d, B,
+      const bool fx = g.nx % kW == 0;
+      auto kern = g.pow2 ? (fx ? k_ecsim_fill<true, true> : k_ecsim_fill<true, false>)
+                         : (fx ? k_ecsim_fill<false, true> : k_ecsim_fill<false, false>);
+      hipLaunchKernelGGL(kern, dim3((unsigned)(ncy * ncz)), dim3(kThreads), 0, c->stream, g, s.d, B,
         currI_sort, matL, (const unsigned short*)(c->ltab + kLines + kLines * 8), c->ltab, c->ltab + kLines, s.par.q, s.par.m,
         s.par.n / (double)s.par.Np, cy0, cys, ncy, cz0, czs, b * ncol_y + a, ncol_y, per_y, per_z, first_sort ? 1 : 0);
     }
