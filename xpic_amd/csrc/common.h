@@ -201,6 +201,8 @@ int matM_apply(xpic_ctx* c, const double* x, double* y, bool add);
 int matL_apply(xpic_ctx* c, const double* x, double* y, bool add);
 int matA_apply(xpic_ctx* c, const double* x, double* y);
 int cheb_matM_inverse(xpic_ctx* c, const double* r, double* out);
+int cg_apply_dot_host(xpic_ctx* c, const double* p, double* Ap, double* pAp);                       // Ap = matM p, p . Ap
+int cg_update_host(xpic_ctx* c, double alpha, const double* p, const double* Ap, double* x, double* r, double* rr);
 int div_neg_add(xpic_ctx* c, double* v3, double* out_scalar);
 int scalar_norm12_host(xpic_ctx* c, const double* f, double* out2);
 int field_import(xpic_ctx* c, double* dst_soa, const double* src_aos_host);

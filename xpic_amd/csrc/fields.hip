@@ -247,6 +247,45 @@ __global__ void __launch_bounds__(kBlock) k_matM(GridDev g, const double* F, dou
   }
 }
 
+// ---- fused CG kernels on matM (krylov.hip: cg).  One CG iteration moves 11 V: these two kernels (2 V + 6 V) and
+// the p = r + beta p update (3 V) -- SURVEY 8(d)'s "maximally fused" count -- instead of the 14 V of one BLAS-1 call
+// per line of the textbook algorithm.
+// Ap = matM p and partial[blk] = sum p . Ap (owned nodes; a node's three components are summed together)
+__global__ void __launch_bounds__(kBlock) k_cg_apply_dot(GridDev g, const double* __restrict__ p, double* __restrict__ Ap,
+  double* partial)
+{
+  double acc[1] = {0.0};
+  const long stride = (long)gridDim.x * kBlock;
+  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < g.nown; i += stride) {
+    int x = (int)(i % g.nx), y = (int)((i / g.nx) % g.ny), z = (int)(i / g.plane);
+    double m[3];
+    matM_at(g, p, x, y, z, m[0], m[1], m[2]);
+    const long o = g.node(x, y, g.wz(z));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      Ap[o + c * g.cstride] = m[c];
+      acc[0] += p[o + c * g.cstride] * m[c];
+    }
+  }
+  block_reduce_store<1>(acc, partial, gridDim.x, blockIdx.x);
+}
+
+// x += alpha p ; r -= alpha Ap ; partial[blk] = sum r . r (after the update)
+__global__ void __launch_bounds__(kBlock) k_cg_update(GridDev g, double alpha, const double* __restrict__ p,
+  const double* __restrict__ Ap, double* __restrict__ x, double* __restrict__ r, double* partial)
+{
+  double acc[1] = {0.0};
+  const long off = (long)blockIdx.y * g.cstride + (long)g.G * g.plane;
+  const long stride = (long)gridDim.x * kBlock;
+  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < g.nown; i += stride) {
+    x[off + i] += alpha * p[off + i];
+    const double rv = r[off + i] - alpha * Ap[off + i];
+    r[off + i] = rv;
+    acc[0] += rv * rv;
+  }
+  block_reduce_store<1>(acc, partial, gridDim.x * gridDim.y, blockIdx.y * gridDim.x + blockIdx.x);
+}
+
 // ---- Chebyshev step on matM: res = r - matM z_in ; d = cd d + cr res ; z_out = z_in + d.
 // FIRST: the start z_0 = d_0 = r / theta is never stored: matM z_0 = (matM r) / theta, everything comes from r.
 template <bool FIRST>
@@ -520,6 +559,26 @@ int field_stats_host(xpic_ctx* c, const double* f, double* sumsq, double* mean3)
   *sumsq = out[0] + out[1] + out[2];
   mean3[0] = out[3]; mean3[1] = out[4]; mean3[2] = out[5];
   return 0;
+}
+
+// Ap = matM p, *pAp = p . Ap  (p's ghost planes must be filled)
+int cg_apply_dot_host(xpic_ctx* c, const double* p, double* Ap, double* pAp)
+{
+  Timed t(c, "matM_apply");
+  long blocks = (c->g.nown + kBlock - 1) / kBlock;
+  if (blocks > kRedBlocks) blocks = kRedBlocks;
+  hipLaunchKernelGGL(k_cg_apply_dot, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, c->g, p, Ap, c->red_partial);
+  XPIC_HIP(hipGetLastError());
+  return finish_reduce(c, 1, (int)blocks, 1, pAp);
+}
+
+// x += alpha p ; r -= alpha Ap ; *rr = r . r
+int cg_update_host(xpic_ctx* c, double alpha, const double* p, const double* Ap, double* x, double* r, double* rr)
+{
+  dim3 grid = red_grid(c->g);
+  hipLaunchKernelGGL(k_cg_update, grid, dim3(kBlock), 0, c->stream, c->g, alpha, p, Ap, x, r, c->red_partial);
+  XPIC_HIP(hipGetLastError());
+  return finish_reduce(c, 1, grid.x * grid.y, 1, rr);
 }
 
 int rot_apply(xpic_ctx* c, int sign, double alpha, const double* x, double* y, bool add)
