@@ -5,7 +5,9 @@
 // with Shape (src/utils/shape.cpp:31-80), SimpleInterpolation (src/algorithms/simple_interpolation.cpp:8-38)
 // and EsirkepovDecomposition (src/algorithms/esirkepov_decomposition.cpp:20-103) for cell-sorted SoA particles.
 //
-// A workgroup owns 4 consecutive cells in x (one wave per cell).
+// A workgroup owns one x-pencil of cells and marches along it in chunks of 4 cells (one wave per cell); what a chunk
+// needs from global memory -- the first pass of particles of each cell, the gather tile (MODE 0), the CIC
+// neighbourhoods (MODE 2) -- is requested one chunk ahead.
 //   * phase 1 (lane = particle) moves / pushes the particle.  MODE 0 gathers E, B with the 2nd-order shape out of an
 //     LDS tile of the 9 x 6 x 6 nodes the workgroup's particles can reach at mid-step (only the three nodes per axis
 //     and weight type that spline_of_2nd_order does not return as exact zeros: the sums are bitwise those of the
@@ -19,7 +21,8 @@
 //     running sum temp_j += W (:57-103) with the sum over the line taken first.  No atomics inside a cell.
 //   * A particle that moves further (up to the reference's own limit of one cell, shape.h:18,91-92) deposits its box
 //     directly with fp64 atomics (slow path, same arithmetic as the reference's loop).
-//   * The 4 cells' lines are merged in an LDS J tile (7 x 4 x 4 nodes) and leave with one fp64 atomic per tile node.
+//   * The chunk's lines are merged in a sliding LDS J window (7 x 4 x 4 nodes per component); the 4 columns the march
+//     has passed leave with one fp64 atomic per node.
 #include <cstring>
 
 #include "common.h"
@@ -41,6 +44,16 @@ constexpr int kTX = kBW + kT - 1;
 constexpr int kTileN = kTX * kT * kT;
 constexpr int kThreadsB = kBW * 64;
 constexpr int kLinesB = 3 * kD * kD; // 48 lines of 4 nodes
+constexpr int kFtPer = (6 * kTileN + kThreadsB - 1) / kThreadsB; // gather-tile values per thread
+constexpr int kMaxNxB = 1024;        // pencils up to this length keep their cell_start row in LDS
+static_assert(3 * kJN <= 2 * kThreadsB, "two window elements per thread");
+
+// raw workgroup barrier that only drains LDS traffic: the particle stores, the J atomics and the requests of the next
+// chunk stay in flight across it (__syncthreads() would wait for every one of them: a round trip to HBM per chunk)
+__device__ inline void lds_barrier_b()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 __device__ inline void wave_sync_b()
 {
@@ -72,64 +85,105 @@ __device__ inline double lane_value(double v, int src)
   return __builtin_bit_cast(double, ((long long)hi << 32) | lo);
 }
 
+// what a wave requests one chunk ahead: its next cell's first pass of particles (and, MODE 2, the cell's CIC
+// neighbourhoods; MODE 0, this thread's share of the workgroup's next gather tile)
 template <int MODE>
-__global__ void __launch_bounds__(kThreadsB) k_esirkepov_push(GridDev g, SortDev s, const double* __restrict__ E,
+struct Ahead {
+  int start, cnt;
+  double r[3], v[3];
+  double e, b;                       // MODE 2: lane's value of the 36 E / 54 B neighbourhood
+  double ft[MODE == 0 ? kFtPer : 1]; // MODE 0: tile values t = thread + k * kThreadsB
+};
+
+// P2: power-of-two spacings (exact reciprocals instead of divisions, device_common.h: scaled_position)
+template <int MODE, bool P2>
+__global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, SortDev s, const double* __restrict__ E,
   const double* __restrict__ B, double* __restrict__ J, double qm, double alpha, double qn_Np, double* pred_w,
   int* bad_count)
 {
-  // workgroup -> (x chunk, cy, cz)
-  const int nxc = (g.nx + kBW - 1) / kBW;
-  const int xc = blockIdx.x % nxc;
-  const int cy = (blockIdx.x / nxc) % g.ny;
-  const int cz = blockIdx.x / (nxc * g.ny);
-  const int cx0 = xc * kBW;
+  // workgroup -> the x-pencil (cy, cz), marched in chunks of kBW cells (one cell per wave)
+  const int cy = blockIdx.x % g.ny;
+  const int cz = blockIdx.x / g.ny;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int cx = cx0 + wave;
-  const bool active = cx < g.nx;
 
   __shared__ double stage[kBW][kSRows * kBPad];
   __shared__ double jtile[3 * kJN];
   __shared__ double ftile[MODE == 0 ? 6 * kTileN : 1];   // Ex,Ey,Ez,Bx,By,Bz on the gather tile (basic only)
   __shared__ double nbE[MODE == 2 ? kBW : 1][36], nbB[MODE == 2 ? kBW : 1][54]; // CIC neighbourhoods (second_push only)
   __shared__ double pwsum[kBW];
+  __shared__ int cstart[kMaxNxB + 2];
 
+  const long pencil0 = ((long)cz * g.ny + cy) * g.nx;
+  const bool cs_lds = g.nx <= kMaxNxB;
+  if (cs_lds)
+    for (int i = threadIdx.x; i <= g.nx; i += kThreadsB) cstart[i] = s.cell_start[pencil0 + i];
   for (int t = threadIdx.x; t < 3 * kJN; t += kThreadsB) jtile[t] = 0.0;
-  if (MODE == 0) {
-    // DMGlobalToLocal(E), (B) (basic/simulation.cpp:56-57) for just the nodes this workgroup can gather from
-    for (int t = threadIdx.x; t < 6 * kTileN; t += kThreadsB) {
-      const int f = t / kTileN, n = t % kTileN;
-      const int tx = n % kTX, ty = (n / kTX) % kT, tz = n / (kTX * kT);
-      const double* F = (f < 3 ? E : B) + (f % 3) * g.cstride;
-      ftile[t] = F[g.nodew(cx0 - 2 + tx, cy - 2 + ty, cz - 2 + tz)];
-    }
-  }
-  if (MODE == 2 && active) {
-    // the cell's 36 E and 54 B values of interpolate_E_s1 / interpolate_B_s1 (numbering as in k_second_push)
+  __syncthreads();
+
+  // neighbourhood slot of this lane (MODE 2): numbering of the cell's 3 x 12 E nodes and 54 B nodes as in k_second_push
+  int ec = 0, eo[3] = {0, 0, 0}, bc = 0, bo[3] = {0, 0, 0};
+  if (MODE == 2) {
     if (lane < 36) {
-      const int ec = lane / 12, l = lane % 12;
-      int eo[3];
+      ec = lane / 12;
+      const int l = lane % 12;
       if (ec == 0) { eo[0] = l % 3 - 1; eo[1] = (l / 3) % 2; eo[2] = l / 6; }
       else if (ec == 1) { eo[0] = l % 2; eo[1] = (l / 2) % 3 - 1; eo[2] = l / 6; }
       else { eo[0] = l % 2; eo[1] = (l / 2) % 2; eo[2] = l / 4 - 1; }
-      nbE[wave][lane] = E[ec * g.cstride + g.nodew(cx + eo[0], cy + eo[1], cz + eo[2])];
     }
     if (lane < 54) {
-      int bc, bo[3];
       if (lane < 18) { bc = 0; bo[0] = lane % 2; bo[1] = (lane / 2) % 3 - 1; bo[2] = lane / 6 - 1; }
       else if (lane < 36) { const int l = lane - 18; bc = 1; bo[0] = l % 3 - 1; bo[1] = (l / 3) % 2; bo[2] = l / 6 - 1; }
       else { const int l = lane - 36; bc = 2; bo[0] = l % 3 - 1; bo[1] = (l / 3) % 3 - 1; bo[2] = l / 9; }
-      nbB[wave][lane] = B[bc * g.cstride + g.nodew(cx + bo[0], cy + bo[1], cz + bo[2])];
     }
   }
-  __syncthreads();
 
-  double acc[kD] = {0.0, 0.0, 0.0, 0.0};
+  // the gather tile of chunk j (MODE 0): requested after the arithmetic of the chunk before, so that its registers
+  // are not held across phases 1 and 2
+  auto request_tile = [&](int j, Ahead<MODE>& pf) {
+    const int cxa0 = j * kBW;
+    if (MODE == 0 && cxa0 < g.nx) {
+      // DMGlobalToLocal(E), (B) (basic/simulation.cpp:56-57) for just the nodes the chunk's particles can gather from
+#pragma unroll
+      for (int k = 0; k < kFtPer; ++k) {
+        const int t = threadIdx.x + k * kThreadsB;
+        pf.ft[k] = 0.0;
+        if (t < 6 * kTileN) {
+          const int f = t / kTileN, n = t % kTileN;
+          const int tx = n % kTX, ty = (n / kTX) % kT, tz = n / (kTX * kT);
+          const double* F = (f < 3 ? E : B) + (f % 3) * g.cstride;
+          pf.ft[k] = F[g.nodew(cxa0 - 2 + tx, cy - 2 + ty, cz - 2 + tz)];
+        }
+      }
+    }
+  };
+  auto request = [&](int j, Ahead<MODE>& pf) {
+    pf.start = 0; pf.cnt = 0; pf.e = 0.0; pf.b = 0.0;
+    const int cxa = j * kBW + wave;
+    if (cxa >= g.nx) return;
+    if (cs_lds) {
+      pf.start = __builtin_amdgcn_readfirstlane(cstart[cxa]);
+      pf.cnt = __builtin_amdgcn_readfirstlane(cstart[cxa + 1]) - pf.start;
+    }
+    else {
+      pf.start = __builtin_amdgcn_readfirstlane(s.cell_start[pencil0 + cxa]);
+      pf.cnt = __builtin_amdgcn_readfirstlane(s.cell_start[pencil0 + cxa + 1]) - pf.start;
+    }
+    if (MODE == 2 && pf.cnt > 0) {
+      if (lane < 36) pf.e = E[ec * g.cstride + g.nodew(cxa + eo[0], cy + eo[1], cz + eo[2])];
+      if (lane < 54) pf.b = B[bc * g.cstride + g.nodew(cxa + bo[0], cy + bo[1], cz + bo[2])];
+    }
+    // MODE 0 (the register-hungry 2nd-order gather) loads its particles when it gets there instead
+    if (MODE != 0 && lane < min(kBC, pf.cnt)) {
+      const long p = (long)pf.start + lane;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { pf.r[a] = s.r[a][p]; pf.v[a] = s.v[a][p]; }
+    }
+  };
+
   double pw = 0.0;
   int bad = 0;
   double* st = stage[wave];
   const double dt = g.dt;
-  const double dd[3] = {g.dx, g.dy, g.dz};
-  const int cc[3] = {cx, cy, cz + g.z0};
 
   // the line of this lane: component c along its own axis; transverse axes (A, B) with the reference's roles
   //   X: A = y, B = z   get_jx :57-71      Y: A = x, B = z   get_jy :73-87      Z: A = y, B = x   get_jz :89-103
@@ -144,10 +198,32 @@ __global__ void __launch_bounds__(kThreadsB) k_esirkepov_push(GridDev g, SortDev
   const double* snB = st + (12 + axB * kD + liB) * kBPad;
   const double* pC = st + (24 + lc * kD) * kBPad;
 
-  if (active) {
-    const long cell = ((long)cz * g.ny + cy) * g.nx + cx;
-    const int start = s.cell_start[cell];
-    const int cnt = s.cell_start[cell + 1] - start;
+  Ahead<MODE> pf;
+  request_tile(0, pf);
+  request(0, pf);
+  const int nch = (g.nx + kBW - 1) / kBW;
+  for (int j = 0; j < nch; ++j) {
+    const int cx0 = j * kBW, cx = cx0 + wave;
+    const bool active = cx < g.nx;
+    const int cc[3] = {cx, cy, cz + g.z0};
+    // ---- this chunk's tile / neighbourhoods, requested one chunk ago, go to LDS; then the next chunk's requests
+    if (MODE == 0) {
+#pragma unroll
+      for (int k = 0; k < kFtPer; ++k) {
+        const int t = threadIdx.x + k * kThreadsB;
+        if (t < 6 * kTileN) ftile[t] = pf.ft[k];
+      }
+      lds_barrier_b();
+    }
+    if (MODE == 2) {
+      if (lane < 36) nbE[wave][lane] = pf.e;
+      if (lane < 54) nbB[wave][lane] = pf.b;
+    }
+    const int start = pf.start, cnt = pf.cnt;
+    double fr[3] = {pf.r[0], pf.r[1], pf.r[2]}, fv[3] = {pf.v[0], pf.v[1], pf.v[2]};
+    request(j + 1, pf);
+
+    double acc[kD] = {0.0, 0.0, 0.0, 0.0};
     for (int base = 0; base < cnt; base += kBC) {
       const int mcnt = min(kBC, cnt - base);
       wave_sync_b();
@@ -157,8 +233,11 @@ __global__ void __launch_bounds__(kThreadsB) k_esirkepov_push(GridDev g, SortDev
       int sst[3] = {0, 0, 0}, ssz[3] = {0, 0, 0};
       if (lane < mcnt) {
         const long p = (long)start + base + lane;
-        double r[3] = {s.r[0][p], s.r[1][p], s.r[2][p]};
-        double v[3] = {s.v[0][p], s.v[1][p], s.v[2][p]};
+        double r[3] = {fr[0], fr[1], fr[2]}, v[3] = {fv[0], fv[1], fv[2]};
+        if (MODE == 0 || base > 0) { // cells beyond one pass (and MODE 0): plain loads
+#pragma unroll
+          for (int a = 0; a < 3; ++a) { r[a] = s.r[a][p]; v[a] = s.v[a][p]; }
+        }
         const double old_r[3] = {r[0], r[1], r[2]};
         double Ep[3] = {0, 0, 0}, Bp[3] = {0, 0, 0};
 
@@ -172,9 +251,11 @@ __global__ void __launch_bounds__(kThreadsB) k_esirkepov_push(GridDev g, SortDev
           int off[3], nN[3];
           double No[3][3], Sh[3][3];
           bool inside = true;
+          double prs[3];
+          scaled_position<P2>(g, r[0], r[1], r[2], prs);
 #pragma unroll
           for (int a = 0; a < 3; ++a) {
-            const double pr = r[a] / dd[a];
+            const double pr = prs[a];
             const int sst = (int)round(pr - 1.5);
             const int ssz = (int)floor(pr + 1.5) + 1 - sst;
             inside = inside && sst >= cc[a] - 2 && sst + ssz <= cc[a] + 4;
@@ -190,21 +271,28 @@ __global__ void __launch_bounds__(kThreadsB) k_esirkepov_push(GridDev g, SortDev
             off[0] += wave; // tile x origin is cx0 - 2, the cell's own is cx - 2
             // the reference's loop order (x fastest, then y, z), zero terms left out
             const int bN[3] = {off[0] + nN[0], off[1] + nN[1], off[2] + nN[2]};
+            // the z loop stays a loop: unrolled, the compiler keeps all 36 weight products of the box live at once
+#pragma nounroll
+            for (int kz = 0; kz < 3; ++kz) {
+              const double nz = No[2][kz], sz = Sh[2][kz];
+              const int zN = (bN[2] + kz) * kT, zS = (off[2] + kz) * kT;
 #pragma unroll
-            for (int kz = 0; kz < 3; ++kz)
-#pragma unroll
-              for (int jy = 0; jy < 3; ++jy)
+              for (int jy = 0; jy < 3; ++jy) {
+                const int yN = bN[1] + jy, yS = off[1] + jy;
+                const double nn = nz * No[1][jy], ns = nz * Sh[1][jy], sn = sz * No[1][jy], ss = sz * Sh[1][jy];
 #pragma unroll
                 for (int ix = 0; ix < 3; ++ix) {
                   // Shape::electric / magnetic (shape.h:54-72): each component has its own three nodes per axis
-                  const int zN = bN[2] + kz, zS = off[2] + kz, yN = bN[1] + jy, yS = off[1] + jy, xN = bN[0] + ix, xS = off[0] + ix;
-                  Ep[0] += ftile[0 * kTileN + (zN * kT + yN) * kTX + xS] * (No[2][kz] * No[1][jy] * Sh[0][ix]);
-                  Ep[1] += ftile[1 * kTileN + (zN * kT + yS) * kTX + xN] * (No[2][kz] * Sh[1][jy] * No[0][ix]);
-                  Ep[2] += ftile[2 * kTileN + (zS * kT + yN) * kTX + xN] * (Sh[2][kz] * No[1][jy] * No[0][ix]);
-                  Bp[0] += ftile[3 * kTileN + (zS * kT + yS) * kTX + xN] * (Sh[2][kz] * Sh[1][jy] * No[0][ix]);
-                  Bp[1] += ftile[4 * kTileN + (zS * kT + yN) * kTX + xS] * (Sh[2][kz] * No[1][jy] * Sh[0][ix]);
-                  Bp[2] += ftile[5 * kTileN + (zN * kT + yS) * kTX + xS] * (No[2][kz] * Sh[1][jy] * Sh[0][ix]);
+                  const int xN = bN[0] + ix, xS = off[0] + ix;
+                  Ep[0] += ftile[0 * kTileN + (zN + yN) * kTX + xS] * (nn * Sh[0][ix]);
+                  Ep[1] += ftile[1 * kTileN + (zN + yS) * kTX + xN] * (ns * No[0][ix]);
+                  Ep[2] += ftile[2 * kTileN + (zS + yN) * kTX + xN] * (sn * No[0][ix]);
+                  Bp[0] += ftile[3 * kTileN + (zS + yS) * kTX + xN] * (ss * No[0][ix]);
+                  Bp[1] += ftile[4 * kTileN + (zS + yN) * kTX + xS] * (sn * Sh[0][ix]);
+                  Bp[2] += ftile[5 * kTileN + (zN + yS) * kTX + xS] * (ns * Sh[0][ix]);
                 }
+              }
+            }
           }
           // else: the particle moved further than the reference itself supports; flagged by the range test below
           update_vEB(dt, qm, Ep, Bp, v);                 // push.update_vEB(dt)  :41
@@ -219,7 +307,7 @@ __global__ void __launch_bounds__(kThreadsB) k_esirkepov_push(GridDev g, SortDev
           // interpolate_E_s1 / interpolate_B_s1 ; update_vEB(dt) ; update_r(0.5 dt)   (:64-69), gathers out of the
           // cell's LDS neighbourhood in the loop and product order of ecsim/simulation.cpp:8-118
           const double old_v[3] = {v[0], v[1], v[2]};
-          const W1 w(g, r[0], r[1], r[2]);
+          const W1T<P2> w(g, r[0], r[1], r[2]);
           const int ox = w.is[0] - w.in[0] + 1, oy = w.is[1] - w.in[1] + 1, oz = w.is[2] - w.in[2] + 1;
           const double* eE = nbE[MODE == 2 ? wave : 0];
           const double* eB = nbB[MODE == 2 ? wave : 0];
@@ -250,10 +338,10 @@ __global__ void __launch_bounds__(kThreadsB) k_esirkepov_push(GridDev g, SortDev
 
         // Shape::setup(old_r, new_r) (shape.cpp:43-54): the box [sst, send) of the pair per axis
         bool ok = true, fast = true;
+        scaled_position<P2>(g, old_r[0], old_r[1], old_r[2], po);
+        scaled_position<P2>(g, r[0], r[1], r[2], pn);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-          po[a] = old_r[a] / dd[a];
-          pn[a] = r[a] / dd[a];
           sst[a] = (int)round(fmin(po[a], pn[a]) - 1.5);
           const int send = (int)floor(fmax(po[a], pn[a]) + 1.5) + 1;
           ssz[a] = send - sst[a];
@@ -326,34 +414,56 @@ __global__ void __launch_bounds__(kThreadsB) k_esirkepov_push(GridDev g, SortDev
         }
       }
     }
+
+    request_tile(j + 1, pf);
+    // ---- merge the chunk's cells in the LDS J window: column 0 is node x = cx0 - 1
+    if (active && has_line) {
+#pragma unroll
+      for (int t = 0; t < kD; ++t) {
+        int tx, ty, tz;
+        if (lc == 0) { tx = wave + t; ty = liA; tz = liB; }
+        else if (lc == 1) { tx = wave + liA; ty = t; tz = liB; }
+        else { tx = wave + liB; ty = liA; tz = t; }
+        if (acc[t] != 0.0) unsafeAtomicAdd(&jtile[lc * kJN + (tz * kD + ty) * kJX + tx], acc[t]);
+      }
+    }
+    lds_barrier_b();
+    // ---- the next chunk starts at node cx0 + 3: the first kBW columns are final and leave with one fp64 atomic per
+    // node (other pencils add to the same nodes); the other three move to the front of the window.  The last chunk
+    // flushes everything (its tail wraps periodically onto nodes 0, 1, ...).
+    const bool last = j + 1 == nch;
+    double keep[2] = {0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int t = threadIdx.x + k * kThreadsB;
+      if (t < 3 * kJN) {
+        const double val = jtile[t];
+        const int c = t / kJN, n = t % kJN;
+        const int tx = n % kJX, ty = (n / kJX) % kD, tz = n / (kJX * kD);
+        if (tx < kBW || last) {
+          if (val != 0.0) unsafeAtomicAdd(&J[c * g.cstride + g.nodew(cx0 - 1 + tx, cy - 1 + ty, cz - 1 + tz)], val);
+        }
+        // what this thread's element holds next: the value kBW columns further on, zero for the new columns
+        keep[k] = (tx + kBW < kJX && !last) ? jtile[t + kBW] : 0.0;
+      }
+    }
+    lds_barrier_b();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int t = threadIdx.x + k * kThreadsB;
+      if (t < 3 * kJN) jtile[t] = keep[k];
+    }
+    lds_barrier_b();
   }
 
   if (MODE == 2) {
     pw = wave_sum_b(pw);
     if (lane == 0) pwsum[wave] = pw;
+    __syncthreads();
+    // pred_w: one partial per workgroup, summed by k_sum_partials in a fixed order (atomics of every wave on one
+    // address would cost more than the whole push)
+    if (threadIdx.x == 0) pred_w[blockIdx.x] = (pwsum[0] + pwsum[1]) + (pwsum[2] + pwsum[3]);
   }
-  // ---- merge the workgroup's cells in the LDS J tile, then one atomic per tile node
-  if (active && has_line) {
-#pragma unroll
-    for (int t = 0; t < kD; ++t) {
-      int tx, ty, tz;
-      if (lc == 0) { tx = wave + t; ty = liA; tz = liB; }
-      else if (lc == 1) { tx = wave + liA; ty = t; tz = liB; }
-      else { tx = wave + liB; ty = liA; tz = t; }
-      if (acc[t] != 0.0) unsafeAtomicAdd(&jtile[lc * kJN + (tz * kD + ty) * kJX + tx], acc[t]);
-    }
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < 3 * kJN; t += kThreadsB) {
-    const double val = jtile[t];
-    if (val == 0.0) continue;
-    const int c = t / kJN, n = t % kJN;
-    const int tx = n % kJX, ty = (n / kJX) % kD, tz = n / (kJX * kD);
-    unsafeAtomicAdd(&J[c * g.cstride + g.nodew(cx0 - 1 + tx, cy - 1 + ty, cz - 1 + tz)], val);
-  }
-  // pred_w: one partial per workgroup, summed by k_sum_partials in a fixed order (2 M atomics on one address would
-  // cost more than the whole push)
-  if (MODE == 2 && threadIdx.x == 0) pred_w[blockIdx.x] = (pwsum[0] + pwsum[1]) + (pwsum[2] + pwsum[3]);
   if (bad) atomicAdd(bad_count, bad);
 }
 
@@ -397,19 +507,20 @@ int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double
   const double alpha = qn_Np / (6.0 * g.dt); // basic/particles.cpp:44, ecsimcorr/particles.cpp:130
   double* scal = c->red_out;                  // [0] pred_w, [1] bad count (as int)
   XPIC_HIP(hipMemsetAsync(scal, 0, sizeof(double) * 2, c->stream));
-  const long nxc = (g.nx + kBW - 1) / kBW;
-  const long nblocks = nxc * g.ny * g.nzl;
-  XPIC_CHECK(nblocks < 2147483647L, "too many cells for one launch");
+  const long nblocks = (long)g.ny * g.nzl; // one workgroup per x-pencil
+  XPIC_CHECK(nblocks < 2147483647L, "too many pencils for one launch");
   const char* name = mode == 0 ? "basic_push" : (mode == 1 ? "corr_first_push" : "corr_second_push");
   {
     Timed t(c, name);
     dim3 grid((unsigned)nblocks), block(kThreadsB);
-    if (mode == 0) hipLaunchKernelGGL(k_esirkepov_push<0>, grid, block, 0, c->stream, g, s.d, E, B, J, qm, alpha, qn_Np, scal, (int*)(scal + 1));
-    else if (mode == 1) hipLaunchKernelGGL(k_esirkepov_push<1>, grid, block, 0, c->stream, g, s.d, E, B, J, qm, alpha, qn_Np, scal, (int*)(scal + 1));
+#define ESK(M) (g.pow2 ? k_esirkepov_push<M, true> : k_esirkepov_push<M, false>)
+    if (mode == 0) hipLaunchKernelGGL(ESK(0), grid, block, 0, c->stream, g, s.d, E, B, J, qm, alpha, qn_Np, scal, (int*)(scal + 1));
+    else if (mode == 1) hipLaunchKernelGGL(ESK(1), grid, block, 0, c->stream, g, s.d, E, B, J, qm, alpha, qn_Np, scal, (int*)(scal + 1));
     else {
-      // per-workgroup pred_w partials go to the (idle) Krylov work vector: nblocks <= cells < 3 * cells doubles
+      // per-workgroup pred_w partials go to the (idle) Krylov work vector: one double per pencil
       XPIC_CHECK(c->kry_w, "second_push needs the ecsimcorr scheme's work vectors");
-      hipLaunchKernelGGL(k_esirkepov_push<2>, grid, block, 0, c->stream, g, s.d, E, B, J, qm, alpha, qn_Np, c->kry_w, (int*)(scal + 1));
+      hipLaunchKernelGGL(ESK(2), grid, block, 0, c->stream, g, s.d, E, B, J, qm, alpha, qn_Np, c->kry_w, (int*)(scal + 1));
+#undef ESK
       hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, c->stream, c->kry_w, nblocks, scal);
     }
     XPIC_HIP(hipGetLastError());
