@@ -369,9 +369,9 @@ def main():
             "bytes_per_launch": bytes_apply, "launches": n_apply, "avg_ms": ms_apply / n_apply,
         }
     esk = {}
-    for key, kern, bpp, bpc in (("basic_push", "k_esirkepov_push<0>", 96.0, 72.0),
-                                ("corr_first_push", "k_esirkepov_push<1>", 72.0, 24.0),
-                                ("corr_second_push", "k_esirkepov_push<2>", 96.0, 72.0)):
+    for key, kern, bpp, bpc in (("basic_push", "k_esirkepov_push<0", 96.0, 72.0),
+                                ("corr_first_push", "k_esirkepov_push<1", 72.0, 24.0),
+                                ("corr_second_push", "k_esirkepov_push<2", 96.0, 72.0)):
         nl, ms = prof[key]
         if not nl:
             continue
@@ -380,7 +380,7 @@ def main():
         bytes_launch = bpp * count_local + bpc * N
         gbs = bytes_launch / (ms / nl * 1e-3) / 1e9
         esk[key] = {
-            "kernel": f"{kern} ({key})", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "kernel": f"{kern}, ...> ({key})", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(args.scheme, n, kern) if world == 1 else None,
             "bytes_per_launch": bytes_launch, "bytes_per_particle": bpp, "launches": nl, "avg_ms": ms / nl,
             "particles_per_s": count_local / (ms / nl * 1e-3),

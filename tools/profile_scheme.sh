@@ -2,7 +2,7 @@
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 S=${1:-basic}; G=${2:-128}; P=${3:-32}; TAG=${4:-r02}; DT=${5:-1.0}
-ARGS="--scheme $S --grid $G --ppc $P --dt $DT --steps 5 --warmup 2 --no-cpu-baseline"
+ARGS="--scheme $S --grid $G --ppc $P --dt $DT --steps 5 --warmup 2"
 cd $R && timeout -k 10 300 python bench.py $ARGS > gpurun_out/bench_${S}_$TAG.json 2> gpurun_out/bench_${S}_$TAG.err || { tail gpurun_out/bench_${S}_$TAG.err; exit 1; }
 cat gpurun_out/bench_${S}_$TAG.json
 cd /tmp && export TMPDIR=/tmp
