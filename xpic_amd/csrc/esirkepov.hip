@@ -34,7 +34,7 @@ namespace {
 
 constexpr int kBW = 4;            // cells (waves) per workgroup along x
 constexpr int kBC = 32;           // particles staged per pass and wave
-constexpr int kBPad = kBC + 1;
+constexpr int kBPad = kBC + 2;      // row pitch 34 doubles: the 4 rows x 2 particles one LDS cycle reads fall in 8 distinct bank pairs
 constexpr int kD = 4;             // deposit box per axis: nodes c-1 .. c+2
 constexpr int kJX = kBW + kD - 1; // J tile nodes along x
 constexpr int kJN = kJX * kD * kD;
@@ -191,12 +191,9 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
   const int lc = has_line ? lane / (kD * kD) : 0;
   const int liA = (lane % (kD * kD)) % kD, liB = (lane % (kD * kD)) / kD;
   const int axA = lc == 1 ? 0 : 1, axB = lc == 2 ? 0 : 2;
-  const double qd = alpha * (lc == 0 ? g.dx : (lc == 1 ? g.dy : g.dz));
-  const double* soA = st + (axA * kD + liA) * kBPad;
-  const double* snA = st + (12 + axA * kD + liA) * kBPad;
-  const double* soB = st + (axB * kD + liB) * kBPad;
-  const double* snB = st + (12 + axB * kD + liB) * kBPad;
-  const double* pC = st + (24 + lc * kD) * kBPad;
+  const double qd = alpha * (lc == 0 ? g.dx : (lc == 1 ? g.dy : g.dz)); // the slow path's line
+  const double qdc[3] = {alpha * g.dx, alpha * g.dy, alpha * g.dz};
+  const int kk = lane >> 4, qb = (lane >> 2) & 3, qq = lane & 3;         // phase 2: particle of the step, block, row / column
 
   Ahead<MODE> pf;
   request_tile(0, pf);
@@ -223,7 +220,7 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
     double fr[3] = {pf.r[0], pf.r[1], pf.r[2]}, fv[3] = {pf.v[0], pf.v[1], pf.v[2]};
     request(j + 1, pf);
 
-    double acc[kD] = {0.0, 0.0, 0.0, 0.0};
+    double acc[3] = {0.0, 0.0, 0.0}; // one 4 x 4 block element per component (phase 2)
     for (int base = 0; base < cnt; base += kBC) {
       const int mcnt = min(kBC, cnt - base);
       wave_sync_b();
@@ -231,6 +228,12 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
       bool slow = false;
       double po[3] = {0, 0, 0}, pn[3] = {0, 0, 0};
       int sst[3] = {0, 0, 0}, ssz[3] = {0, 0, 0};
+      if (lane >= mcnt && lane < ((mcnt + 3) & ~3)) {
+        // phase 2 works on K = 4 particles per step: the columns that fill up the last step are particles of weight zero
+        double* col = st + lane;
+#pragma unroll
+        for (int e = 0; e < kSRows; ++e) col[e * kBPad] = 0.0;
+      }
       if (lane < mcnt) {
         const long p = (long)start + base + lane;
         double r[3] = {fr[0], fr[1], fr[2]}, v[3] = {fv[0], fv[1], fv[2]};
@@ -404,28 +407,33 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
       }
       wave_sync_b();
 
-      if (has_line) {
-        // J_c[t][iA][iB] += P_c[t] * T,  T = -qd (Sn_A (2 Sn_B + So_B) + So_A (2 So_B + Sn_B))
-#pragma unroll 4
-        for (int p = 0; p < mcnt; ++p) {
-          const double T = -qd * (snA[p] * (2.0 * snB[p] + soB[p]) + soA[p] * (2.0 * soB[p] + snB[p]));
+      // ---- phase 2 on the matrix cores: J_c[i][u][w] += sum_p P_c[i] * T_c[u][w],
+      //   T_c[u][w] = -qd_c (Sn_A[u] (2 Sn_B[w] + So_B[w]) + So_A[u] (2 So_B[w] + Sn_B[w]))
+      // is, per component, a 4 x 16 x P product: one v_mfma_f64_4x4x4_4b_f64 per K = 4 particles with block b = w, rows
+      // i, columns u (lane roles A[b][i][k], B[b][k][j] at lane 16 k + 4 b + (i or j); D[b][i][j] at lane 16 i + 4 b + j).
+      // The lane forms its own T from the staged 1-D spline values of particle k.
+      for (int t0 = 0; t0 < mcnt; t0 += 4) {
+        const double* cp = st + t0 + kk;
 #pragma unroll
-          for (int t = 0; t < kD; ++t) acc[t] += pC[t * kBPad + p] * T;
+        for (int c = 0; c < 3; ++c) {
+          const int aA = c == 1 ? 0 : 1, aB = c == 2 ? 0 : 2; // X: A = y, B = z;  Y: A = x, B = z;  Z: A = y, B = x
+          const double sA_o = cp[(aA * kD + qq) * kBPad], sA_n = cp[(12 + aA * kD + qq) * kBPad];
+          const double sB_o = cp[(aB * kD + qb) * kBPad], sB_n = cp[(12 + aB * kD + qb) * kBPad];
+          const double T = -qdc[c] * (sA_n * (2.0 * sB_n + sB_o) + sA_o * (2.0 * sB_o + sB_n));
+          acc[c] = __builtin_amdgcn_mfma_f64_4x4x4f64(cp[(24 + c * kD + qq) * kBPad], T, acc[c], 0, 0, 0);
         }
       }
     }
 
     request_tile(j + 1, pf);
     // ---- merge the chunk's cells in the LDS J window: column 0 is node x = cx0 - 1
-    if (active && has_line) {
+    if (active) {
+      // lane holds J_c[i = lane >> 4][u = lane & 3][w = (lane >> 2) & 3]: own-axis node i, A-index u, B-index w
+      const int di = lane >> 4;
+      const int tX[3] = {wave + di, wave + qq, wave + qb}, tY[3] = {qq, di, qq}, tZ[3] = {qb, qb, di};
 #pragma unroll
-      for (int t = 0; t < kD; ++t) {
-        int tx, ty, tz;
-        if (lc == 0) { tx = wave + t; ty = liA; tz = liB; }
-        else if (lc == 1) { tx = wave + liA; ty = t; tz = liB; }
-        else { tx = wave + liB; ty = liA; tz = t; }
-        if (acc[t] != 0.0) unsafeAtomicAdd(&jtile[lc * kJN + (tz * kD + ty) * kJX + tx], acc[t]);
-      }
+      for (int c = 0; c < 3; ++c)
+        if (acc[c] != 0.0) unsafeAtomicAdd(&jtile[c * kJN + (tZ[c] * kD + tY[c]) * kJX + tX[c]], acc[c]);
     }
     lds_barrier_b();
     // ---- the next chunk starts at node cx0 + 3: the first kBW columns are final and leave with one fp64 atomic per
