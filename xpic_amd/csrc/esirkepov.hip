@@ -33,8 +33,27 @@ namespace xpic {
 namespace {
 
 constexpr int kBW = 4;            // cells (waves) per workgroup along x
-constexpr int kBC = 32;           // particles staged per pass and wave
-constexpr int kBPad = kBC + 2;      // row pitch 34 doubles: the 4 rows x 2 particles one LDS cycle reads fall in 8 distinct bank pairs
+// Particles staged per pass and wave.  A pass costs nearly the same whatever it holds (the wave issues the same VALU
+// stream for 1 or 64 particles), so the pass is as wide as the LDS allows at the occupancy the registers allow: 48 with
+// the gather tile (MODE 0, 2 workgroups/CU), 36 at 3 workgroups/CU (MODE 1), 48 at 2 (MODE 2).  A 32-ppc Poisson cell
+// exceeds 48 particles with probability 0.003, 36 with 0.21, 32 with 0.45 (measured: basic 17.8 -> 12.0 ms,
+// ecsimcorr pushes 7.0/10.9 -> 6.6/8.9 ms at 128^3 x 32).
+#ifndef ESK_BC0
+#define ESK_BC0 48
+#endif
+#ifndef ESK_BC1
+#define ESK_BC1 36
+#endif
+#ifndef ESK_BC2
+#define ESK_BC2 48
+#endif
+template <int MODE> struct StageDim {
+  static constexpr int kBC = MODE == 0 ? ESK_BC0 : MODE == 1 ? ESK_BC1 : ESK_BC2;
+  // row pitch: the 4 rows x 2 particles one LDS cycle of the phase-2 reads touches fall in 8 distinct bank pairs for
+  // pitches 2, 6, 18, 22 (mod 32) -- 34, 38, 50 here
+  static constexpr int kBPad = kBC + 2;
+  static_assert(kBC % 4 == 0 && (kBPad % 32 == 2 || kBPad % 32 == 6 || kBPad % 32 == 18 || kBPad % 32 == 22), "stage pitch");
+};
 constexpr int kD = 4;             // deposit box per axis: nodes c-1 .. c+2
 constexpr int kJX = kBW + kD - 1; // J tile nodes along x
 constexpr int kJN = kJX * kD * kD;
@@ -102,6 +121,7 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
   int* bad_count)
 {
   // workgroup -> the x-pencil (cy, cz), marched in chunks of kBW cells (one cell per wave)
+  constexpr int kBC = StageDim<MODE>::kBC, kBPad = StageDim<MODE>::kBPad;
   const int cy = blockIdx.x % g.ny;
   const int cz = blockIdx.x / g.ny;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
