@@ -5,24 +5,30 @@
 // with Shape (src/utils/shape.cpp:31-80), SimpleInterpolation (src/algorithms/simple_interpolation.cpp:8-38)
 // and EsirkepovDecomposition (src/algorithms/esirkepov_decomposition.cpp:20-103) for cell-sorted SoA particles.
 //
-// A workgroup owns one x-pencil of cells and marches along it in chunks of 4 cells (one wave per cell); what a chunk
-// needs from global memory -- the first pass of particles of each cell, the gather tile (MODE 0), the CIC
-// neighbourhoods (MODE 2) -- is requested one chunk ahead.
-//   * phase 1 (lane = particle) moves / pushes the particle.  MODE 0 gathers E, B with the 2nd-order shape out of an
-//     LDS tile of the 9 x 6 x 6 nodes the workgroup's particles can reach at mid-step (only the three nodes per axis
-//     and weight type that spline_of_2nd_order does not return as exact zeros: the sums are bitwise those of the
-//     reference's loop over its 3..4-wide box); MODE 2 gathers with the CIC weights out of the cell's 36 + 54 value
-//     neighbourhood in LDS, like k_second_push.
+// A workgroup (4 waves) owns one x-pencil of cells and marches along it in ROUNDS.  A round takes the particles of as
+// many consecutive cells as fit into its 240 stage columns (up to 8 cells; a cell's columns are padded to a multiple
+// of 4; a cell with more particles than a round holds continues in the next round) and hands them out one per thread,
+// so that the waves are full whatever the number of particles per cell: the instruction stream of a wave costs the same
+// for 1 or 64 live lanes, and with one wave per cell (the previous organisation) a 32-particle cell left half of them
+// idle.  What a round needs from global memory -- its particles, the CIC neighbourhoods of its cells (MODE 2) -- is
+// requested one round ahead; the round table itself is composed one round ahead from cell_start (scalar loads).
+//   * phase 1 (thread = particle) moves / pushes the particle.  MODE 0 gathers E, B with the 2nd-order shape out of an
+//     LDS tile of the 13 x 6 x 6 nodes the round's particles can reach at mid-step (only the three nodes per axis and
+//     weight type that spline_of_2nd_order does not return as exact zeros, summed in the order of the reference's loop
+//     over its 3..4-wide box); the tile shares the LDS of the stage, which is written after every gather is done.
+//     MODE 2 gathers with the CIC weights out of the cells' 36 + 54 value neighbourhoods in LDS, like k_second_push.
 //   * A particle that starts in cell c and ends less than about half a cell away (every particle of the BASELINE
 //     workloads) has old and new spline supports inside the nodes c-1 .. c+2 of each axis.  For those the deposit is
 //     the dense 4 x 4 x 4 box per component: phase 1 stages the 1-D old / new spline values and the prefix sums of
-//     their differences on these 4 nodes; in phase 2 lane = one of the 48 "lines" of the cell (component, two
-//     transverse node indices), which adds  P_c[t] * T  to its 4 nodes particle after particle -- the reference's
-//     running sum temp_j += W (:57-103) with the sum over the line taken first.  No atomics inside a cell.
+//     their differences on these 4 nodes (36 values per particle, one stage column).
+//   * phase 2 runs on the matrix cores: per component the box of a cell is  J_c[i][u][w] += sum_p P_c[i] T_c[u][w]
+//     (the reference's running sum temp_j += W, :57-103, with the sum over the line taken first), one
+//     v_mfma_f64_4x4x4_4b_f64 per 4 particles (a "K step").  The K steps of the round are dealt out evenly to the four
+//     waves; a wave that passes from one cell to the next adds its box into the J window.  No atomics inside a cell.
 //   * A particle that moves further (up to the reference's own limit of one cell, shape.h:18,91-92) deposits its box
 //     directly with fp64 atomics (slow path, same arithmetic as the reference's loop).
-//   * The chunk's lines are merged in a sliding LDS J window (7 x 4 x 4 nodes per component); the 4 columns the march
-//     has passed leave with one fp64 atomic per node.
+//   * The boxes are merged in a circular LDS J window (11 x 4 x 4 nodes per component); the columns the march has
+//     passed leave with one fp64 atomic per node.
 #include <cstring>
 
 #include "common.h"
@@ -32,43 +38,48 @@ namespace xpic {
 
 namespace {
 
-constexpr int kBW = 4;            // cells (waves) per workgroup along x
-// Particles staged per pass and wave.  A pass costs nearly the same whatever it holds (the wave issues the same VALU
-// stream for 1 or 64 particles), so the pass is as wide as the LDS allows at the occupancy the registers allow: 48 with
-// the gather tile (MODE 0, 2 workgroups/CU), 36 at 3 workgroups/CU (MODE 1), 48 at 2 (MODE 2).  A 32-ppc Poisson cell
-// exceeds 48 particles with probability 0.003, 36 with 0.21, 32 with 0.45 (measured: basic 17.8 -> 12.0 ms,
-// ecsimcorr pushes 7.0/10.9 -> 6.6/8.9 ms at 128^3 x 32).
-#ifndef ESK_BC0
-#define ESK_BC0 48
+#ifdef ESK_STAMPS
+// in-kernel section timers (experiment build only): s_memtime deltas of wave 0 summed per section over all workgroups
+__device__ unsigned long long g_esk_stamps[16];
+#define STAMP(k)                                                  \
+  do {                                                            \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    stamp_acc_[k] += now_ - stamp_t_;                             \
+    stamp_t_ = now_;                                              \
+  } while (0)
+#else
+#define STAMP(k)
 #endif
-#ifndef ESK_BC1
-#define ESK_BC1 36
-#endif
-#ifndef ESK_BC2
-#define ESK_BC2 48
+constexpr int kW = 4;                 // waves per workgroup
+constexpr int kThreadsB = kW * 64;
+constexpr int kSeg = 8;               // cells (segments) per round
+// Columns of the stage = particles of a round, each cell's padded to a multiple of 4 (the K of the MFMA step).  A wave
+// issues the same instruction stream for 1 or 64 particles, so a round packs the particles of as many cells of the
+// pencil as fit: at 32 particles per cell about 7 cells = 224 of the 256 lanes, where one wave per cell filled 32 of 64.
+#ifndef ESK_COLS1
+#define ESK_COLS1 160
 #endif
 template <int MODE> struct StageDim {
-  static constexpr int kBC = MODE == 0 ? ESK_BC0 : MODE == 1 ? ESK_BC1 : ESK_BC2;
-  // row pitch: the 4 rows x 2 particles one LDS cycle of the phase-2 reads touches fall in 8 distinct bank pairs for
-  // pitches 2, 6, 18, 22 (mod 32) -- 34, 38, 50 here
-  static constexpr int kBPad = kBC + 2;
-  static_assert(kBC % 4 == 0 && (kBPad % 32 == 2 || kBPad % 32 == 6 || kBPad % 32 == 18 || kBPad % 32 == 22), "stage pitch");
+  static constexpr int kCols = MODE == 1 ? ESK_COLS1 : 240;
+  static constexpr int kPitch = kCols + 4; // row pitch: 4 rows x 4 columns of a phase-2 read fall in 16 distinct bank pairs (pitch = 4 mod 8)
+  static_assert(kCols % 4 == 0 && kCols <= kThreadsB && kPitch % 8 == 4, "stage geometry");
 };
-constexpr int kD = 4;             // deposit box per axis: nodes c-1 .. c+2
-constexpr int kJX = kBW + kD - 1; // J tile nodes along x
+constexpr int kD = 4;                 // deposit box per axis: nodes c-1 .. c+2
+constexpr int kJX = kSeg + kD - 1;    // J window nodes along x
 constexpr int kJN = kJX * kD * kD;
-constexpr int kSRows = 36;        // So[3][4], Sn[3][4], P[3][4]
-constexpr int kT = 6;             // gather tile per axis (MODE 0): nodes c-2 .. c+3
-constexpr int kTX = kBW + kT - 1;
+constexpr int kJPer = (3 * kJN + kThreadsB - 1) / kThreadsB; // window elements per thread
+constexpr int kSRows = 36;            // So[3][4], Sn[3][4], P[3][4]
+constexpr int kT = 6;                 // gather tile per axis (MODE 0): nodes c-2 .. c+3
+constexpr int kTX = kSeg + kT - 1;
 constexpr int kTileN = kTX * kT * kT;
-constexpr int kThreadsB = kBW * 64;
-constexpr int kLinesB = 3 * kD * kD; // 48 lines of 4 nodes
 constexpr int kFtPer = (6 * kTileN + kThreadsB - 1) / kThreadsB; // gather-tile values per thread
-constexpr int kMaxNxB = 1024;        // pencils up to this length keep their cell_start row in LDS
-static_assert(3 * kJN <= 2 * kThreadsB, "two window elements per thread");
+constexpr int kLinesB = 3 * kD * kD;  // 48 lines of 4 nodes
+constexpr int kNb = 36 + 54;          // CIC neighbourhood of a cell (MODE 2): 3 x 12 E nodes, 54 B nodes
+constexpr int kNbPer = (kSeg * kNb + kThreadsB - 1) / kThreadsB;
+static_assert(6 * kTileN <= kSRows * StageDim<0>::kPitch, "the gather tile shares the stage's LDS");
 
 // raw workgroup barrier that only drains LDS traffic: the particle stores, the J atomics and the requests of the next
-// chunk stay in flight across it (__syncthreads() would wait for every one of them: a round trip to HBM per chunk)
+// round stay in flight across it (__syncthreads() would wait for every one of them: a round trip to HBM per round)
 __device__ inline void lds_barrier_b()
 {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -80,13 +91,14 @@ __device__ inline void wave_sync_b()
   __builtin_amdgcn_wave_barrier();
 }
 
-// spline_of_2nd_order (src/interfaces/sort_parameters.cpp:21-30)
+// spline_of_2nd_order (src/interfaces/sort_parameters.cpp:21-30): 0.75 - s^2 for |s| <= 0.5, 0.5 (1.5 - |s|)^2 for
+// 0.5 < |s| < 1.5, else 0 -- the same expressions; the outer zero comes out of the clamp (0.5 * 0 * 0) instead of a
+// third branch
 __device__ inline double spline2(double s)
 {
   s = fabs(s);
-  if (s <= 0.5) return (0.75 - s * s);
-  if (0.5 < s && s < 1.5) return 0.5 * (1.5 - s) * (1.5 - s);
-  return 0.0;
+  const double t = 1.5 - fmin(s, 1.5);
+  return s <= 0.5 ? (0.75 - s * s) : 0.5 * t * t;
 }
 
 __device__ inline double wave_sum_b(double v)
@@ -104,15 +116,28 @@ __device__ inline double lane_value(double v, int src)
   return __builtin_bit_cast(double, ((long long)hi << 32) | lo);
 }
 
-// what a wave requests one chunk ahead: its next cell's first pass of particles (and, MODE 2, the cell's CIC
-// neighbourhoods; MODE 0, this thread's share of the workgroup's next gather tile)
+// One round of a pencil: up to kSeg segments, each the (rest of the) particles of one cell.  A cell with more particles
+// than a round holds is continued in the next round (then alone in its round's first segment).
+struct RoundTab {
+  int base;            // first cell of the round: the J window's column 0 is node base - 1
+  int nseg, ncols, tcount;
+  int adv;             // cells completed by the round: the window moves on by this many columns
+  int cell[kSeg];      // cell - base
+  int start[kSeg];     // first particle
+  int col0[kSeg + 1];  // first stage column (multiple of 4)
+  int toff[kSeg + 1];  // first thread
+};
+
+// what a thread requests one round ahead: its particle of the next round (and, MODE 2, its share of the cells' CIC
+// neighbourhoods)
 template <int MODE>
 struct Ahead {
-  int start, cnt;
+  int p, col, crel, seg; // particle (-1: none), stage column, cell - base, segment
   double r[3], v[3];
-  double e, b;                       // MODE 2: lane's value of the 36 E / 54 B neighbourhood
-  double ft[MODE == 0 ? kFtPer : 1]; // MODE 0: tile values t = thread + k * kThreadsB
+  double nb[MODE == 2 ? kNbPer : 1];
 };
+
+using UniformInts = const __attribute__((address_space(4))) int*; // wave-uniform reads of cell_start: scalar loads
 
 // P2: power-of-two spacings (exact reciprocals instead of divisions, device_common.h: scaled_position)
 template <int MODE, bool P2>
@@ -120,89 +145,129 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
   const double* __restrict__ B, double* __restrict__ J, double qm, double alpha, double qn_Np, double* pred_w,
   int* bad_count)
 {
-  // workgroup -> the x-pencil (cy, cz), marched in chunks of kBW cells (one cell per wave)
-  constexpr int kBC = StageDim<MODE>::kBC, kBPad = StageDim<MODE>::kBPad;
+  // workgroup -> the x-pencil (cy, cz), marched in rounds
+  constexpr int kCols = StageDim<MODE>::kCols, kPitch = StageDim<MODE>::kPitch;
   const int cy = blockIdx.x % g.ny;
   const int cz = blockIdx.x / g.ny;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 
-  __shared__ double stage[kBW][kSRows * kBPad];
+  __shared__ double stage[kSRows * kPitch];
   __shared__ double jtile[3 * kJN];
-  __shared__ double ftile[MODE == 0 ? 6 * kTileN : 1];   // Ex,Ey,Ez,Bx,By,Bz on the gather tile (basic only)
-  __shared__ double nbE[MODE == 2 ? kBW : 1][36], nbB[MODE == 2 ? kBW : 1][54]; // CIC neighbourhoods (second_push only)
-  __shared__ double pwsum[kBW];
-  __shared__ int cstart[kMaxNxB + 2];
+  __shared__ double nbv[MODE == 2 ? kSeg * kNb : 1]; // CIC neighbourhoods of the round's cells (second_push only)
+  __shared__ double pwsum[kW];
+  __shared__ RoundTab tab[2];
+  double* const ftile = stage; // Ex,Ey,Ez,Bx,By,Bz on the gather tile (basic only): dead before the first stage write
 
   const long pencil0 = ((long)cz * g.ny + cy) * g.nx;
-  const bool cs_lds = g.nx <= kMaxNxB;
-  if (cs_lds)
-    for (int i = threadIdx.x; i <= g.nx; i += kThreadsB) cstart[i] = s.cell_start[pencil0 + i];
+  UniformInts cs = (UniformInts)(s.cell_start + pencil0);
   for (int t = threadIdx.x; t < 3 * kJN; t += kThreadsB) jtile[t] = 0.0;
-  __syncthreads();
 
-  // neighbourhood slot of this lane (MODE 2): numbering of the cell's 3 x 12 E nodes and 54 B nodes as in k_second_push
-  int ec = 0, eo[3] = {0, 0, 0}, bc = 0, bo[3] = {0, 0, 0};
+  // this thread's entries e = thread + i * kThreadsB of the kSeg x 90 neighbourhood table (MODE 2): segment, field
+  // component and node offset, numbered as in k_second_push; packed seg | comp << 4 | isB << 6 | (d + 1) << 8, 10, 12
+  int nbd[MODE == 2 ? kNbPer : 1];
   if (MODE == 2) {
-    if (lane < 36) {
-      ec = lane / 12;
-      const int l = lane % 12;
-      if (ec == 0) { eo[0] = l % 3 - 1; eo[1] = (l / 3) % 2; eo[2] = l / 6; }
-      else if (ec == 1) { eo[0] = l % 2; eo[1] = (l / 2) % 3 - 1; eo[2] = l / 6; }
-      else { eo[0] = l % 2; eo[1] = (l / 2) % 2; eo[2] = l / 4 - 1; }
-    }
-    if (lane < 54) {
-      if (lane < 18) { bc = 0; bo[0] = lane % 2; bo[1] = (lane / 2) % 3 - 1; bo[2] = lane / 6 - 1; }
-      else if (lane < 36) { const int l = lane - 18; bc = 1; bo[0] = l % 3 - 1; bo[1] = (l / 3) % 2; bo[2] = l / 6 - 1; }
-      else { const int l = lane - 36; bc = 2; bo[0] = l % 3 - 1; bo[1] = (l / 3) % 3 - 1; bo[2] = l / 9; }
+#pragma unroll
+    for (int i = 0; i < kNbPer; ++i) {
+      const int e = threadIdx.x + i * kThreadsB;
+      const int sg = e / kNb, k = e % kNb;
+      int comp, isB, d0, d1, d2;
+      if (k < 36) {
+        isB = 0;
+        comp = k / 12;
+        const int l = k % 12;
+        if (comp == 0) { d0 = l % 3 - 1; d1 = (l / 3) % 2; d2 = l / 6; }
+        else if (comp == 1) { d0 = l % 2; d1 = (l / 2) % 3 - 1; d2 = l / 6; }
+        else { d0 = l % 2; d1 = (l / 2) % 2; d2 = l / 4 - 1; }
+      }
+      else {
+        isB = 1;
+        const int kb = k - 36;
+        if (kb < 18) { comp = 0; d0 = kb % 2; d1 = (kb / 2) % 3 - 1; d2 = kb / 6 - 1; }
+        else if (kb < 36) { const int l = kb - 18; comp = 1; d0 = l % 3 - 1; d1 = (l / 3) % 2; d2 = l / 6 - 1; }
+        else { const int l = kb - 36; comp = 2; d0 = l % 3 - 1; d1 = (l / 3) % 3 - 1; d2 = l / 9; }
+      }
+      nbd[i] = e < kSeg * kNb ? (sg | comp << 4 | isB << 6 | (d0 + 1) << 8 | (d1 + 1) << 10 | (d2 + 1) << 12) : -1;
     }
   }
 
-  // the gather tile of chunk j (MODE 0): requested after the arithmetic of the chunk before, so that its registers
-  // are not held across phases 1 and 2
-  auto request_tile = [&](int j, Ahead<MODE>& pf) {
-    const int cxa0 = j * kBW;
-    if (MODE == 0 && cxa0 < g.nx) {
-      // DMGlobalToLocal(E), (B) (basic/simulation.cpp:56-57) for just the nodes the chunk's particles can gather from
+  // (the J window is circular: see the flush at the end of a round)
+  // ---- the next round's composition: whole cells while their padded columns fit (every thread runs the same scalar
+  // loop; thread 0 records it)
+  int cur = 0, cur_off = 0;
+  auto compose = [&](RoundTab& T) {
+    const int base = cur;
+    // the cell_start entries the round can need, requested together (one scalar-cache latency instead of one per cell)
+    int cv[kSeg + 1];
 #pragma unroll
-      for (int k = 0; k < kFtPer; ++k) {
-        const int t = threadIdx.x + k * kThreadsB;
-        pf.ft[k] = 0.0;
-        if (t < 6 * kTileN) {
-          const int f = t / kTileN, n = t % kTileN;
-          const int tx = n % kTX, ty = (n / kTX) % kT, tz = n / (kTX * kT);
-          const double* F = (f < 3 ? E : B) + (f % 3) * g.cstride;
-          pf.ft[k] = F[g.nodew(cxa0 - 2 + tx, cy - 2 + ty, cz - 2 + tz)];
+    for (int i = 0; i <= kSeg; ++i) cv[i] = cs[min(base + i, g.nx)];
+    int nseg = 0, cols = 0, tc = 0;
+    bool open = true;
+#pragma unroll
+    for (int i = 0; i < kSeg; ++i) {
+      if (open && base + i < g.nx) {
+        const int c0 = cv[i] + (i == 0 ? cur_off : 0);
+        const int rem = cv[i + 1] - c0;
+        if (rem <= 0) { cur = base + i + 1; cur_off = 0; }
+        else {
+          const int room = kCols - cols;
+          int take = rem;
+          bool fits = true;
+          if (((rem + 3) & ~3) > room) {
+            if (nseg > 0) fits = false;
+            else take = room; // a cell of more than kCols particles: a full round of it
+          }
+          if (!fits) open = false;
+          else {
+            if (threadIdx.x == 0) { T.cell[nseg] = i; T.start[nseg] = c0; T.col0[nseg] = cols; T.toff[nseg] = tc; }
+            ++nseg;
+            cols += (take + 3) & ~3;
+            tc += take;
+            if (take == rem) { cur = base + i + 1; cur_off = 0; }
+            else { cur_off = (i == 0 ? cur_off : 0) + take; cur = base + i; open = false; }
+          }
         }
       }
     }
+    if (threadIdx.x == 0) {
+      T.base = base; T.nseg = nseg; T.ncols = cols; T.tcount = tc; T.adv = cur - base;
+      T.col0[nseg] = cols; T.toff[nseg] = tc;
+    }
   };
-  auto request = [&](int j, Ahead<MODE>& pf) {
-    pf.start = 0; pf.cnt = 0; pf.e = 0.0; pf.b = 0.0;
-    const int cxa = j * kBW + wave;
-    if (cxa >= g.nx) return;
-    if (cs_lds) {
-      pf.start = __builtin_amdgcn_readfirstlane(cstart[cxa]);
-      pf.cnt = __builtin_amdgcn_readfirstlane(cstart[cxa + 1]) - pf.start;
-    }
-    else {
-      pf.start = __builtin_amdgcn_readfirstlane(s.cell_start[pencil0 + cxa]);
-      pf.cnt = __builtin_amdgcn_readfirstlane(s.cell_start[pencil0 + cxa + 1]) - pf.start;
-    }
-    if (MODE == 2 && pf.cnt > 0) {
-      if (lane < 36) pf.e = E[ec * g.cstride + g.nodew(cxa + eo[0], cy + eo[1], cz + eo[2])];
-      if (lane < 54) pf.b = B[bc * g.cstride + g.nodew(cxa + bo[0], cy + bo[1], cz + bo[2])];
-    }
-    // MODE 0 (the register-hungry 2nd-order gather) loads its particles when it gets there instead
-    if (MODE != 0 && lane < min(kBC, pf.cnt)) {
-      const long p = (long)pf.start + lane;
+
+  auto request = [&](const RoundTab& T, Ahead<MODE>& pf) {
+    pf.p = -1; pf.col = 0; pf.crel = 0; pf.seg = 0;
 #pragma unroll
-      for (int a = 0; a < 3; ++a) { pf.r[a] = s.r[a][p]; pf.v[a] = s.v[a][p]; }
+    for (int a = 0; a < 3; ++a) { pf.r[a] = 0.0; pf.v[a] = 0.0; }
+    const int nseg = T.nseg;
+    if ((int)threadIdx.x < T.tcount) {
+      int sg = 0;
+#pragma unroll
+      for (int i = 1; i < kSeg; ++i) sg += (i < nseg && (int)threadIdx.x >= T.toff[i]) ? 1 : 0;
+      const int k = (int)threadIdx.x - T.toff[sg];
+      pf.seg = sg; pf.p = T.start[sg] + k; pf.col = T.col0[sg] + k; pf.crel = T.cell[sg];
+      // MODE 0 (the register-hungry 2nd-order gather) loads its particle when it gets there instead
+      if (MODE != 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { pf.r[a] = s.r[a][pf.p]; pf.v[a] = s.v[a][pf.p]; }
+      }
+    }
+    if (MODE == 2) {
+      const int base = T.base;
+#pragma unroll
+      for (int i = 0; i < kNbPer; ++i) {
+        pf.nb[i] = 0.0;
+        const int d = nbd[i];
+        if (d >= 0 && (d & 15) < nseg) {
+          const int cx = base + T.cell[d & 15];
+          const double* F = ((d >> 6) & 1 ? B : E) + ((d >> 4) & 3) * g.cstride;
+          pf.nb[i] = F[g.nodew(cx + ((d >> 8) & 3) - 1, cy + ((d >> 10) & 3) - 1, cz + ((d >> 12) & 3) - 1)];
+        }
+      }
     }
   };
 
   double pw = 0.0;
   int bad = 0;
-  double* st = stage[wave];
   const double dt = g.dt;
 
   // the line of this lane: component c along its own axis; transverse axes (A, B) with the reference's roles
@@ -215,275 +280,347 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
   const double qdc[3] = {alpha * g.dx, alpha * g.dy, alpha * g.dz};
   const int kk = lane >> 4, qb = (lane >> 2) & 3, qq = lane & 3;         // phase 2: particle of the step, block, row / column
 
+  compose(tab[0]);
+  __syncthreads();
   Ahead<MODE> pf;
-  request_tile(0, pf);
-  request(0, pf);
-  const int nch = (g.nx + kBW - 1) / kBW;
-  for (int j = 0; j < nch; ++j) {
-    const int cx0 = j * kBW, cx = cx0 + wave;
-    const bool active = cx < g.nx;
-    const int cc[3] = {cx, cy, cz + g.z0};
-    // ---- this chunk's tile / neighbourhoods, requested one chunk ago, go to LDS; then the next chunk's requests
+  request(tab[0], pf);
+#ifdef ESK_STAMPS
+  unsigned long long stamp_t_ = __builtin_readcyclecounter();
+  unsigned long long stamp_acc_[10] = {};
+#endif
+  for (int rd = 0;; ++rd) {
+    STAMP(0);
+    const RoundTab& T = tab[rd & 1];
+    const int base = __builtin_amdgcn_readfirstlane(T.base);
+    if (base >= g.nx) break;
+    const int nseg = __builtin_amdgcn_readfirstlane(T.nseg), ncols = __builtin_amdgcn_readfirstlane(T.ncols);
+    const int adv = __builtin_amdgcn_readfirstlane(T.adv);
+    // ---- this round's neighbourhoods / tile go to LDS; the next round is composed and requested
     if (MODE == 0) {
+      // DMGlobalToLocal(E), (B) (basic/simulation.cpp:56-57) for just the nodes the round's particles can gather from
+      double ft[kFtPer];
 #pragma unroll
       for (int k = 0; k < kFtPer; ++k) {
         const int t = threadIdx.x + k * kThreadsB;
-        if (t < 6 * kTileN) ftile[t] = pf.ft[k];
+        ft[k] = 0.0;
+        if (t < 6 * kTileN && nseg > 0) {
+          const int f = t / kTileN, n = t % kTileN;
+          const int tx = n % kTX, ty = (n / kTX) % kT, tz = n / (kTX * kT);
+          const double* F = (f < 3 ? E : B) + (f % 3) * g.cstride;
+          ft[k] = F[g.nodew(base - 2 + tx, cy - 2 + ty, cz - 2 + tz)];
+        }
       }
-      lds_barrier_b();
+#pragma unroll
+      for (int k = 0; k < kFtPer; ++k) {
+        const int t = threadIdx.x + k * kThreadsB;
+        if (t < 6 * kTileN) ftile[t] = ft[k];
+      }
     }
     if (MODE == 2) {
-      if (lane < 36) nbE[wave][lane] = pf.e;
-      if (lane < 54) nbB[wave][lane] = pf.b;
-    }
-    const int start = pf.start, cnt = pf.cnt;
-    double fr[3] = {pf.r[0], pf.r[1], pf.r[2]}, fv[3] = {pf.v[0], pf.v[1], pf.v[2]};
-    request(j + 1, pf);
-
-    double acc[3] = {0.0, 0.0, 0.0}; // one 4 x 4 block element per component (phase 2)
-    for (int base = 0; base < cnt; base += kBC) {
-      const int mcnt = min(kBC, cnt - base);
-      wave_sync_b();
-      // a particle whose old / new supports leave the cell's 4-node box: deposited by the whole wave further down
-      bool slow = false;
-      double po[3] = {0, 0, 0}, pn[3] = {0, 0, 0};
-      int sst[3] = {0, 0, 0}, ssz[3] = {0, 0, 0};
-      if (lane >= mcnt && lane < ((mcnt + 3) & ~3)) {
-        // phase 2 works on K = 4 particles per step: the columns that fill up the last step are particles of weight zero
-        double* col = st + lane;
 #pragma unroll
-        for (int e = 0; e < kSRows; ++e) col[e * kBPad] = 0.0;
+      for (int i = 0; i < kNbPer; ++i) {
+        const int e = threadIdx.x + i * kThreadsB;
+        if (e < kSeg * kNb) nbv[e] = pf.nb[i];
       }
-      if (lane < mcnt) {
-        const long p = (long)start + base + lane;
-        double r[3] = {fr[0], fr[1], fr[2]}, v[3] = {fv[0], fv[1], fv[2]};
-        if (MODE == 0 || base > 0) { // cells beyond one pass (and MODE 0): plain loads
-#pragma unroll
-          for (int a = 0; a < 3; ++a) { r[a] = s.r[a][p]; v[a] = s.v[a][p]; }
-        }
-        const double old_r[3] = {r[0], r[1], r[2]};
-        double Ep[3] = {0, 0, 0}, Bp[3] = {0, 0, 0};
+    }
+    const int p = pf.p, col = pf.col, crel = pf.crel, seg = pf.seg;
+    double r[3] = {pf.r[0], pf.r[1], pf.r[2]}, v[3] = {pf.v[0], pf.v[1], pf.v[2]};
+    STAMP(1);
+    compose(tab[(rd + 1) & 1]);
+    STAMP(2);
+    lds_barrier_b();
+    STAMP(3);
+    request(tab[(rd + 1) & 1], pf);
+    STAMP(4);
 
-        if (MODE == 0) {
-          // push.update_r(dt / 2) ; shape.setup(point.r) ; interpolation.process   (basic/particles.cpp:31-38)
+    // ---- phase 1: thread = particle
+    const int cc[3] = {base + crel, cy, cz + g.z0};
+    // a particle whose old / new supports leave the cell's 4-node box: deposited by the whole wave further down
+    bool slow = false, fast = false;
+    double po[3] = {0, 0, 0}, pn[3] = {0, 0, 0};
+    int sst[3] = {0, 0, 0}, ssz[3] = {0, 0, 0};
+    if (p >= 0) {
+      if (MODE == 0) {
 #pragma unroll
-          for (int a = 0; a < 3; ++a) r[a] += v[a] * (dt / 2.0);
-          // Shape::make_start / make_end (shape.cpp:12-28) give the box [sst, sst + ssz), ssz = 3 or 4.  Inside it
-          // spline_of_2nd_order is an exact zero outside three nodes: for the node-centred weights ("No") those are
-          // sst + nN .. sst + nN + 2 with nN = 0 or 1, for the half-shifted ones ("Sh") always sst .. sst + 2.
-          int off[3], nN[3];
-          double No[3][3], Sh[3][3];
-          bool inside = true;
-          double prs[3];
-          scaled_position<P2>(g, r[0], r[1], r[2], prs);
+        for (int a = 0; a < 3; ++a) { r[a] = s.r[a][p]; v[a] = s.v[a][p]; }
+      }
+      const double old_r[3] = {r[0], r[1], r[2]};
+      double Ep[3] = {0, 0, 0}, Bp[3] = {0, 0, 0};
+
+      if (MODE == 0) {
+        // push.update_r(dt / 2) ; shape.setup(point.r) ; interpolation.process   (basic/particles.cpp:31-38)
 #pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            const double pr = prs[a];
-            const int sst = (int)round(pr - 1.5);
-            const int ssz = (int)floor(pr + 1.5) + 1 - sst;
-            inside = inside && sst >= cc[a] - 2 && sst + ssz <= cc[a] + 4;
-            nN[a] = (pr - (double)sst) < 1.5 ? 0 : 1; // node sst has |pr - sst| < 1.5, or node sst + 3 may have
-            off[a] = sst - (cc[a] - 2);
+        for (int a = 0; a < 3; ++a) r[a] += v[a] * (dt / 2.0);
+        // Shape::make_start / make_end (shape.cpp:12-28) give the box [sst, sst + ssz), ssz = 3 or 4.  Inside it
+        // spline_of_2nd_order is an exact zero outside three nodes: for the node-centred weights ("No") those are
+        // sst + nN .. sst + nN + 2 with nN = 0 or 1, for the half-shifted ones ("Sh") always sst .. sst + 2.
+        int off[3], nN[3];
+        double No[3][3], Sh[3][3];
+        bool inside = true;
+        double prs[3];
+        scaled_position<P2>(g, r[0], r[1], r[2], prs);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-              No[a][t] = spline2(pr - (double)(sst + nN[a] + t));  // Shape::fill, :57-80
-              Sh[a][t] = spline2(pr - ((double)(sst + t) + 0.5));
-            }
+        for (int a = 0; a < 3; ++a) {
+          const double pr = prs[a];
+          const int gst = (int)round(pr - 1.5);
+          const int gsz = (int)floor(pr + 1.5) + 1 - gst;
+          inside = inside && gst >= cc[a] - 2 && gst + gsz <= cc[a] + 4;
+          nN[a] = (pr - (double)gst) < 1.5 ? 0 : 1; // node gst has |pr - gst| < 1.5, or node gst + 3 may have
+          off[a] = gst - (cc[a] - 2);
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            No[a][t] = spline2(pr - (double)(gst + nN[a] + t));  // Shape::fill, :57-80
+            Sh[a][t] = spline2(pr - ((double)(gst + t) + 0.5));
           }
-          if (inside) {
-            off[0] += wave; // tile x origin is cx0 - 2, the cell's own is cx - 2
-            // the reference's loop order (x fastest, then y, z), zero terms left out
-            const int bN[3] = {off[0] + nN[0], off[1] + nN[1], off[2] + nN[2]};
-            // the z loop stays a loop: unrolled, the compiler keeps all 36 weight products of the box live at once
+        }
+        if (inside) {
+          off[0] += crel; // tile x origin is base - 2, the cell's own is cx - 2
+          // the reference's loop order (x fastest, then y, z), zero terms left out
+          const int bN[3] = {off[0] + nN[0], off[1] + nN[1], off[2] + nN[2]};
+          // the z loop stays a loop: unrolled, the compiler keeps all 36 weight products of the box live at once
 #pragma nounroll
-            for (int kz = 0; kz < 3; ++kz) {
-              const double nz = No[2][kz], sz = Sh[2][kz];
-              const int zN = (bN[2] + kz) * kT, zS = (off[2] + kz) * kT;
+          for (int kz = 0; kz < 3; ++kz) {
+            const double nz = No[2][kz], sz = Sh[2][kz];
+            const int zN = (bN[2] + kz) * kT, zS = (off[2] + kz) * kT;
 #pragma unroll
-              for (int jy = 0; jy < 3; ++jy) {
-                const int yN = bN[1] + jy, yS = off[1] + jy;
-                const double nn = nz * No[1][jy], ns = nz * Sh[1][jy], sn = sz * No[1][jy], ss = sz * Sh[1][jy];
+            for (int jy = 0; jy < 3; ++jy) {
+              const int yN = bN[1] + jy, yS = off[1] + jy;
+              const double nn = nz * No[1][jy], ns = nz * Sh[1][jy], sn = sz * No[1][jy], ss = sz * Sh[1][jy];
+              // the 18 tile values of this (z, y) row pair are requested together and waited for once: left to
+              // itself the compiler waits out the LDS latency after every single read
+              double f[6][3];
 #pragma unroll
-                for (int ix = 0; ix < 3; ++ix) {
-                  // Shape::electric / magnetic (shape.h:54-72): each component has its own three nodes per axis
-                  const int xN = bN[0] + ix, xS = off[0] + ix;
-                  Ep[0] += ftile[0 * kTileN + (zN + yN) * kTX + xS] * (nn * Sh[0][ix]);
-                  Ep[1] += ftile[1 * kTileN + (zN + yS) * kTX + xN] * (ns * No[0][ix]);
-                  Ep[2] += ftile[2 * kTileN + (zS + yN) * kTX + xN] * (sn * No[0][ix]);
-                  Bp[0] += ftile[3 * kTileN + (zS + yS) * kTX + xN] * (ss * No[0][ix]);
-                  Bp[1] += ftile[4 * kTileN + (zS + yN) * kTX + xS] * (sn * Sh[0][ix]);
-                  Bp[2] += ftile[5 * kTileN + (zN + yS) * kTX + xS] * (ns * Sh[0][ix]);
-                }
+              for (int ix = 0; ix < 3; ++ix) {
+                // Shape::electric / magnetic (shape.h:54-72): each component has its own three nodes per axis
+                const int xN = bN[0] + ix, xS = off[0] + ix;
+                f[0][ix] = ftile[0 * kTileN + (zN + yN) * kTX + xS];
+                f[1][ix] = ftile[1 * kTileN + (zN + yS) * kTX + xN];
+                f[2][ix] = ftile[2 * kTileN + (zS + yN) * kTX + xN];
+                f[3][ix] = ftile[3 * kTileN + (zS + yS) * kTX + xN];
+                f[4][ix] = ftile[4 * kTileN + (zS + yN) * kTX + xS];
+                f[5][ix] = ftile[5 * kTileN + (zN + yS) * kTX + xS];
               }
-            }
-          }
-          // else: the particle moved further than the reference itself supports; flagged by the range test below
-          update_vEB(dt, qm, Ep, Bp, v);                 // push.update_vEB(dt)  :41
+              __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int a = 0; a < 3; ++a) r[a] += v[a] * (dt / 2.0); // push.update_r(dt / 2)  :42
-        }
-        else if (MODE == 1) {
-#pragma unroll
-          for (int a = 0; a < 3; ++a) r[a] += v[a] * (0.5 * dt); // BorisPush::update_r(0.5 * dt)  ecsimcorr/particles.cpp:39
-        }
-        else {
-          // interpolate_E_s1 / interpolate_B_s1 ; update_vEB(dt) ; update_r(0.5 dt)   (:64-69), gathers out of the
-          // cell's LDS neighbourhood in the loop and product order of ecsim/simulation.cpp:8-118
-          const double old_v[3] = {v[0], v[1], v[2]};
-          const W1T<P2> w(g, r[0], r[1], r[2]);
-          const int ox = w.is[0] - w.in[0] + 1, oy = w.is[1] - w.in[1] + 1, oz = w.is[2] - w.in[2] + 1;
-          const double* eE = nbE[MODE == 2 ? wave : 0];
-          const double* eB = nbB[MODE == 2 ? wave : 0];
-#pragma unroll
-          for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-              for (int i = 0; i < 2; ++i) {
-                Ep[0] += eE[(k * 2 + j) * 3 + (ox + i)] * (w.wn[2][k] * w.wn[1][j] * w.ws[0][i]);
-                Ep[1] += eE[12 + (k * 3 + (oy + j)) * 2 + i] * (w.wn[2][k] * w.ws[1][j] * w.wn[0][i]);
-                Ep[2] += eE[24 + ((oz + k) * 2 + j) * 2 + i] * (w.ws[2][k] * w.wn[1][j] * w.wn[0][i]);
-                Bp[0] += eB[((oz + k) * 3 + (oy + j)) * 2 + i] * (w.ws[2][k] * w.ws[1][j] * w.wn[0][i]);
-                Bp[1] += eB[18 + ((oz + k) * 2 + j) * 3 + (ox + i)] * (w.ws[2][k] * w.wn[1][j] * w.ws[0][i]);
-                Bp[2] += eB[36 + (k * 3 + (oy + j)) * 3 + (ox + i)] * (w.wn[2][k] * w.ws[1][j] * w.ws[0][i]);
+              for (int ix = 0; ix < 3; ++ix) {
+                Ep[0] += f[0][ix] * (nn * Sh[0][ix]);
+                Ep[1] += f[1][ix] * (ns * No[0][ix]);
+                Ep[2] += f[2][ix] * (sn * No[0][ix]);
+                Bp[0] += f[3][ix] * (ss * No[0][ix]);
+                Bp[1] += f[4][ix] * (sn * Sh[0][ix]);
+                Bp[2] += f[5][ix] * (ns * Sh[0][ix]);
               }
-          update_vEB(dt, qm, Ep, Bp, v);
-#pragma unroll
-          for (int a = 0; a < 3; ++a) r[a] += v[a] * (0.5 * dt);
-          // pred_w += qn_Np * 0.5 * (old_v + point.p).dot(E_p)   (:77-78)
-          pw += qn_Np * 0.5 * ((old_v[0] + v[0]) * Ep[0] + (old_v[1] + v[1]) * Ep[1] + (old_v[2] + v[2]) * Ep[2]);
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          s.r[a][p] = r[a];
-          if (MODE != 1) s.v[a][p] = v[a];
-        }
-
-        // Shape::setup(old_r, new_r) (shape.cpp:43-54): the box [sst, send) of the pair per axis
-        bool ok = true, fast = true;
-        scaled_position<P2>(g, old_r[0], old_r[1], old_r[2], po);
-        scaled_position<P2>(g, r[0], r[1], r[2], pn);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          sst[a] = (int)round(fmin(po[a], pn[a]) - 1.5);
-          const int send = (int)floor(fmax(po[a], pn[a]) + 1.5) + 1;
-          ssz[a] = send - sst[a];
-          ok = ok && ssz[a] <= 4;                                       // the reference's Shape::shape[] limit
-          fast = fast && sst[a] >= cc[a] - 1 && send <= cc[a] + 3;      // inside the cell's dense 4-node box
-        }
-        double* col = st + lane;
-        if (ok && fast) {
-          // old / new spline values on the nodes c-1 .. c+2 (exact zeros outside the support, as the reference's loop
-          // sees them) and the prefix sums of their differences along each axis
-#pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            double run = 0.0;
-#pragma unroll
-            for (int t = 0; t < kD; ++t) {
-              const double gx = (double)(cc[a] - 1 + t);
-              const double so = spline2(po[a] - gx), sn = spline2(pn[a] - gx);
-              run += sn - so;
-              col[(a * kD + t) * kBPad] = so;
-              col[(12 + a * kD + t) * kBPad] = sn;
-              col[(24 + a * kD + t) * kBPad] = run;
+              __builtin_amdgcn_sched_barrier(0);
             }
           }
         }
-        else {
+        // else: the particle moved further than the reference itself supports; flagged by the range test below
+        update_vEB(dt, qm, Ep, Bp, v);                 // push.update_vEB(dt)  :41
 #pragma unroll
-          for (int e = 0; e < kSRows; ++e) col[e * kBPad] = 0.0; // nothing for phase 2
-          if (ok) slow = true;
-          else ++bad; // the reference would overflow Shape::shape here; deposit nothing and report
-        }
+        for (int a = 0; a < 3; ++a) r[a] += v[a] * (dt / 2.0); // push.update_r(dt / 2)  :42
       }
-      // ---- slow path (rare): EsirkepovDecomposition::process of ONE particle by the 48 line lanes, on the particle's
-      // own box [sst, sst + ssz) (Shape::setup(old, new), shape.cpp:43-54), straight to the global J with fp64 atomics.
-      // Same terms and running sums as :57-103.
-      for (unsigned long long sm = __ballot(slow); sm; sm &= sm - 1) {
-        const int src = __ffsll((long long)sm) - 1;
-        double qo[3], qn[3];
-        int qs[3], qz[3];
+      else if (MODE == 1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) r[a] += v[a] * (0.5 * dt); // BorisPush::update_r(0.5 * dt)  ecsimcorr/particles.cpp:39
+      }
+      else {
+        // interpolate_E_s1 / interpolate_B_s1 ; update_vEB(dt) ; update_r(0.5 dt)   (:64-69), gathers out of the
+        // cell's LDS neighbourhood in the loop and product order of ecsim/simulation.cpp:8-118
+        const double old_v[3] = {v[0], v[1], v[2]};
+        const W1T<P2> w(g, r[0], r[1], r[2]);
+        const int ox = w.is[0] - w.in[0] + 1, oy = w.is[1] - w.in[1] + 1, oz = w.is[2] - w.in[2] + 1;
+        const double* eE = nbv + (MODE == 2 ? seg * kNb : 0);
+        const double* eB = eE + 36;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              Ep[0] += eE[(k * 2 + j) * 3 + (ox + i)] * (w.wn[2][k] * w.wn[1][j] * w.ws[0][i]);
+              Ep[1] += eE[12 + (k * 3 + (oy + j)) * 2 + i] * (w.wn[2][k] * w.ws[1][j] * w.wn[0][i]);
+              Ep[2] += eE[24 + ((oz + k) * 2 + j) * 2 + i] * (w.ws[2][k] * w.wn[1][j] * w.wn[0][i]);
+              Bp[0] += eB[((oz + k) * 3 + (oy + j)) * 2 + i] * (w.ws[2][k] * w.ws[1][j] * w.wn[0][i]);
+              Bp[1] += eB[18 + ((oz + k) * 2 + j) * 3 + (ox + i)] * (w.ws[2][k] * w.wn[1][j] * w.ws[0][i]);
+              Bp[2] += eB[36 + (k * 3 + (oy + j)) * 3 + (ox + i)] * (w.wn[2][k] * w.ws[1][j] * w.ws[0][i]);
+            }
+        update_vEB(dt, qm, Ep, Bp, v);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) r[a] += v[a] * (0.5 * dt);
+        // pred_w += qn_Np * 0.5 * (old_v + point.p).dot(E_p)   (:77-78)
+        pw += qn_Np * 0.5 * ((old_v[0] + v[0]) * Ep[0] + (old_v[1] + v[1]) * Ep[1] + (old_v[2] + v[2]) * Ep[2]);
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        s.r[a][p] = r[a];
+        if (MODE != 1) s.v[a][p] = v[a];
+      }
+
+      // Shape::setup(old_r, new_r) (shape.cpp:43-54): the box [sst, send) of the pair per axis
+      bool ok = true;
+      fast = true;
+      scaled_position<P2>(g, old_r[0], old_r[1], old_r[2], po);
+      scaled_position<P2>(g, r[0], r[1], r[2], pn);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        sst[a] = (int)round(fmin(po[a], pn[a]) - 1.5);
+        const int send = (int)floor(fmax(po[a], pn[a]) + 1.5) + 1;
+        ssz[a] = send - sst[a];
+        ok = ok && ssz[a] <= 4;                                       // the reference's Shape::shape[] limit
+        fast = fast && sst[a] >= cc[a] - 1 && send <= cc[a] + 3;      // inside the cell's dense 4-node box
+      }
+      fast = fast && ok;
+      if (ok && !fast) slow = true;
+      if (!ok) ++bad; // the reference would overflow Shape::shape here; deposit nothing and report
+    }
+    STAMP(5);
+    if (MODE == 0) lds_barrier_b(); // every gather out of the tile is done: its LDS becomes the stage
+
+    if (p >= 0) {
+      double* colp = stage + col;
+      if (fast) {
+        // old / new spline values on the nodes c-1 .. c+2 (exact zeros outside the support, as the reference's loop
+        // sees them) and the prefix sums of their differences along each axis
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-          qo[a] = lane_value(po[a], src);
-          qn[a] = lane_value(pn[a], src);
-          qs[a] = __builtin_amdgcn_readlane(sst[a], src);
-          qz[a] = __builtin_amdgcn_readlane(ssz[a], src);
-        }
-        if (has_line && liA < qz[axA] && liB < qz[axB]) {
-          const double gA = (double)(qs[axA] + liA), gB = (double)(qs[axB] + liB);
-          const double sA_o = spline2(qo[axA] - gA), sA_n = spline2(qn[axA] - gA);
-          const double sB_o = spline2(qo[axB] - gB), sB_n = spline2(qn[axB] - gB);
-          const double T = sA_n * (2.0 * sB_n + sB_o) + sA_o * (2.0 * sB_o + sB_n);
           double run = 0.0;
-          for (int t = 0; t < qz[lc]; ++t) {
-            const double gC = (double)(qs[lc] + t);
-            run = run + (-qd * (spline2(qn[lc] - gC) - spline2(qo[lc] - gC)) * T);
-            int n[3];
-            n[lc] = qs[lc] + t; n[axA] = qs[axA] + liA; n[axB] = qs[axB] + liB;
-            if (run != 0.0) unsafeAtomicAdd(&J[lc * g.cstride + g.nodew(n[0], n[1], n[2] - g.z0)], run);
+#pragma unroll
+          for (int t = 0; t < kD; ++t) {
+            const double gx = (double)(cc[a] - 1 + t);
+            const double so = spline2(po[a] - gx), sn = spline2(pn[a] - gx);
+            run += sn - so;
+            colp[(a * kD + t) * kPitch] = so;
+            colp[(12 + a * kD + t) * kPitch] = sn;
+            colp[(24 + a * kD + t) * kPitch] = run;
           }
         }
       }
-      wave_sync_b();
-
-      // ---- phase 2 on the matrix cores: J_c[i][u][w] += sum_p P_c[i] * T_c[u][w],
-      //   T_c[u][w] = -qd_c (Sn_A[u] (2 Sn_B[w] + So_B[w]) + So_A[u] (2 So_B[w] + Sn_B[w]))
-      // is, per component, a 4 x 16 x P product: one v_mfma_f64_4x4x4_4b_f64 per K = 4 particles with block b = w, rows
-      // i, columns u (lane roles A[b][i][k], B[b][k][j] at lane 16 k + 4 b + (i or j); D[b][i][j] at lane 16 i + 4 b + j).
-      // The lane forms its own T from the staged 1-D spline values of particle k.
-      for (int t0 = 0; t0 < mcnt; t0 += 4) {
-        const double* cp = st + t0 + kk;
+      else {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const int aA = c == 1 ? 0 : 1, aB = c == 2 ? 0 : 2; // X: A = y, B = z;  Y: A = x, B = z;  Z: A = y, B = x
-          const double sA_o = cp[(aA * kD + qq) * kBPad], sA_n = cp[(12 + aA * kD + qq) * kBPad];
-          const double sB_o = cp[(aB * kD + qb) * kBPad], sB_n = cp[(12 + aB * kD + qb) * kBPad];
-          const double T = -qdc[c] * (sA_n * (2.0 * sB_n + sB_o) + sA_o * (2.0 * sB_o + sB_n));
-          acc[c] = __builtin_amdgcn_mfma_f64_4x4x4f64(cp[(24 + c * kD + qq) * kBPad], T, acc[c], 0, 0, 0);
+        for (int e = 0; e < kSRows; ++e) colp[e * kPitch] = 0.0; // nothing for phase 2
+      }
+    }
+    if ((int)threadIdx.x < 3 * nseg) {
+      // phase 2 works on K = 4 particles per step: the columns that fill up a cell's last step are particles of weight zero
+      const int sg = threadIdx.x / 3;
+      const int c = T.col0[sg] + (T.toff[sg + 1] - T.toff[sg]) + (int)threadIdx.x % 3;
+      if (c < T.col0[sg + 1]) {
+#pragma unroll
+        for (int e = 0; e < kSRows; ++e) stage[e * kPitch + c] = 0.0;
+      }
+    }
+    // ---- slow path (rare): EsirkepovDecomposition::process of ONE particle by the 48 line lanes, on the particle's
+    // own box [sst, sst + ssz) (Shape::setup(old, new), shape.cpp:43-54), straight to the global J with fp64 atomics.
+    // Same terms and running sums as :57-103.
+    for (unsigned long long sm = __ballot(slow); sm; sm &= sm - 1) {
+      const int src = __ffsll((long long)sm) - 1;
+      double qo[3], qn[3];
+      int qs[3], qz[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        qo[a] = lane_value(po[a], src);
+        qn[a] = lane_value(pn[a], src);
+        qs[a] = __builtin_amdgcn_readlane(sst[a], src);
+        qz[a] = __builtin_amdgcn_readlane(ssz[a], src);
+      }
+      if (has_line && liA < qz[axA] && liB < qz[axB]) {
+        const double gA = (double)(qs[axA] + liA), gB = (double)(qs[axB] + liB);
+        const double sA_o = spline2(qo[axA] - gA), sA_n = spline2(qn[axA] - gA);
+        const double sB_o = spline2(qo[axB] - gB), sB_n = spline2(qn[axB] - gB);
+        const double Tl = sA_n * (2.0 * sB_n + sB_o) + sA_o * (2.0 * sB_o + sB_n);
+        double run = 0.0;
+        for (int t = 0; t < qz[lc]; ++t) {
+          const double gC = (double)(qs[lc] + t);
+          run = run + (-qd * (spline2(qn[lc] - gC) - spline2(qo[lc] - gC)) * Tl);
+          int n[3];
+          n[lc] = qs[lc] + t; n[axA] = qs[axA] + liA; n[axB] = qs[axB] + liB;
+          if (run != 0.0) unsafeAtomicAdd(&J[lc * g.cstride + g.nodew(n[0], n[1], n[2] - g.z0)], run);
         }
       }
     }
-
-    request_tile(j + 1, pf);
-    // ---- merge the chunk's cells in the LDS J window: column 0 is node x = cx0 - 1
-    if (active) {
-      // lane holds J_c[i = lane >> 4][u = lane & 3][w = (lane >> 2) & 3]: own-axis node i, A-index u, B-index w
-      const int di = lane >> 4;
-      const int tX[3] = {wave + di, wave + qq, wave + qb}, tY[3] = {qq, di, qq}, tZ[3] = {qb, qb, di};
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        if (acc[c] != 0.0) unsafeAtomicAdd(&jtile[c * kJN + (tZ[c] * kD + tY[c]) * kJX + tX[c]], acc[c]);
-    }
+    STAMP(6);
     lds_barrier_b();
-    // ---- the next chunk starts at node cx0 + 3: the first kBW columns are final and leave with one fp64 atomic per
-    // node (other pencils add to the same nodes); the other three move to the front of the window.  The last chunk
-    // flushes everything (its tail wraps periodically onto nodes 0, 1, ...).
-    const bool last = j + 1 == nch;
-    double keep[2] = {0.0, 0.0};
+    STAMP(7);
+
+    // ---- phase 2 on the matrix cores: J_c[i][u][w] += sum_p P_c[i] * T_c[u][w],
+    //   T_c[u][w] = -qd_c (Sn_A[u] (2 Sn_B[w] + So_B[w]) + So_A[u] (2 So_B[w] + Sn_B[w]))
+    // is, per component, a 4 x 16 x P product: one v_mfma_f64_4x4x4_4b_f64 per K = 4 particles with block b = w, rows
+    // i, columns u (lane roles A[b][i][k], B[b][k][j] at lane 16 k + 4 b + (i or j); D[b][i][j] at lane 16 i + 4 b + j).
+    // The lane forms its own T from the staged 1-D spline values of particle k.  The round's K steps are dealt out
+    // evenly to the waves; a wave that passes from one cell to the next merges its box into the J window.
+    {
+      const int K = ncols >> 2;
+      const int k0 = (K * wave) >> 2, k1 = (K * (wave + 1)) >> 2;
+      if (k0 < k1) {
+        int sg = 0;
+        while (sg + 1 < nseg && __builtin_amdgcn_readfirstlane(T.col0[sg + 1]) <= 4 * k0) ++sg;
+        int nextcol = __builtin_amdgcn_readfirstlane(T.col0[sg + 1]);
+        double acc[3] = {0.0, 0.0, 0.0}; // one 4 x 4 block element per component
+        // the lane holds J_c[i = lane >> 4][u = lane & 3][w = (lane >> 2) & 3]: own-axis node i, A-index u, B-index w
+        auto merge = [&](int cr) {
+          const int di = lane >> 4;
+          const int m0 = (base + cr) % kJX; // window column of node x is (x + 1) mod kJX: node cx - 1 + d sits at m0 + d
+          int tX[3] = {m0 + di, m0 + qq, m0 + qb};
+          const int tY[3] = {qq, di, qq}, tZ[3] = {qb, qb, di};
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int t = threadIdx.x + k * kThreadsB;
-      if (t < 3 * kJN) {
-        const double val = jtile[t];
-        const int c = t / kJN, n = t % kJN;
-        const int tx = n % kJX, ty = (n / kJX) % kD, tz = n / (kJX * kD);
-        if (tx < kBW || last) {
-          if (val != 0.0) unsafeAtomicAdd(&J[c * g.cstride + g.nodew(cx0 - 1 + tx, cy - 1 + ty, cz - 1 + tz)], val);
+          for (int c = 0; c < 3; ++c) {
+            if (tX[c] >= kJX) tX[c] -= kJX;
+            if (acc[c] != 0.0) unsafeAtomicAdd(&jtile[c * kJN + (tZ[c] * kD + tY[c]) * kJX + tX[c]], acc[c]);
+          }
+        };
+        for (int k = k0; k < k1; ++k) {
+          if (4 * k >= nextcol) {
+            merge(__builtin_amdgcn_readfirstlane(T.cell[sg]));
+            acc[0] = acc[1] = acc[2] = 0.0;
+            ++sg;
+            nextcol = __builtin_amdgcn_readfirstlane(T.col0[sg + 1]);
+          }
+          const double* cp = stage + 4 * k + kk;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const int aA = c == 1 ? 0 : 1, aB = c == 2 ? 0 : 2; // X: A = y, B = z;  Y: A = x, B = z;  Z: A = y, B = x
+            const double sA_o = cp[(aA * kD + qq) * kPitch], sA_n = cp[(12 + aA * kD + qq) * kPitch];
+            const double sB_o = cp[(aB * kD + qb) * kPitch], sB_n = cp[(12 + aB * kD + qb) * kPitch];
+            const double Tc = -qdc[c] * (sA_n * (2.0 * sB_n + sB_o) + sA_o * (2.0 * sB_o + sB_n));
+            acc[c] = __builtin_amdgcn_mfma_f64_4x4x4f64(cp[(24 + c * kD + qq) * kPitch], Tc, acc[c], 0, 0, 0);
+          }
         }
-        // what this thread's element holds next: the value kBW columns further on, zero for the new columns
-        keep[k] = (tx + kBW < kJX && !last) ? jtile[t + kBW] : 0.0;
+        merge(__builtin_amdgcn_readfirstlane(T.cell[sg]));
       }
     }
+    STAMP(8);
     lds_barrier_b();
+    // ---- the next round starts at cell base + adv: the window's nodes base - 1 .. base + adv - 2 are final and leave
+    // with one fp64 atomic per node (other pencils add to the same nodes); their columns, zeroed, become the nodes
+    // kJX further on (the window is circular, nothing moves).  The last round flushes everything (its tail wraps
+    // periodically onto nodes 0, 1, ...).  The next merges are two barriers away.
+    {
+      const bool last = base + adv >= g.nx;
+      const int b11 = base % kJX;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int t = threadIdx.x + k * kThreadsB;
-      if (t < 3 * kJN) jtile[t] = keep[k];
+      for (int k = 0; k < kJPer; ++k) {
+        const int t = threadIdx.x + k * kThreadsB;
+        if (t < 3 * kJN) {
+          const int c = t / kJN, n = t % kJN;
+          const int tx = n % kJX, ty = (n / kJX) % kD, tz = n / (kJX * kD);
+          int j = tx - b11;
+          if (j < 0) j += kJX;
+          if (j < adv || last) {
+            const double val = jtile[t];
+            if (val != 0.0) {
+              unsafeAtomicAdd(&J[c * g.cstride + g.nodew(base - 1 + j, cy - 1 + ty, cz - 1 + tz)], val);
+              jtile[t] = 0.0;
+            }
+          }
+        }
+      }
     }
-    lds_barrier_b();
   }
 
+#ifdef ESK_STAMPS
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 10; ++k) atomicAdd(&g_esk_stamps[k], stamp_acc_[k]);
+#endif
   if (MODE == 2) {
     pw = wave_sum_b(pw);
     if (lane == 0) pwsum[wave] = pw;
@@ -512,6 +649,20 @@ __global__ void __launch_bounds__(1024) k_sum_partials(const double* __restrict_
 }
 
 }  // namespace
+
+#ifdef ESK_STAMPS
+extern "C" int xpic_debug_esk_stamps(double* out, int reset)
+{
+  unsigned long long h[16];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_esk_stamps), sizeof(h)) != hipSuccess) return 1;
+  for (int k = 0; k < 16; ++k) out[k] = (double)h[k];
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_esk_stamps), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
 
 int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double* B, double* J, double* pred_w_host)
 {
