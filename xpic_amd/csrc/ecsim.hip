@@ -288,12 +288,16 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
 #if FILL_EXP >= 6 && FILL_EXP <= 8
       for (int e = 0; e < kAcc; ++e) acc[e] = 1.0 + lane;
 #endif
-      for (int base = 0; base < cnt; base += kCP) {
-        const int mcnt = min(kCP, cnt - base);
+      // A pass stages up to kCP particles.  Phase 2 works on 4 particles of one octant per step; a pass that is not the
+      // cell's last leaves the 0..3 particles that do not fill a step of their octant to the next pass (their lanes keep
+      // them and stage them again with the newcomers) instead of padding every octant in every pass: a Poisson(64)
+      // cell then takes sum_o ceil(n_o / 4) = 19 steps on average instead of 22.4.
+      int handed = min(kCP, cnt);     // particles of the cell handed to lanes so far
+      bool real = lane < handed;
+      while (cnt > 0) {
+        const bool lastpass = handed >= cnt;
 #if FILL_EXP >= 6 && FILL_EXP <= 8
-        const bool real = false;
-#else
-        const bool real = lane < mcnt;
+        real = false;
 #endif
         wave_sync(); // the previous pass's operand reads (and the neighbourhood store) are done
         // CIC weights and the half-cell octant first: the octant decides the particle's stage slot
@@ -302,6 +306,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
         const int oct = real ? (ox | (oy << 1) | (oz << 2)) : 8;
         // compaction by octant: the particles of octant o take the stage slots ooff[o] .. ooff[o] + ocnt[o] - 1
         int ocnt[8], ooff[8], slot = 0;
+        bool keep = false; // this lane's particle waits for the next pass
         {
           int run = 0;
 #pragma unroll
@@ -309,7 +314,11 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
             const unsigned long long mk = __ballot(oct == o);
             ocnt[o] = __popcll(mk);
             ooff[o] = run;
-            if (oct == o) slot = run + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+            if (oct == o) {
+              const int rk = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+              slot = run + rk;
+              keep = !lastpass && rk >= (ocnt[o] & ~3);
+            }
             run += ocnt[o];
           }
         }
@@ -358,11 +367,21 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
           dst[16] = double2{A_p * (1.0 + bz * bz), iq * (v[0] + cxv + vb * bx)};
           dst[17] = double2{iq * (v[1] + cyv + vb * by), iq * (v[2] + czv + vb * bz)};
         }
-        // next pass of this cell: loads in flight during this pass's phase 2
-        if (base + kCP + lane < cnt) {
-          const long p = (long)start + base + kCP + lane;
+        // next pass of this cell: the free lanes take the next particles, loads in flight during this pass's phase 2
+        bool real_next = false;
+        if (!lastpass) {
+          const unsigned long long km = __ballot(keep);
+          const int take = min(cnt - handed, kCP - (int)__popcll(km));
+          const unsigned long long fm = ~km;
+          const int fr = __builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
+          const bool get = !keep && fr < take;
+          if (get) {
+            const long p = (long)start + handed + fr;
 #pragma unroll
-          for (int a = 0; a < 3; ++a) { cur[a] = s.r[a][p]; cur[3 + a] = s.v[a][p]; }
+            for (int a = 0; a < 3; ++a) { cur[a] = s.r[a][p]; cur[3 + a] = s.v[a][p]; }
+          }
+          real_next = keep || get;
+          handed += take;
         }
         wave_sync();
             STAMP(1);
@@ -374,7 +393,8 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
         for (int o = 0; o < 8; ++o) {
           const int no = ocnt[o];
           const double* seg = st + ooff[o] * kPitch;
-          for (int t = 0; 4 * t < no; ++t) {
+          const int nst = lastpass ? (no + 3) >> 2 : no >> 2;
+          for (int t = 0; t < nst; ++t) {
             const int r = 4 * t + kk;
             const double* sp = r < no ? seg + r * kPitch : zslot;
             double a[3], b[3];
@@ -408,6 +428,8 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
         }
 #endif
         STAMP(2);
+        if (lastpass) break;
+        real = real_next;
       }
     }
 
