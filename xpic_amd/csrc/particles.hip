@@ -234,126 +234,140 @@ __global__ void __launch_bounds__(kBlock) k_scan_apply(const int* in, long n, co
 }
 
 // ecsim::Particles::second_push (src/impls/ecsim/particles.cpp:175-192).
-// One wave per cell, lane = particle.  Every particle of the cell gathers from the same 36 E and 54 B values
-// (interpolate_E_s1 / interpolate_B_s1, ecsim/simulation.cpp:8-118): they are fetched once per cell into LDS, the
-// 48 gathers per particle then hit LDS instead of L1/L2, and the particle streams are read and written fully
-// coalesced (the cell's particles are contiguous).
-constexpr int kSPW = 4;     // waves per workgroup
-constexpr int kSPCells = 256; // consecutive cells per workgroup: wave w takes cells w, w + 4, ... of the run
+// A workgroup owns one x-pencil of cells and marches along it in rounds of 256 CONSECUTIVE PARTICLES, one per thread,
+// whatever cells they belong to (the pencil's particles are contiguous): every wave is full, where one wave per cell
+// ran its second pass of a 64-particle Poisson cell with a handful of live lanes (1.47 passes per cell on average; the
+// instruction stream of a pass costs the same for 1 or 64 lanes, and the gather + Boris arithmetic is 10 of this
+// kernel's 27 ms at 256^3 x 64).  A round's particles lie in at most kSPSeg consecutive cells (a round ends early
+// where they do not); all they gather from (interpolate_E_s1 / interpolate_B_s1, ecsim/simulation.cpp:8-118) is the
+// strip of E, B nodes around those cells: 349 values, fetched once per round into LDS.  The next round's strip and
+// particles are requested while the current round is pushed; the strip is double-buffered: one barrier per round.
+constexpr int kSPW = 4;      // waves per workgroup
+constexpr int kSPRound = kSPW * 64;
+constexpr int kSPSeg = 8;    // cells a round can span
+// strip layout [z row][y row][x]: Ex (x from c-1: S+2 nodes, y: 2, z: 2), Ey (x from c: S+1, y from cy-1: 3, z: 2),
+// Ez (S+1, 2, z from cz-1: 3), Bx (S+1, 3, 3), By (S+2, 2, 3), Bz (S+2, 3, 2)
+constexpr int kSPXs = kSPSeg + 2, kSPXn = kSPSeg + 1;
+constexpr int kSPoEx = 0, kSPoEy = kSPoEx + kSPXs * 4, kSPoEz = kSPoEy + kSPXn * 6, kSPoBx = kSPoEz + kSPXn * 6;
+constexpr int kSPoBy = kSPoBx + kSPXn * 9, kSPoBz = kSPoBy + kSPXs * 6, kSPStrip = kSPoBz + kSPXs * 6;
+constexpr int kSPPer = (kSPStrip + kSPRound - 1) / kSPRound; // strip values per thread
 
-struct PushPrefetch {
-  int start, cnt;
-  double e, b;       // lane's value of the cell's 36 E / 54 B neighbourhood
-  double r[2][3];    // lane's particle and the particle 64 further on
-  double v[2][3];
-};
+using UniformIntsP = const __attribute__((address_space(4))) int*; // wave-uniform reads of cell_start: scalar loads
 
 template <bool PREBIN, bool MIG, bool P2>
-__global__ void __launch_bounds__(kSPW * 64) k_second_push(GridDev g, SortDev s, const double* __restrict__ E,
-  const double* __restrict__ B, double qm, long ncell, long chunk, Migr mg)
+__global__ void __launch_bounds__(kSPRound) k_second_push(GridDev g, SortDev s, const double* __restrict__ E,
+  const double* __restrict__ B, double qm, long npencil, long chunk, Migr mg)
 {
-  // workgroup -> a run of kSPCells consecutive cells; XCD r sweeps its own contiguous range of runs (see k_matA).
-  // A wave marches over its cells with everything of the NEXT cell (neighbourhood, up to 128 particles) in flight
-  // while the current one is pushed: no dependent global round trip sits between two cells.
+  // workgroup -> pencil; XCD r sweeps its own contiguous range of pencils (see k_matA)
   const long q = (long)(blockIdx.x % 8) * chunk + blockIdx.x / 8;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long first = q * kSPCells;
-  if (blockIdx.x / 8 >= chunk || first >= ncell) return;
-  const int ncl = (int)min((long)kSPCells, ncell - first);
+  if (blockIdx.x / 8 >= chunk || q >= npencil) return;
+  const int cy = (int)(q % g.ny), cz = (int)(q / g.ny);
+  UniformIntsP cs = (UniformIntsP)(s.cell_start + q * g.nx);
 
-  __shared__ int cstart[kSPCells + 1];
-  __shared__ double nbE[kSPW][36], nbB[kSPW][54];
-  for (int i = threadIdx.x; i <= ncl; i += kSPW * 64) cstart[i] = s.cell_start[first + i];
-  __syncthreads();
+  __shared__ double strip[2][kSPStrip];
 
-  // neighbourhood slot of this lane (node numbering of the cell's 3 x 12 E nodes: X (k*2+j)*3+l, Y (k*3+l)*2+i,
-  // Z (l*2+j)*2+i; B: as load_bnb of ecsim.hip)
-  int ec = 0, eo[3] = {0, 0, 0}, bc = 0, bo[3] = {0, 0, 0};
-  if (lane < 36) {
-    ec = lane / 12;
-    const int l = lane % 12;
-    if (ec == 0) { eo[0] = l % 3 - 1; eo[1] = (l / 3) % 2; eo[2] = l / 6; }
-    else if (ec == 1) { eo[0] = l % 2; eo[1] = (l / 2) % 3 - 1; eo[2] = l / 6; }
-    else { eo[0] = l % 2; eo[1] = (l / 2) % 2; eo[2] = l / 4 - 1; }
-  }
-  if (lane < 54) {
-    if (lane < 18) { bc = 0; bo[0] = lane % 2; bo[1] = (lane / 2) % 3 - 1; bo[2] = lane / 6 - 1; }
-    else if (lane < 36) { const int l = lane - 18; bc = 1; bo[0] = l % 3 - 1; bo[1] = (l / 3) % 2; bo[2] = l / 6 - 1; }
-    else { const int l = lane - 36; bc = 2; bo[0] = l % 3 - 1; bo[1] = (l / 3) % 3 - 1; bo[2] = l / 9; }
-  }
-
-  auto prefetch = [&](int ci, PushPrefetch& pf) {
-    pf.start = 0; pf.cnt = 0; pf.e = 0.0; pf.b = 0.0;
-    if (ci >= ncl) return;
-    pf.start = __builtin_amdgcn_readfirstlane(cstart[ci]);
-    pf.cnt = __builtin_amdgcn_readfirstlane(cstart[ci + 1]) - pf.start;
-    if (pf.cnt == 0) return;
-    const long cell = first + ci;
-    const int cx = (int)(cell % g.nx), cy = (int)((cell / g.nx) % g.ny), cz = (int)(cell / g.plane);
-    if (lane < 36) pf.e = E[ec * g.cstride + g.nodew(cx + eo[0], cy + eo[1], cz + eo[2])];
-    if (lane < 54) pf.b = B[bc * g.cstride + g.nodew(cx + bo[0], cy + bo[1], cz + bo[2])];
+  // this thread's strip entries e = thread + i * 256: the row of the field array the value comes from and its x
+  // offset from the round's first cell
+  const double* srow[kSPPer];
+  int sdx[kSPPer];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-      if (64 * h + lane < pf.cnt) {
-        const long p = (long)pf.start + 64 * h + lane;
+  for (int i = 0; i < kSPPer; ++i) {
+    const int e = threadIdx.x + i * kSPRound;
+    int comp, l, X, Y, x0, y0, z0; // component (0..2 E, 3..5 B), local index, row length, rows per plane, origin
+    if (e < kSPoEy) { comp = 0; l = e - kSPoEx; X = kSPXs; Y = 2; x0 = -1; y0 = 0; z0 = 0; }
+    else if (e < kSPoEz) { comp = 1; l = e - kSPoEy; X = kSPXn; Y = 3; x0 = 0; y0 = -1; z0 = 0; }
+    else if (e < kSPoBx) { comp = 2; l = e - kSPoEz; X = kSPXn; Y = 2; x0 = 0; y0 = 0; z0 = -1; }
+    else if (e < kSPoBy) { comp = 3; l = e - kSPoBx; X = kSPXn; Y = 3; x0 = 0; y0 = -1; z0 = -1; }
+    else if (e < kSPoBz) { comp = 4; l = e - kSPoBy; X = kSPXs; Y = 2; x0 = -1; y0 = 0; z0 = -1; }
+    else { comp = 5; l = e - kSPoBz; X = kSPXs; Y = 3; x0 = -1; y0 = -1; z0 = 0; }
+    const int ix = l % X, iy = (l / X) % Y, iz = l / (X * Y);
+    sdx[i] = x0 + ix;
+    srow[i] = e < kSPStrip
+      ? (comp < 3 ? E : B) + (comp % 3) * g.cstride + g.node(0, g.wy(cy + y0 + iy), g.wz(cz + z0 + iz))
+      : nullptr;
+  }
+
+  // a round: particles [P0, P1) in the cells c_lo .. c_lo + kSPSeg - 1; adv = cells the round finishes
+  struct Round { int c_lo, P0, P1, adv; };
+  auto compose = [&](int c_lo, int P0) {
+    Round r;
+    r.c_lo = c_lo; r.P0 = P0;
+    int cv[kSPSeg + 1];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { pf.r[h][a] = s.r[a][p]; pf.v[h][a] = s.v[a][p]; }
-      }
+    for (int i = 0; i <= kSPSeg; ++i) cv[i] = cs[min(c_lo + i, g.nx)];
+    r.P1 = min(P0 + kSPRound, cv[kSPSeg]);
+    r.adv = 0;
+#pragma unroll
+    for (int i = 0; i < kSPSeg; ++i) r.adv += (c_lo + i < g.nx && cv[i + 1] <= r.P1) ? 1 : 0;
+    return r;
   };
 
-  const double* eE = nbE[wave];
-  const double* eB = nbB[wave];
-  auto push = [&](long p, const double* r, double* v) {
-    const W1T<P2> w(g, r[0], r[1], r[2]);
-    const int ox = w.is[0] - w.in[0] + 1, oy = w.is[1] - w.in[1] + 1, oz = w.is[2] - w.in[2] + 1;
-    double Ep[3] = {0, 0, 0}, Bp[3] = {0, 0, 0};
+  struct Ahead { double r[3], v[3], f[kSPPer]; };
+  auto request = [&](const Round& r, Ahead& pf) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+    for (int i = 0; i < kSPPer; ++i) {
+      pf.f[i] = 0.0;
+      // (nodes beyond x = nx, the periodic image of node 0, are never gathered from)
+      if (srow[i] && r.c_lo + sdx[i] <= g.nx) pf.f[i] = srow[i][g.wx(r.c_lo + sdx[i])];
+    }
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+    for (int a = 0; a < 3; ++a) { pf.r[a] = 0.0; pf.v[a] = 0.0; }
+    const long p = (long)r.P0 + threadIdx.x;
+    if (p < r.P1) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          Ep[0] += eE[(k * 2 + j) * 3 + (ox + i)] * (w.wn[2][k] * w.wn[1][j] * w.ws[0][i]);
-          Ep[1] += eE[12 + (k * 3 + (oy + j)) * 2 + i] * (w.wn[2][k] * w.ws[1][j] * w.wn[0][i]);
-          Ep[2] += eE[24 + ((oz + k) * 2 + j) * 2 + i] * (w.ws[2][k] * w.wn[1][j] * w.wn[0][i]);
-          Bp[0] += eB[((oz + k) * 3 + (oy + j)) * 2 + i] * (w.ws[2][k] * w.ws[1][j] * w.wn[0][i]);
-          Bp[1] += eB[18 + ((oz + k) * 2 + j) * 3 + (ox + i)] * (w.ws[2][k] * w.wn[1][j] * w.ws[0][i]);
-          Bp[2] += eB[36 + (k * 3 + (oy + j)) * 3 + (ox + i)] * (w.wn[2][k] * w.ws[1][j] * w.ws[0][i]);
-        }
-    update_vEB(g.dt, qm, Ep, Bp, v);
-    s.v[0][p] = v[0]; s.v[1][p] = v[1]; s.v[2][p] = v[2];
-    if (PREBIN) {
-      // the next step opens with first_push + update_cells of exactly this state: r + v dt, wrapped, binned.  Doing
-      // the binning here (same expressions as k_move_bin<true, true, .>) saves that pass its 48 B per particle.
-      const double x = bound_periodic(r[0] + v[0] * g.dt, g.Lx);
-      const double y = bound_periodic(r[1] + v[1] * g.dt, g.Ly);
-      const double z = bound_periodic(r[2] + v[2] * g.dt, g.Lz);
-      bin_particle<MIG, P2>(g, s, p, x, y, z, v[0], v[1], v[2], mg);
+      for (int a = 0; a < 3; ++a) { pf.r[a] = s.r[a][p]; pf.v[a] = s.v[a][p]; }
     }
   };
 
-  PushPrefetch pf;
-  prefetch(wave, pf);
-  for (int ci = wave; ci < ncl; ci += kSPW) {
-    PushPrefetch cur = pf;
-    prefetch(ci + kSPW, pf);
-    if (cur.cnt == 0) continue;
-    // the previous cell's gathers are done (in-order LDS) before its neighbourhood is overwritten
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    if (lane < 36) nbE[wave][lane] = cur.e;
-    if (lane < 54) nbB[wave][lane] = cur.b;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+  Round nxt = compose(0, cs[0]);
+  Ahead pf;
+  request(nxt, pf);
+  for (int rd = 0; nxt.c_lo < g.nx; ++rd) {
+    const Round cur = nxt;
+    double* st = strip[rd & 1];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-      if (64 * h + lane < cur.cnt) push((long)cur.start + 64 * h + lane, cur.r[h], cur.v[h]);
-    for (int base = 128; base < cur.cnt; base += 64) { // cells beyond 128 particles: plain loads
-      if (base + lane >= cur.cnt) break;
-      const long p = (long)cur.start + base + lane;
-      const double r[3] = {s.r[0][p], s.r[1][p], s.r[2][p]};
-      double v[3] = {s.v[0][p], s.v[1][p], s.v[2][p]};
-      push(p, r, v);
+    for (int i = 0; i < kSPPer; ++i) {
+      const int e = threadIdx.x + i * kSPRound;
+      if (e < kSPStrip) st[e] = pf.f[i];
+    }
+    const double r[3] = {pf.r[0], pf.r[1], pf.r[2]};
+    double v[3] = {pf.v[0], pf.v[1], pf.v[2]};
+    nxt = compose(cur.c_lo + cur.adv, cur.P1);
+    // raw barrier that only drains LDS traffic (the requests of the next round stay in flight).  One per round: the
+    // strip written here was last read two rounds ago, before the previous round's barrier.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    request(nxt, pf);
+
+    const long p = (long)cur.P0 + threadIdx.x;
+    if (p < cur.P1) {
+      const W1T<P2> w(g, r[0], r[1], r[2]);
+      const int ox = w.is[0] - w.in[0] + 1, oy = w.is[1] - w.in[1] + 1, oz = w.is[2] - w.in[2] + 1;
+      const int dn = w.in[0] - cur.c_lo, ds = dn + ox; // x index of the node-centred / half-shifted lower node in the strip
+      double Ep[3] = {0, 0, 0}, Bp[3] = {0, 0, 0};
+      // loop and product order of ecsim/simulation.cpp:8-118
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            Ep[0] += st[kSPoEx + (k * 2 + j) * kSPXs + (ds + i)] * (w.wn[2][k] * w.wn[1][j] * w.ws[0][i]);
+            Ep[1] += st[kSPoEy + (k * 3 + (oy + j)) * kSPXn + (dn + i)] * (w.wn[2][k] * w.ws[1][j] * w.wn[0][i]);
+            Ep[2] += st[kSPoEz + ((oz + k) * 2 + j) * kSPXn + (dn + i)] * (w.ws[2][k] * w.wn[1][j] * w.wn[0][i]);
+            Bp[0] += st[kSPoBx + ((oz + k) * 3 + (oy + j)) * kSPXn + (dn + i)] * (w.ws[2][k] * w.ws[1][j] * w.wn[0][i]);
+            Bp[1] += st[kSPoBy + ((oz + k) * 2 + j) * kSPXs + (ds + i)] * (w.ws[2][k] * w.wn[1][j] * w.ws[0][i]);
+            Bp[2] += st[kSPoBz + (k * 3 + (oy + j)) * kSPXs + (ds + i)] * (w.wn[2][k] * w.ws[1][j] * w.ws[0][i]);
+          }
+      update_vEB(g.dt, qm, Ep, Bp, v);
+      s.v[0][p] = v[0]; s.v[1][p] = v[1]; s.v[2][p] = v[2];
+      if (PREBIN) {
+        // the next step opens with first_push + update_cells of exactly this state: r + v dt, wrapped, binned.  Doing
+        // the binning here (same expressions as k_move_bin<true, true, .>) saves that pass its 48 B per particle.
+        const double x = bound_periodic(r[0] + v[0] * g.dt, g.Lx);
+        const double y = bound_periodic(r[1] + v[1] * g.dt, g.Ly);
+        const double z = bound_periodic(r[2] + v[2] * g.dt, g.Lz);
+        bin_particle<MIG, P2>(g, s, p, x, y, z, v[0], v[1], v[2], mg);
+      }
     }
   }
 }
@@ -868,16 +882,16 @@ int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B, bo
   s.prebinned = false;
   if (s.n == 0) return 0;
   Timed t(c, "second_push");
-  const long ngroups = (c->ncell + kSPCells - 1) / kSPCells;
-  const long chunk = (ngroups + 7) / 8;
+  const long npencil = (long)c->g.ny * c->g.nzl; // one workgroup per x-pencil
+  const long chunk = (npencil + 7) / 8;
   const bool mig = c->comm.kind != 0;
   Migr mg = make_migr(c, s);
   if (prebin) {
     XPIC_HIP(hipMemsetAsync(s.d.cell_count, 0, sizeof(int) * (c->ncell + 1), c->stream));
     if (mig) XPIC_HIP(hipMemsetAsync(s.mig_count, 0, sizeof(int) * 4, c->stream));
   }
-#define LAUNCH(P, G, Q) hipLaunchKernelGGL((k_second_push<P, G, Q>), dim3((unsigned)(8 * chunk)), dim3(kSPW * 64), 0, c->stream, \
-    c->g, s.d, E, B, s.par.q / s.par.m, (long)c->ncell, chunk, mg)
+#define LAUNCH(P, G, Q) hipLaunchKernelGGL((k_second_push<P, G, Q>), dim3((unsigned)(8 * chunk)), dim3(kSPRound), 0, c->stream, \
+    c->g, s.d, E, B, s.par.q / s.par.m, npencil, chunk, mg)
   if (c->g.pow2) { // exact reciprocal spacings: no fp64 division per position (device_common.h: scaled_position)
     if (!prebin) LAUNCH(false, false, true);
     else if (mig) LAUNCH(true, true, true);
