@@ -327,7 +327,7 @@ def main():
         },
         "ksp_iters_per_s": its_total / world / (ms_solve * 1e-3) if ms_solve else None,  # iterations are global
         "ksp_method": None if args.scheme == "basic" else
-                      ("GMRES(30), right-preconditioned by a Chebyshev polynomial in matM (outer iterations; each = 1 matA "
+                      ("flexible GMRES(30), right-preconditioned by a Chebyshev polynomial in matM on fp32 work vectors (outer iterations; each = 1 matA "
                        "apply + the polynomial's matM applies)" if not args.plain_gmres else "GMRES(30), no preconditioner"),
         "ksp_iterations_per_step": its_total / world / args.steps,
         "phase_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},

@@ -322,7 +322,7 @@ int xpic_destroy(xpic_ctx* ctx)
   for (auto& s : ctx->sorts) sort_free(s);
   for (int f = 0; f < XPIC_NFIELDS; ++f) (void)hipFree(ctx->field[f]);
   (void)hipFree(ctx->matL); (void)hipFree(ctx->ltab); (void)hipFree(ctx->kry_V); (void)hipFree(ctx->kry_w);
-  (void)hipFree(ctx->kry_t); (void)hipFree(ctx->kry_p[0]); (void)hipFree(ctx->kry_p[1]); (void)hipFree(ctx->kry_p[2]);
+  (void)hipFree(ctx->kry_t); (void)hipFree(ctx->kry_Z); (void)hipFree(ctx->kry_p[0]); (void)hipFree(ctx->kry_p[1]); (void)hipFree(ctx->kry_p[2]);
   (void)hipFree(ctx->red_partial); (void)hipFree(ctx->red_out); (void)hipHostFree(ctx->red_host);
   (void)hipFree(ctx->scan_tmp);
   for (int i = 0; i < 4; ++i) (void)hipFree(ctx->halo_buf[i]);
@@ -617,7 +617,7 @@ int xpic_solve(xpic_ctx* ctx, int op, int rhs, int x, double rtol, double atol, 
 int xpic_set_preconditioner(xpic_ctx* ctx, int kind, int degree)
 {
   CTX_CHECK(ctx);
-  XPIC_CHECK(kind == 0 || kind == 1, "unknown preconditioner kind");
+  XPIC_CHECK(kind >= 0 && kind <= 2, "unknown preconditioner kind");
   ctx->precond = kind;
   if (degree > 0) ctx->cheb_degree = degree > 64 ? 64 : degree;
   return 0;

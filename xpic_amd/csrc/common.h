@@ -150,7 +150,8 @@ struct xpic_ctx {
   // Krylov workspace
   double* kry_V = nullptr; // (m+1) vectors
   double* kry_w = nullptr;
-  double* kry_t = nullptr; // preconditioned vector
+  double* kry_t = nullptr; // preconditioner scratch (fp32 copy of its input)
+  double* kry_Z = nullptr; // flexible GMRES: the preconditioned basis z_j = P v_j (allocated by the first preconditioned solve)
   double* kry_p[3] = {nullptr, nullptr, nullptr}; // Chebyshev preconditioner work vectors
   int precond = 1;     // 0 none, 1 Chebyshev polynomial in matM (right preconditioning)
   int cheb_degree = 0; // steps of the Chebyshev iteration (set at create from the spectral interval)

@@ -164,13 +164,13 @@ int finish_reduce(xpic_ctx* c, int nv, int nblocks, int nseg, double* host_out)
 
 // ---- curl: Rotor::fill_stencil + values (src/utils/operators.cpp:155-215) ---------------------------
 // positive shift: (rot F)_x = (Fz[y+1]-Fz[y])/dy - (Fy[z+1]-Fy[z])/dz, ... ; negative: backward differences.
-template <int SIGN>
-__device__ inline void rot_at(const GridDev& g, const double* F, int x, int y, int z, double& rx, double& ry, double& rz)
+template <int SIGN, class T = double> // T: storage type of the vector (arithmetic is fp64)
+__device__ inline void rot_at(const GridDev& g, const T* F, int x, int y, int z, double& rx, double& ry, double& rz)
 {
   const double ix = 1.0 / g.dx, iy = 1.0 / g.dy, iz = 1.0 / g.dz;
-  const double* Fx = F;
-  const double* Fy = F + g.cstride;
-  const double* Fz = F + 2 * g.cstride;
+  const T* Fx = F;
+  const T* Fy = F + g.cstride;
+  const T* Fz = F + 2 * g.cstride;
   const long c0 = g.nodew(x, y, z);
   if (SIGN > 0) {
     const long xp = g.nodew(x + 1, y, z), yp = g.nodew(x, y + 1, z), zp = g.nodew(x, y, z + 1);
@@ -211,26 +211,27 @@ __global__ void __launch_bounds__(kBlock) k_rot(GridDev g, double alpha, const d
 
 // (matM x)_c = 2 x_c + 0.5 dt^2 (rot- rot+ x)_c   (src/impls/ecsim/simulation.cpp:544-551)
 // rot+ is evaluated on the fly at the 2 neighbours each backward difference needs: a 13-point stencil.
-__device__ inline void matM_at(const GridDev& g, const double* F, int x, int y, int z, double& mx, double& my, double& mz)
+template <class T = double>
+__device__ inline void matM_at(const GridDev& g, const T* F, int x, int y, int z, double& mx, double& my, double& mz)
 {
   const double ix = 1.0 / g.dx, iy = 1.0 / g.dy, iz = 1.0 / g.dz;
   double ax, ay, az; // rot+ at (x,y,z)
   double bx, by, bz; // rot+ at (x-1,y,z)
   double cx, cy, cz; // rot+ at (x,y-1,z)
   double dx_, dy_, dz_; // rot+ at (x,y,z-1)
-  rot_at<+1>(g, F, x, y, z, ax, ay, az);
-  rot_at<+1>(g, F, x - 1, y, z, bx, by, bz);
-  rot_at<+1>(g, F, x, y - 1, z, cx, cy, cz);
-  rot_at<+1>(g, F, x, y, z - 1, dx_, dy_, dz_);
+  rot_at<+1, T>(g, F, x, y, z, ax, ay, az);
+  rot_at<+1, T>(g, F, x - 1, y, z, bx, by, bz);
+  rot_at<+1, T>(g, F, x, y - 1, z, cx, cy, cz);
+  rot_at<+1, T>(g, F, x, y, z - 1, dx_, dy_, dz_);
   const double s = 0.5 * g.dt * g.dt;
   const long c0 = g.nodew(x, y, z);
   // negative-shift curl of G = rot+ F (operators.cpp:196-213)
   double rx = +iy * az - iy * cz - iz * ay + iz * dy_;
   double ry = -ix * az + ix * bz + iz * ax - iz * dx_;
   double rz = +ix * ay - ix * by - iy * ax + iy * cx;
-  mx = 2.0 * F[c0] + s * rx;
-  my = 2.0 * F[c0 + g.cstride] + s * ry;
-  mz = 2.0 * F[c0 + 2 * g.cstride] + s * rz;
+  mx = 2.0 * (double)F[c0] + s * rx;
+  my = 2.0 * (double)F[c0 + g.cstride] + s * ry;
+  mz = 2.0 * (double)F[c0 + 2 * g.cstride] + s * rz;
 }
 
 __global__ void __launch_bounds__(kBlock) k_matM(GridDev g, const double* F, double* out, int add)
@@ -307,6 +308,38 @@ __global__ void __launch_bounds__(kBlock) k_cheb(GridDev g, const double* __rest
       const double dn = cd * (FIRST ? z0 : d[oc]) + cr * (rv - (FIRST ? m[c] * itheta : m[c]));
       d[oc] = dn;
       zout[oc] = z0 + dn;
+    }
+  }
+}
+
+// The same step on fp32 copies of the vectors (fp64 arithmetic): the preconditioner of a flexible GMRES may be inexact,
+// and the iteration is pure memory traffic (5 V per step).  FIRST reads the fp64 input and leaves its fp32 copy for the
+// later steps; LAST writes the fp64 result.
+template <bool FIRST, bool LAST>
+__global__ void __launch_bounds__(kBlock) k_cheb32(GridDev g, const double* __restrict__ r64, float* __restrict__ r32,
+  const float* __restrict__ zin, float* __restrict__ d, float* __restrict__ zout, double* __restrict__ out64, double cd,
+  double cr, double itheta)
+{
+  const long n = g.nown;
+  const long stride = (long)gridDim.x * kBlock;
+  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    int x = (int)(i % g.nx), y = (int)((i / g.nx) % g.ny), z = (int)(i / g.plane);
+    double m[3];
+    if (FIRST) matM_at<double>(g, r64, x, y, z, m[0], m[1], m[2]);
+    else matM_at<float>(g, zin, x, y, z, m[0], m[1], m[2]);
+    const long o = g.node(x, y, g.wz(z));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const long oc = o + c * g.cstride;
+      const double rv = FIRST ? r64[oc] : (double)r32[oc];
+      const double z0 = FIRST ? rv * itheta : (double)zin[oc];
+      const double dn = cd * (FIRST ? z0 : (double)d[oc]) + cr * (rv - (FIRST ? m[c] * itheta : m[c]));
+      if (FIRST && !LAST) r32[oc] = (float)rv;
+      if (LAST) out64[oc] = z0 + dn;
+      else {
+        d[oc] = (float)dn;
+        zout[oc] = (float)(z0 + dn);
+      }
     }
   }
 }
@@ -625,34 +658,60 @@ int matA_apply(xpic_ctx* c, const double* x, double* y)
   return 0;
 }
 
+int halo_fill_f32(xpic_ctx* c, float* f, int width);
+
 // z = p_k(matM) r ~ matM^-1 r: k steps of the Chebyshev iteration on [a, b] = [2, 2 + 2 dt^2 sum 1/h^2], the exact
 // spectral interval of matM = 2 I + 0.5 dt^2 rot- rot+ on the periodic Yee grid.  A fixed polynomial: a linear
-// operator, no inner products (no all-reduce), one 1-plane halo per step.  `z` ends in out; uses c->kry_p[0..2].
+// operator, no inner products (no all-reduce), one 1-plane halo per step.  `z` ends in out; uses c->kry_p[0..2] and
+// c->kry_t.  precond kind 1 keeps the iteration's vectors in fp32 (half the traffic; the flexible GMRES around it does
+// not care how exact its preconditioner is, krylov.hip), kind 2 in fp64.
 int cheb_matM_inverse(xpic_ctx* c, const double* r, double* out)
 {
   Timed t(c, "precond");
   const GridDev& g = c->g;
   const double a = 2.0, b = 2.0 + 2.0 * g.dt * g.dt * (1.0 / (g.dx * g.dx) + 1.0 / (g.dy * g.dy) + 1.0 / (g.dz * g.dz));
   const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma1 = theta / delta;
-  double* d = c->kry_p[0];
-  double* z0 = c->kry_p[1];
-  double* z1 = c->kry_p[2];
   const int degree = c->cheb_degree;
   if (degree <= 1) return launch_ew(c, FScaleTo{out, 1.0 / theta, r});
   double rho = 1.0 / sigma1;
   long blocks = (g.nown + kBlock - 1) / kBlock;
   if (blocks > 65536) blocks = 65536;
+  const dim3 grid((unsigned)blocks), block(kBlock);
+  if (c->precond == 1) {
+    float* d = (float*)c->kry_p[0];
+    float* z0 = (float*)c->kry_p[1];
+    float* z1 = (float*)c->kry_p[2];
+    float* r32 = (float*)c->kry_t;
+    for (int i = 1; i < degree; ++i) {
+      const double rho_new = 1.0 / (2.0 * sigma1 - rho);
+      const double cd = rho_new * rho, cr = 2.0 * rho_new / delta, it = 1.0 / theta;
+      const bool first = i == 1, last = i == degree - 1;
+      if (first) XPIC_CALL(halo_fill(c, const_cast<double*>(r), 1));
+      else XPIC_CALL(halo_fill_f32(c, z0, 1));
+      if (first && last) hipLaunchKernelGGL((k_cheb32<true, true>), grid, block, 0, c->stream, g, r, r32, z0, d, z1, out, cd, cr, it);
+      else if (first) hipLaunchKernelGGL((k_cheb32<true, false>), grid, block, 0, c->stream, g, r, r32, z0, d, z1, out, cd, cr, it);
+      else if (last) hipLaunchKernelGGL((k_cheb32<false, true>), grid, block, 0, c->stream, g, r, r32, z0, d, z1, out, cd, cr, it);
+      else hipLaunchKernelGGL((k_cheb32<false, false>), grid, block, 0, c->stream, g, r, r32, z0, d, z1, out, cd, cr, it);
+      XPIC_HIP(hipGetLastError());
+      rho = rho_new;
+      std::swap(z0, z1);
+    }
+    return 0;
+  }
+  double* d = c->kry_p[0];
+  double* z0 = c->kry_p[1];
+  double* z1 = c->kry_p[2];
   for (int i = 1; i < degree; ++i) {
     const double rho_new = 1.0 / (2.0 * sigma1 - rho);
     double* zout = i == degree - 1 ? out : z1; // the last step lands in the caller's vector
     if (i == 1) {
       XPIC_CALL(halo_fill(c, const_cast<double*>(r), 1));
-      hipLaunchKernelGGL(k_cheb<true>, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, g, r, r, d, zout,
+      hipLaunchKernelGGL(k_cheb<true>, grid, block, 0, c->stream, g, r, r, d, zout,
         rho_new * rho, 2.0 * rho_new / delta, 1.0 / theta);
     }
     else {
       XPIC_CALL(halo_fill(c, z0, 1));
-      hipLaunchKernelGGL(k_cheb<false>, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, g, r, z0, d, zout,
+      hipLaunchKernelGGL(k_cheb<false>, grid, block, 0, c->stream, g, r, z0, d, zout,
         rho_new * rho, 2.0 * rho_new / delta, 1.0 / theta);
     }
     XPIC_HIP(hipGetLastError());
@@ -718,8 +777,8 @@ int field_export(xpic_ctx* c, const double* src, double* dst_host)
 namespace {
 
 // buf[c][w][plane] <-> f[c][zs0 + w][plane]
-template <int OP> // 0: pack f -> buf, 1: unpack buf -> f, 2: add buf into f
-__global__ void __launch_bounds__(kBlock) k_planes(GridDev g, double* f, double* buf, int zs0, int width)
+template <int OP, class T = double> // 0: pack f -> buf, 1: unpack buf -> f, 2: add buf into f
+__global__ void __launch_bounds__(kBlock) k_planes(GridDev g, T* f, T* buf, int zs0, int width)
 {
   const long per = (long)width * g.plane;
   const long n = 3 * per;
@@ -760,27 +819,34 @@ int ensure_halo_buf(xpic_ctx* c, size_t bytes)
   return 0;
 }
 
-int halo_fill(xpic_ctx* c, double* f, int width)
+namespace {
+template <class T>
+int halo_fill_t(xpic_ctx* c, T* f, int width)
 {
   const GridDev& g = c->g;
   if (g.G == 0) return 0;
   XPIC_CHECK(width <= g.G && width <= g.nzl, "halo width exceeds the ghost layer");
   Timed t(c, "halo");
   const long n = 3L * width * g.plane;
-  const size_t bytes = sizeof(double) * n;
+  const size_t bytes = sizeof(T) * n;
   XPIC_CALL(ensure_halo_buf(c, bytes));
   const unsigned nb = plane_grid(n);
+  T* hb[4] = {(T*)c->halo_buf[0], (T*)c->halo_buf[1], (T*)c->halo_buf[2], (T*)c->halo_buf[3]};
   // my bottom owned planes go down, my top owned planes go up
-  hipLaunchKernelGGL(k_planes<0>, dim3(nb), dim3(kBlock), 0, c->stream, g, f, c->halo_buf[0], g.G, width);
-  hipLaunchKernelGGL(k_planes<0>, dim3(nb), dim3(kBlock), 0, c->stream, g, f, c->halo_buf[1], g.G + g.nzl - width, width);
+  hipLaunchKernelGGL((k_planes<0, T>), dim3(nb), dim3(kBlock), 0, c->stream, g, f, hb[0], g.G, width);
+  hipLaunchKernelGGL((k_planes<0, T>), dim3(nb), dim3(kBlock), 0, c->stream, g, f, hb[1], g.G + g.nzl - width, width);
   XPIC_HIP(hipGetLastError());
   XPIC_CALL(comm_ring(c, c->halo_buf[0], bytes, c->halo_buf[1], bytes, c->halo_buf[2], bytes, c->halo_buf[3], bytes));
   // from the upper neighbour: its bottom planes = my upper ghost; from the lower: its top planes = my lower ghost
-  hipLaunchKernelGGL(k_planes<1>, dim3(nb), dim3(kBlock), 0, c->stream, g, f, c->halo_buf[2], g.G + g.nzl, width);
-  hipLaunchKernelGGL(k_planes<1>, dim3(nb), dim3(kBlock), 0, c->stream, g, f, c->halo_buf[3], g.G - width, width);
+  hipLaunchKernelGGL((k_planes<1, T>), dim3(nb), dim3(kBlock), 0, c->stream, g, f, hb[2], g.G + g.nzl, width);
+  hipLaunchKernelGGL((k_planes<1, T>), dim3(nb), dim3(kBlock), 0, c->stream, g, f, hb[3], g.G - width, width);
   XPIC_HIP(hipGetLastError());
   return 0;
 }
+}  // namespace
+
+int halo_fill(xpic_ctx* c, double* f, int width) { return halo_fill_t<double>(c, f, width); }
+int halo_fill_f32(xpic_ctx* c, float* f, int width) { return halo_fill_t<float>(c, f, width); }
 
 int halo_add(xpic_ctx* c, double* f, int width)
 {

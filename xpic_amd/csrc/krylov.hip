@@ -20,16 +20,23 @@ int apply_op(xpic_ctx* c, int op, double* x, double* y)
   return matM_apply(c, x, y, false);
 }
 
-// Right-preconditioned restarted GMRES: A P y = b, x = P y.  The recurrence residual is the TRUE residual
-// |b - A x|, so the stopping rule is the same with and without P.
+// Right-preconditioned restarted GMRES in its flexible form: z_j = P v_j is kept (kry_Z), the Arnoldi relation is
+// A Z = V H and x = x0 + Z y.  The recurrence residual is the TRUE residual |b - A x|, so the stopping rule is the
+// same with and without P -- and, the z_j being whatever P returned, it stays so when P is applied in reduced
+// precision (fields.hip: cheb_matM_inverse works on fp32 copies).  Compared with x = P (V y) this also saves the
+// preconditioner application that closes every cycle.
 int gmres(xpic_ctx* c, int op, const double* b, double* x, double rtol, double atol, int maxit, int* its_out,
   int* reason, double* rnorm_out)
 {
   const int m = kRestart;
   // both GMRES solves are right-preconditioned by the Chebyshev polynomial in matM: for the "correct" solve on matM
   // itself it is an approximate inverse (1-2 iterations instead of ~25)
-  const bool pc = (op == XPIC_OP_MATA_GMRES || op == XPIC_OP_MATM_GMRES) && c->precond == 1;
-  double* tmp = c->kry_t;
+  const bool pc = (op == XPIC_OP_MATA_GMRES || op == XPIC_OP_MATM_GMRES) && c->precond != 0;
+  if (pc && !c->kry_Z) {
+    XPIC_HIP(hipMalloc(&c->kry_Z, sizeof(double) * c->nvec * m));
+    XPIC_HIP(hipMemsetAsync(c->kry_Z, 0, sizeof(double) * c->nvec * m, c->stream));
+  }
+  double* Z = c->kry_Z;
   double* V = c->kry_V;
   double* w = c->kry_w;
   std::vector<double> H((m + 1) * m, 0.0), cs(m), sn(m), gg(m + 1), h(m + 2), yv(m);
@@ -61,8 +68,9 @@ int gmres(xpic_ctx* c, int op, const double* b, double* x, double rtol, double a
     for (; j < m && its < maxit; ++j) {
       double* Vj = V + (long)j * c->nvec;
       if (pc) {
-        XPIC_CALL(cheb_matM_inverse(c, Vj, tmp));
-        XPIC_CALL(apply_op(c, op, tmp, w));
+        double* Zj = Z + (long)j * c->nvec;
+        XPIC_CALL(cheb_matM_inverse(c, Vj, Zj));
+        XPIC_CALL(apply_op(c, op, Zj, w));
       }
       else XPIC_CALL(apply_op(c, op, Vj, w));
       XPIC_CALL(vec_mdot_host(c, w, V, j + 1, h.data()));           // VecMDot
@@ -91,13 +99,7 @@ int gmres(xpic_ctx* c, int op, const double* b, double* x, double rtol, double a
       for (int k = i + 1; k < j; ++k) t -= H[i * m + k] * yv[k];
       yv[i] = H[i * m + i] != 0.0 ? t / H[i * m + i] : 0.0;
     }
-    if (pc) { // x += P (V y)
-      XPIC_CALL(vec_set(c, w, 0.0));
-      XPIC_CALL(vec_maxpy(c, w, V, j, yv.data()));
-      XPIC_CALL(cheb_matM_inverse(c, w, tmp));
-      XPIC_CALL(vec_axpy(c, x, 1.0, tmp));
-    }
-    else XPIC_CALL(vec_maxpy(c, x, V, j, yv.data())); // x += V y
+    XPIC_CALL(vec_maxpy(c, x, pc ? Z : V, j, yv.data())); // x += Z y  (x += V y without P)
     if (rnorm <= tol) break;
     if (its >= maxit) break;
     // restart: r = b - A x, kept in w
