@@ -87,6 +87,8 @@ struct GridDev {
   }
 };
 
+constexpr int kCellStartPad = 16; // readable ints behind cell_start[ncell]
+
 struct SortDev {
   double* r[3];   // positions  (SoA)
   double* v[3];   // velocities (SoA; `Point::p` holds velocity in these schemes)
@@ -95,7 +97,7 @@ struct SortDev {
   int* cell;      // new local cell of each particle (or -1: dropped)
   int* rank;      // arrival rank of the particle inside its new cell
   int* cell_count;
-  int* cell_start; // [ncell+1] exclusive prefix of cell_count
+  int* cell_start; // [ncell+1 (+ kCellStartPad readable)] exclusive prefix of cell_count
 };
 
 struct Sort {

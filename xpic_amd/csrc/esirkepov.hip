@@ -76,6 +76,7 @@ constexpr int kFtPer = (6 * kTileN + kThreadsB - 1) / kThreadsB; // gather-tile 
 constexpr int kLinesB = 3 * kD * kD;  // 48 lines of 4 nodes
 constexpr int kNb = 36 + 54;          // CIC neighbourhood of a cell (MODE 2): 3 x 12 E nodes, 54 B nodes
 constexpr int kNbPer = (kSeg * kNb + kThreadsB - 1) / kThreadsB;
+static_assert(kSeg <= kCellStartPad, "compose reads kSeg entries ahead");
 static_assert(6 * kTileN <= kSRows * StageDim<0>::kPitch, "the gather tile shares the stage's LDS");
 
 // raw workgroup barrier that only drains LDS traffic: the particle stores, the J atomics and the requests of the next
@@ -199,7 +200,7 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
     // the cell_start entries the round can need, requested together (one scalar-cache latency instead of one per cell)
     int cv[kSeg + 1];
 #pragma unroll
-    for (int i = 0; i <= kSeg; ++i) cv[i] = cs[min(base + i, g.nx)];
+    for (int i = 0; i <= kSeg; ++i) cv[i] = cs[base + i]; // entries past the pencil's end are read (kCellStartPad) but not used
     int nseg = 0, cols = 0, tc = 0;
     bool open = true;
 #pragma unroll
@@ -298,6 +299,7 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
     // ---- this round's neighbourhoods / tile go to LDS; the next round is composed and requested
     if (MODE == 0) {
       // DMGlobalToLocal(E), (B) (basic/simulation.cpp:56-57) for just the nodes the round's particles can gather from
+      // (requesting the tile a round ahead was measured: no gain, the other workgroup of the CU covers the latency)
       double ft[kFtPer];
 #pragma unroll
       for (int k = 0; k < kFtPer; ++k) {
@@ -307,7 +309,9 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
           const int f = t / kTileN, n = t % kTileN;
           const int tx = n % kTX, ty = (n / kTX) % kT, tz = n / (kTX * kT);
           const double* F = (f < 3 ? E : B) + (f % 3) * g.cstride;
-          ft[k] = F[g.nodew(base - 2 + tx, cy - 2 + ty, cz - 2 + tz)];
+          // (a particle of the pencil's last cell reaches node nx + 2 at most: nothing beyond is gathered from, and
+          // nodew folds an index only once)
+          if (base - 2 + tx <= g.nx + 2) ft[k] = F[g.nodew(base - 2 + tx, cy - 2 + ty, cz - 2 + tz)];
         }
       }
 #pragma unroll

@@ -660,7 +660,10 @@ int sort_alloc(xpic_ctx* c, Sort& s, int64_t cap)
   XPIC_HIP(hipMalloc(&s.d.cell, sizeof(int) * cap));
   XPIC_HIP(hipMalloc(&s.d.rank, sizeof(int) * cap));
   XPIC_HIP(hipMalloc(&s.d.cell_count, sizeof(int) * (c->ncell + 1)));
-  XPIC_HIP(hipMalloc(&s.d.cell_start, sizeof(int) * (c->ncell + 1)));
+  // + kCellStartPad: the pencil kernels read a fixed number of entries ahead of the cell they are at (never used past
+  // the pencil's end, but the reads must land in the allocation)
+  XPIC_HIP(hipMalloc(&s.d.cell_start, sizeof(int) * (c->ncell + 1 + kCellStartPad)));
+  XPIC_HIP(hipMemsetAsync(s.d.cell_start, 0, sizeof(int) * (c->ncell + 1 + kCellStartPad), c->stream));
   XPIC_HIP(hipMemsetAsync(s.d.cell_count, 0, sizeof(int) * (c->ncell + 1), c->stream));
   XPIC_HIP(hipMemsetAsync(s.d.cell_start, 0, sizeof(int) * (c->ncell + 1), c->stream));
   if (c->g.G > 0) {
