@@ -219,6 +219,18 @@ def test_preconditioned_solve(oracle):
     g.set_preconditioner(1, 12)
     its12, _, _ = g.solve(0, X.E, X.W1, 1e-9, 1e-50, 300)
     assert its12 <= its_pc
+    # kind 1 keeps the polynomial's work vectors in fp32, kind 2 in fp64: same iteration count (+- 1), and -- the GMRES
+    # being the flexible variant (x = x0 + sum y_j P v_j with the stored P v_j) -- the fp32 vectors do not limit the
+    # residual that can be reached
+    g.set_preconditioner(2, 0)
+    its64, reason64, _ = g.solve(0, X.E, X.W2, 1e-9, 1e-50, 300)
+    assert reason64 > 0 and abs(its64 - its_pc) <= 1
+    assert np.abs(g.get_field(X.W2) - xg).max() <= 1e-7 * np.abs(xg).max()
+    g.set_preconditioner(1, 0)
+    _, reason_t, rn_t = g.solve(0, X.E, X.W1, 1e-12, 1e-50, 300)
+    xt = g.get_field(X.W1)
+    rt = np.linalg.norm(o.matM(xt) + o.matL_apply(xt) - rhs)
+    assert reason_t > 0 and rt <= 2e-12 * np.linalg.norm(rhs), (rt, rn_t)
 
 
 def test_default_step_uses_preconditioner_and_matches_oracle(oracle):
