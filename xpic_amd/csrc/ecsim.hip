@@ -70,17 +70,21 @@ namespace {
 
 constexpr int kW = 4;             // waves per workgroup = cells per chunk
 #ifndef FILL_KCP
-#define FILL_KCP 48
+#define FILL_KCP 56
 #endif
 #ifndef FILL_OCC
 #define FILL_OCC 2
 #endif
-constexpr int kCP = FILL_KCP;      // particles staged per pass and wave (Poisson(64) cells: two passes)
+constexpr int kCP = FILL_KCP;      // particles staged per pass and wave (Poisson(64) cells: two passes for 5 cells of 6)
 // One stage slot = one particle: 24 weights [c][i][h] (i: the 2 x 2 nodes transverse to the component's staggered axis,
-// h: lower / upper node along it), 9 A_p*matB, 3 I_p.  Pitch 42 doubles = 84 dwords: the 16-byte stores of 8
-// consecutive slots fall in 8 distinct bank quads (84 l mod 32 = 0,20,8,28,16,4,24,12) and the operand reads of the
-// two particles that share an LDS cycle are 20 banks apart.
-constexpr int kPitch = 42;
+// h: lower / upper node along it), 9 A_p*matB, 3 I_p.  Pitch 38 doubles = 76 dwords: the 16-byte stores of 8
+// consecutive slots fall in 8 distinct bank quads (76 l mod 32 = 0,12,24,4,16,28,8,20) and the operand reads of the
+// two particles that share an LDS cycle are 12 banks apart (pitch 42 measured the same; 38 makes room for 56 slots
+// per wave at two workgroups per CU: 123.9 ms per assembly against 125.4 with 48).
+#ifndef FILL_PITCH
+#define FILL_PITCH 38
+#endif
+constexpr int kPitch = FILL_PITCH;
 constexpr int kOffAB = 24; // [24, 33): A_p*matB row-major, [33, 36): I_p
 constexpr int kStage = kCP * kPitch;
 constexpr int kAcc = 36;          // accumulators per lane: 30 matL (component pair x octant bits of the pair) + 6 currI
