@@ -6,7 +6,7 @@
 // and EsirkepovDecomposition (src/algorithms/esirkepov_decomposition.cpp:20-103) for cell-sorted SoA particles.
 //
 // A workgroup (4 waves) owns one x-pencil of cells and marches along it in ROUNDS.  A round takes the particles of as
-// many consecutive cells as fit into its 240 stage columns (up to 8 cells; a cell's columns are padded to a multiple
+// many consecutive cells as fit into its 240 stage columns (160 for MODE 1; up to 8 cells; a cell's columns are padded to a multiple
 // of 4; a cell with more particles than a round holds continues in the next round) and hands them out one per thread,
 // so that the waves are full whatever the number of particles per cell: the instruction stream of a wave costs the same
 // for 1 or 64 live lanes, and with one wave per cell (the previous organisation) a 32-particle cell left half of them
@@ -56,6 +56,7 @@ constexpr int kSeg = 8;               // cells (segments) per round
 // Columns of the stage = particles of a round, each cell's padded to a multiple of 4 (the K of the MFMA step).  A wave
 // issues the same instruction stream for 1 or 64 particles, so a round packs the particles of as many cells of the
 // pencil as fit: at 32 particles per cell about 7 cells = 224 of the 256 lanes, where one wave per cell filled 32 of 64.
+// MODE 1 (the lightest phase 1) does better with 160 columns and three workgroups per CU (6.7 ms against 7.8 with 240).
 #ifndef ESK_COLS1
 #define ESK_COLS1 160
 #endif
