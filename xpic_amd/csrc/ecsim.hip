@@ -70,17 +70,18 @@ namespace {
 
 constexpr int kW = 4;             // waves per workgroup = cells per chunk
 #ifndef FILL_KCP
-#define FILL_KCP 56
+#define FILL_KCP 64
 #endif
 #ifndef FILL_OCC
 #define FILL_OCC 2
 #endif
-constexpr int kCP = FILL_KCP;      // particles staged per pass and wave (Poisson(64) cells: two passes for 5 cells of 6)
+constexpr int kCP = FILL_KCP;      // particles staged per pass and wave: one pass for a cell of up to 64 (53 % of Poisson(64) cells)
 // One stage slot = one particle: 24 weights [c][i][h] (i: the 2 x 2 nodes transverse to the component's staggered axis,
 // h: lower / upper node along it), 9 A_p*matB, 3 I_p.  Pitch 38 doubles = 76 dwords: the 16-byte stores of 8
 // consecutive slots fall in 8 distinct bank quads (76 l mod 32 = 0,12,24,4,16,28,8,20) and the operand reads of the
-// two particles that share an LDS cycle are 12 banks apart (pitch 42 measured the same; 38 makes room for 56 slots
-// per wave at two workgroups per CU: 123.9 ms per assembly against 125.4 with 48).
+// two particles that share an LDS cycle are 12 banks apart (pitch 42 measured the same).  With pitch 38 and without the
+// LDS copies of two small tables (FILL_LEAN_LDS) four waves x 64 slots + the rest are 79 856 bytes: two workgroups per
+// CU.  Per assembly at 256^3 x 64: 48 slots 125.4 ms, 56 slots 123.9, 64 slots 121.7.
 #ifndef FILL_PITCH
 #define FILL_PITCH 38
 #endif
@@ -95,7 +96,12 @@ constexpr int kLines = kMatLines + kCurLines;
 constexpr int kThreads = kW * 64;
 constexpr int kSlots = kW + 2;    // window columns: kW finished + 2 carried
 constexpr int kOwn = (kLines + kThreads - 1) / kThreads; // window lines owned by a thread (init, flush, carry)
-constexpr int kMaxNxLds = 512;    // pencils up to this length keep their cell_start row in LDS
+#ifndef FILL_LEAN_LDS
+#define FILL_LEAN_LDS 1 // 1: the per-lane window offsets and the cell_start row are read from global memory (five 16-byte
+                        // loads per chunk, scalar loads) instead of LDS copies: the 6.6 KB are what lets a wave stage 64 particles
+#endif
+constexpr int kDtabPitch = 40;     // ushorts per lane of the transposed offset table (FILL_LEAN_LDS)
+constexpr int kMaxNxLds = FILL_LEAN_LDS ? 0 : 512; // pencils up to this length keep their cell_start row in LDS
 
 // accumulator of the block (c1, c2) for a particle of octant o = ox | oy << 1 | oz << 2: the rows depend on the
 // octant bit of axis c1 only, the columns on that of axis c2
@@ -167,7 +173,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
 
   __shared__ __attribute__((aligned(16))) double sh[kW * kStage];
   __shared__ __attribute__((aligned(16))) double zslot[kPitch]; // the particle of weight zero that fills up a K = 4 step
-  __shared__ unsigned short dsc[kAcc * 64]; // offset (in doubles) of lane's element of accumulator e inside the merge window
+  __shared__ unsigned short dsc[FILL_LEAN_LDS ? 1 : kAcc * 64]; // offset (in doubles) of lane's element of accumulator e inside the merge window
   __shared__ int cstart[kMaxNxLds + 2];
   __shared__ double bnb[kW][54];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -185,11 +191,12 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
   const int offB = qj * 2 + (qb & 1);                    // + c2 * 8: column weights s[c2][j = qj][h2]
   const bool cur1_lane = qj == 0, cur2_lane = qj == 0 && qb < 2;
 
-  for (int i = threadIdx.x; i < kAcc * 64; i += kThreads) dsc[i] = dtab[i];
+  if (!FILL_LEAN_LDS)
+    for (int i = threadIdx.x; i < kAcc * 64; i += kThreads) dsc[i] = dtab[i];
   if (threadIdx.x < kPitch) zslot[threadIdx.x] = 0.0;
 
   const long pencil0 = ((long)cz * g.ny + cy) * g.nx;
-  const bool cs_lds = g.nx <= kMaxNxLds;
+  const bool cs_lds = !FILL_LEAN_LDS && g.nx <= kMaxNxLds;
   if (cs_lds)
     for (int i = threadIdx.x; i <= g.nx; i += kThreads) cstart[i] = s.cell_start[pencil0 + i];
   // address of column 0 of the window lines this thread owns (line = thread + mm * kThreads), first-touch flag in bit 0
@@ -248,8 +255,12 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
       pf.cnt = __builtin_amdgcn_readfirstlane(cstart[cx + 1]) - pf.start;
     }
     else {
-      pf.start = __builtin_amdgcn_readfirstlane(s.cell_start[pencil0 + cx]);
-      pf.cnt = __builtin_amdgcn_readfirstlane(s.cell_start[pencil0 + cx + 1]) - pf.start;
+      // wave-uniform index: a scalar load (cell_start does not change while this kernel runs)
+      using UniformInts = const __attribute__((address_space(4))) int*;
+      UniformInts cs = (UniformInts)(s.cell_start + pencil0);
+      const int cxu = __builtin_amdgcn_readfirstlane(cx);
+      pf.start = cs[cxu];
+      pf.cnt = cs[cxu + 1] - pf.start;
     }
     pf.b = load_bnb(g, B, lane, cx, cy, cz);
     if (lane < min(kCP, pf.cnt)) {
@@ -480,7 +491,23 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     // the finished columns out and keeps the last two in registers.
     unsigned wdst[kAcc]; // requested now, used after the window is seeded
 #pragma unroll
-    for (int e = 0; e < kAcc; ++e) wdst[e] = dsc[e * 64 + lane];
+    for (int e = 0; e < kAcc; ++e) wdst[e] = 0;
+    if (FILL_LEAN_LDS) {
+      // the lane's 36 offsets are 72 contiguous bytes of the table (transposed on the host): five 16-byte loads
+      const uint4* q = reinterpret_cast<const uint4*>(dtab + lane * kDtabPitch);
+#pragma unroll
+      for (int k = 0; k < kDtabPitch / 8; ++k) {
+        const uint4 w4 = q[k];
+        const unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int h = 0; h < 8; ++h)
+          if (k * 8 + h < kAcc) wdst[k * 8 + h] = (w[h >> 1] >> (16 * (h & 1))) & 0xffffu;
+      }
+    }
+    else {
+#pragma unroll
+      for (int e = 0; e < kAcc; ++e) wdst[e] = dsc[e * 64 + lane];
+    }
     STAMP(3);
     lds_barrier();
     STAMP(4);
@@ -674,6 +701,12 @@ int build_ltab(xpic_ctx* c)
       for (int c2 = 0; c2 < 3; ++c2) seen[acc_main(c1, c2, o)] = 1;
   }
   static_assert((kLines * kSlots + 64) <= kW * kStage, "the dummy doubles must lie inside the stage area");
+  if (FILL_LEAN_LDS) { // [lane][kDtabPitch] instead of [e][64]
+    std::vector<unsigned short> t(64 * kDtabPitch, 0);
+    for (int e = 0; e < kAcc; ++e)
+      for (int lane = 0; lane < 64; ++lane) t[lane * kDtabPitch + e] = dtab[e * 64 + lane];
+    dtab.swap(t);
+  }
   const size_t total = linetab.size() + cowr.size() + (dtab.size() + 1) / 2;
   XPIC_HIP(hipMalloc(&c->ltab, sizeof(int) * total));
   XPIC_HIP(hipMemcpy(c->ltab, linetab.data(), sizeof(int) * linetab.size(), hipMemcpyHostToDevice));
