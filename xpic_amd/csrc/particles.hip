@@ -139,7 +139,13 @@ __global__ void __launch_bounds__(kBlock) k_scatter_incoming(SortDev s, const do
 template <bool MOVE, bool WRAP>
 __global__ void __launch_bounds__(kBlock) k_scatter(GridDev g, SortDev s, int64_t n, double step)
 {
-  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  // XCD r (workgroups r, r + 8, ...) sweeps its own contiguous eighth of the particles: the six 8-byte records of a
+  // particle that changes cell and the stayers of the cell it arrives in (a neighbour in x or y: close by in the
+  // array) then pass through the same L2 and leave it as full lines (28.5 -> 25 ms at 256^3 x 64)
+  const int64_t nblk = (n + kBlock - 1) / kBlock, chunk = (nblk + 7) / 8;
+  const int64_t blk = (int64_t)(blockIdx.x % 8) * chunk + blockIdx.x / 8;
+  if (blk >= nblk) return;
+  const int64_t p = blk * kBlock + threadIdx.x;
   if (p >= n) return;
   const int c = s.cell[p];
   if (c < 0) return;
@@ -798,7 +804,7 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap)
   }
   if (s.n > 0) {
     Timed t(c, "scatter");
-    const unsigned nb = pgrid(s.n);
+    const unsigned nb = (unsigned)(8 * ((pgrid(s.n) + 7) / 8)); // 8 XCD runs of equal length
 #define LAUNCH(M, W) hipLaunchKernelGGL((k_scatter<M, W>), dim3(nb), dim3(kBlock), 0, c->stream, c->g, s.d, s.n, step)
     if (move && wrap) LAUNCH(true, true);
     else if (move) LAUNCH(true, false);
