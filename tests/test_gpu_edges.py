@@ -153,3 +153,43 @@ def test_long_pencils_and_odd_colour_periods(oracle):
         po, co = canon(*o.particles(k))
         pg, cg = canon(*g.particles(k))
         assert np.array_equal(co, cg) and np.abs(po - pg).max() < 1e-9
+
+
+@pytest.mark.parametrize("scheme", ["basic", "ecsimcorr"])
+def test_esirkepov_rounds_ragged_pencils(oracle, scheme):
+    """The Esirkepov kernels pack the particles of up to 8 consecutive cells into one round of 240 (160) stage columns:
+    a cell of 700 particles (several rounds of its own, the rest sharing a round with its neighbours), one of exactly
+    240, runs of empty cells longer than a round's 8 cells, cells of 1..5 particles (all padding), a pencil that ends in
+    a full cell, and particles fast enough to leave the 4-node box (the cooperative slow path)."""
+    import xpic_amd as X
+
+    n, d = (21, 7, 6), (0.5, 0.4, 0.5)
+    dt = 0.05 if scheme == "basic" else 0.2
+    o, g = pair(oracle, scheme, n, d, dt)
+    o.add_sort(10, 1.0, -1.0, 1.0)
+    g.add_sort(10, 1.0, -1.0, 1.0, capacity=20000)
+    rng = np.random.default_rng(5)
+    pts = []
+    cells = [((3, 2, 1), 700), ((4, 2, 1), 37), ((5, 2, 1), 240), ((20, 2, 1), 130), ((0, 2, 1), 3),
+             ((19, 6, 5), 64), ((20, 6, 5), 65), ((0, 0, 0), 1), ((11, 3, 3), 5), ((12, 3, 3), 2), ((13, 3, 3), 241)]
+    for cell, cnt in cells:
+        r = (np.array(cell) + rng.random((cnt, 3))) * np.array(d)
+        v = rng.normal(0, 0.3, (cnt, 3))
+        v[: max(1, cnt // 16)] *= 6.0  # a few that move most of a cell in a step
+        v = np.clip(v, -0.7 * min(d) / dt, 0.7 * min(d) / dt)  # beyond ~0.8 cell the box of a move exceeds Shape::shape[]
+        pts.append(np.hstack([r, v]))
+    pts = np.vstack(pts)
+    assert o.add_particles(0, pts) == g.add_particles(0, pts) == len(pts)
+    B = np.zeros(o.fshape()) + np.array([0.1, -0.2, 0.3])
+    for name, fid in (("B", X.B), ("B0", X.B0)):
+        o.set_field(name, B)
+        g.set_field(fid, B)
+    for sim in (o, g):
+        sim.set_tolerances(1e-11, 1e-50, 300)
+    for t in range(3):
+        assert o.step() >= 0
+        g.step()
+        same_fields(o, g, ["E", "B"], 1e-7)
+    po, co = canon(*o.particles(0))
+    pg, cg = canon(*g.particles(0))
+    assert np.array_equal(co, cg) and np.abs(po - pg).max() < 1e-9
