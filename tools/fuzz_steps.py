@@ -31,8 +31,6 @@ def _case(case, rng, worst, verbose):
     g = X.Context(scheme, n, d, dt)
     if scheme != "basic":
         g.set_preconditioner(int(rng.integers(0, 3)))
-    o.add_sort(10, 1.0, -1.0, 1.0)
-    g.add_sort(10, 1.0, -1.0, 1.0, capacity=200000)
     # Poisson background + a few heavy cells + empty stretches
     ppc = float(rng.choice([0.3, 3.0, 20.0, 70.0]))
     cnt = rng.poisson(ppc, n[::-1])
@@ -46,6 +44,8 @@ def _case(case, rng, worst, verbose):
             r = (np.array([cx, cy, cz]) + rng.random((c, 3))) * np.array(d)
             pts.append(np.hstack([r, np.clip(rng.normal(0, 0.25, (c, 3)), -0.6 * min(d) / dt, 0.6 * min(d) / dt)]))
     pts = np.vstack(pts) if pts else np.zeros((0, 6))
+    o.add_sort(10, 1.0, -1.0, 1.0)
+    g.add_sort(10, 1.0, -1.0, 1.0, capacity=len(pts) + 1000)
     if len(pts):
         assert o.add_particles(0, pts) == g.add_particles(0, pts) == len(pts)
     B = np.zeros(o.fshape()) + rng.normal(0, 0.2, 3)
@@ -55,7 +55,17 @@ def _case(case, rng, worst, verbose):
     for sim in (o, g):
         sim.set_tolerances(1e-11, 1e-50, 400)
     for t in range(2):
-        assert o.step() >= 0, (case, scheme, n, "oracle step failed")
+        if o.step() < 0:
+            # a particle moved further than the reference's Shape::shape[] holds (the fields of the heavy cells can
+            # accelerate one that far): the oracle refuses the step, and so must the device
+            try:
+                g.step()
+            except X.XpicError as e:
+                assert "moved more than one cell" in str(e), (case, scheme, n, str(e))
+                if verbose:
+                    print("case %2d %-9s n=%-14s both sides refuse the step (move of more than a cell)" % (case, scheme, n), flush=True)
+                return
+            raise AssertionError((case, scheme, n, "the oracle refused the step, the device did not"))
         g.step()
     err = 0.0
     for name, fid in (("E", X.E), ("B", X.B)):
