@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Random small configurations (grid extents, spacings, particles per cell from 0 to a few hundred, clustered cells),
-two steps of every scheme on the GPU against the CPU oracle.  usage: fuzz_steps.py [cases] [seed]"""
+two steps of every scheme on the GPU against the CPU oracle.  usage: fuzz_steps.py [cases] [seed] [largest nx + 1]"""
 import os
 import sys
 
@@ -13,18 +13,18 @@ import xpic_amd as X
 
 
 
-def run(cases=12, seed=7, verbose=True):
+def run(cases=12, seed=7, verbose=True, nxmax=41):
     rng = np.random.default_rng(seed)
     oracle_lib.lib()
     worst = {}
     for case in range(cases):
-        _case(case, rng, worst, verbose)
+        _case(case, rng, worst, verbose, nxmax)
     return worst
 
 
-def _case(case, rng, worst, verbose):
+def _case(case, rng, worst, verbose, nxmax):
     scheme = ("basic", "ecsim", "ecsimcorr")[case % 3]
-    n = tuple(int(v) for v in rng.integers(6, [41, 13, 12]))
+    n = tuple(int(v) for v in rng.integers(6, [nxmax, 13, 12]))
     d = tuple(float(v) for v in rng.choice([0.25, 0.4, 0.5, 0.7], 3))
     dt = float(rng.choice([0.05, 0.1]) if scheme == "basic" else rng.choice([0.2, 0.5]))
     o = oracle_lib.OracleSim(scheme, n, d, dt)
@@ -87,5 +87,6 @@ def _case(case, rng, worst, verbose):
     del g
 
 if __name__ == "__main__":
-    w = run(int(sys.argv[1]) if len(sys.argv) > 1 else 12, int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+    w = run(int(sys.argv[1]) if len(sys.argv) > 1 else 12, int(sys.argv[2]) if len(sys.argv) > 2 else 7,
+            nxmax=int(sys.argv[3]) if len(sys.argv) > 3 else 41)
     print("worst relative field error per scheme:", w)
