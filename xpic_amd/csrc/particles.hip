@@ -43,9 +43,10 @@ struct Migr {
 
 // New cell of a (moved, wrapped) particle and its arrival rank in that cell; with MIG also the send side of
 // update_cells_mpi.  Every live lane of the wave calls it together (ballots).
+// src: the cell the particle sits in now, if the caller knows it (-1 otherwise).
 template <bool MIG, bool P2 = false>
 __device__ __forceinline__ void bin_particle(const GridDev& g, const SortDev& s, int64_t p, double x, double y, double z,
-  double vx, double vy, double vz, const Migr& mg)
+  double vx, double vy, double vz, const Migr& mg, int src = -1)
 {
   int c = MIG ? dest_of<P2>(g, mg.rank, mg.nranks, x, y, z) : cell_of<P2>(g, x, y, z);
   if (MIG && c <= -2) {
@@ -66,8 +67,14 @@ __device__ __forceinline__ void bin_particle(const GridDev& g, const SortDev& s,
   // cells: the lanes are grouped by cell with ballots, then ONE atomic instruction carries the returning add of
   // every group's first lane (one memory round trip per wave, not one per distinct cell).
   const int lane = threadIdx.x & 63;
+  // With the source cell known, only the particles that stay are grouped (a wave holds two or three source cells); the
+  // few that change cell (~7 %, up to 26 different neighbours: most of the loop's trips) take a returning atomic each,
+  // one instruction for all of them, in flight while the loop runs.
+  const bool solo = src >= 0 && c >= 0 && c != src;
+  int solo_rank = 0;
+  if (solo) solo_rank = atomicAdd(&s.cell_count[c], 1);
   int my_leader = lane, rank_in = 0, gsize = 0;
-  unsigned long long todo = __ballot(c >= 0);
+  unsigned long long todo = __ballot(c >= 0 && !solo);
   while (todo) {
     const int leader = __ffsll((long long)todo) - 1;
     const int lc = __shfl(c, leader, 64);
@@ -80,9 +87,9 @@ __device__ __forceinline__ void bin_particle(const GridDev& g, const SortDev& s,
     todo &= ~same;
   }
   int base = 0;
-  if (c >= 0 && lane == my_leader) base = atomicAdd(&s.cell_count[c], gsize);
+  if (c >= 0 && !solo && lane == my_leader) base = atomicAdd(&s.cell_count[c], gsize);
   base = __shfl(base, my_leader, 64);
-  const int rank = c >= 0 ? base + rank_in : 0;
+  const int rank = c >= 0 ? (solo ? solo_rank : base + rank_in) : 0;
   s.rank[p] = rank;
 }
 
@@ -372,7 +379,7 @@ __global__ void __launch_bounds__(kSPRound) k_second_push(GridDev g, SortDev s, 
         const double x = bound_periodic(r[0] + v[0] * g.dt, g.Lx);
         const double y = bound_periodic(r[1] + v[1] * g.dt, g.Ly);
         const double z = bound_periodic(r[2] + v[2] * g.dt, g.Lz);
-        bin_particle<MIG, P2>(g, s, p, x, y, z, v[0], v[1], v[2], mg);
+        bin_particle<MIG, P2>(g, s, p, x, y, z, v[0], v[1], v[2], mg, (int)(q * g.nx) + w.in[0]);
       }
     }
   }
