@@ -92,7 +92,9 @@ __device__ inline void gather_s1(const GridDev& g, const double* __restrict__ E,
   }
 }
 
-// BorisPush::update_vEB (src/algorithms/boris_push.cpp:48-57), same operation order
+// BorisPush::update_vEB (src/algorithms/boris_push.cpp:48-57), same operation order; the three divisions by the same
+// denominator are one reciprocal and three products (one rounding apart from the reference's quotient: an fp64 division
+// is ~15 instructions, and the kernels this sits in are bound by instruction issue)
 __device__ inline void update_vEB(double dt, double qm, const double* E, const double* B, double* v)
 {
   const double alpha = dt * qm;
@@ -103,8 +105,9 @@ __device__ inline void update_vEB(double dt, double qm, const double* E, const d
   const double bw[3] = {+(b[1] * w[2] - b[2] * w[1]), -(b[0] * w[2] - b[2] * w[0]), +(b[0] * w[1] - b[1] * w[0])};
   const double bbw[3] = {+(b[1] * bw[2] - b[2] * bw[1]), -(b[0] * bw[2] - b[2] * bw[0]), +(b[0] * bw[1] - b[1] * bw[0])};
   const double den = 1.0 + 0.25 * (b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+  const double rden = 1.0 / den;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) v[c] += a[c] + (bw[c] + 0.5 * bbw[c]) / den;
+  for (int c = 0; c < 3; ++c) v[c] += a[c] + (bw[c] + 0.5 * bbw[c]) * rden;
 }
 
 
