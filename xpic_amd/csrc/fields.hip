@@ -167,7 +167,7 @@ int finish_reduce(xpic_ctx* c, int nv, int nblocks, int nseg, double* host_out)
 template <int SIGN, class T = double> // T: storage type of the vector (arithmetic is fp64)
 __device__ inline void rot_at(const GridDev& g, const T* F, int x, int y, int z, double& rx, double& ry, double& rz)
 {
-  const double ix = 1.0 / g.dx, iy = 1.0 / g.dy, iz = 1.0 / g.dz;
+  const double ix = g.inv[0], iy = g.inv[1], iz = g.inv[2]; // 1 / d, formed once on the host (the same quotient)
   const T* Fx = F;
   const T* Fy = F + g.cstride;
   const T* Fz = F + 2 * g.cstride;
@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(kBlock) k_rot(GridDev g, double alpha, const d
 template <class T = double>
 __device__ inline void matM_at(const GridDev& g, const T* F, int x, int y, int z, double& mx, double& my, double& mz)
 {
-  const double ix = 1.0 / g.dx, iy = 1.0 / g.dy, iz = 1.0 / g.dz;
+  const double ix = g.inv[0], iy = g.inv[1], iz = g.inv[2]; // 1 / d, formed once on the host (the same quotient)
   double ax, ay, az; // rot+ at (x,y,z)
   double bx, by, bz; // rot+ at (x-1,y,z)
   double cx, cy, cz; // rot+ at (x,y-1,z)
@@ -398,7 +398,7 @@ template <int C>
 __device__ __forceinline__ double matM_comp(const GridDev& g, const double* __restrict__ F, int x, int y, int z)
 {
   constexpr int A = (C + 1) % 3, B = (C + 2) % 3;
-  const double ih[3] = {1.0 / g.dx, 1.0 / g.dy, 1.0 / g.dz};
+  const double ih[3] = {g.inv[0], g.inv[1], g.inv[2]}; // 1 / d, formed once on the host (the same quotient)
   auto at = [&](int comp, int ox, int oy, int oz) { return F[comp * g.cstride + g.nodew(x + ox, y + oy, z + oz)]; };
   auto sh = [&](int axis, int s, int& ox, int& oy, int& oz) { (axis == 0 ? ox : (axis == 1 ? oy : oz)) += s; };
   // G_comp at offset (ox,oy,oz): forward differences
@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(kRowX* kRowY, 4) k_matA(GridDev g, const doubl
 // then |.|_1 and |.|_2^2 partials of that scalar
 __global__ void __launch_bounds__(kBlock) k_div_neg_add(GridDev g, const double* __restrict__ v, double* out)
 {
-  const double ix = 1.0 / g.dx, iy = 1.0 / g.dy, iz = 1.0 / g.dz;
+  const double ix = g.inv[0], iy = g.inv[1], iz = g.inv[2]; // 1 / d, formed once on the host (the same quotient)
   const long stride = (long)gridDim.x * kBlock;
   for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < g.nown; i += stride) {
     int x = (int)(i % g.nx), y = (int)((i / g.nx) % g.ny), z = (int)(i / g.plane);
