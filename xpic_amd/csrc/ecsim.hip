@@ -90,6 +90,10 @@ constexpr int kOffAB = 24; // [24, 33): A_p*matB row-major, [33, 36): I_p
 constexpr int kStage = kCP * kPitch;
 constexpr int kAcc = 36;          // accumulators per lane: 30 matL (component pair x octant bits of the pair) + 6 currI
 typedef double mfma_acc __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const char* LdsBytes; // LDS addresses are 32 bits: say so where address arithmetic is hot
+typedef __attribute__((address_space(3))) double LdsDouble;
+typedef double dpair __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) dpair LdsDouble2;
 constexpr int kMatLines = 816;    // distinct (c1, row dy, row dz, k) streams one pencil can touch
 constexpr int kCurLines = 16;     // (c, dy, dz) streams of currI
 constexpr int kLines = kMatLines + kCurLines;
@@ -176,7 +180,9 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
   __shared__ unsigned short dsc[FILL_LEAN_LDS ? 1 : kAcc * 64]; // offset (in doubles) of lane's element of accumulator e inside the merge window
   __shared__ int cstart[kMaxNxLds + 2];
   __shared__ double bnb[kW][54];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // the wave index is the same for all lanes: say so (readfirstlane), or the compiler treats every branch and count that
+  // depends on it (active, cnt, lastpass, the K-step loops) as divergent and guards them with exec masks and VALU compares
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   double* st = sh + wave * kStage;
   const double dt = g.dt;
 
@@ -189,7 +195,8 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
   const int kk = lane >> 4, qb = (lane >> 2) & 3, qj = lane & 3;
   const int offA = qj * 2 + (qb >> 1);                   // + c1 * 8: row weights s[c1][i = qj][h1]
   const int offB = qj * 2 + (qb & 1);                    // + c2 * 8: column weights s[c2][j = qj][h2]
-  const bool cur1_lane = qj == 0, cur2_lane = qj == 0 && qb < 2;
+  const int offI18 = 8 * (kOffAB + 9 + (qb >> 1));       // byte offset of I_p[X] for the blocks (X, h), of I_p[Y] for (Y, h)
+  const int offA8 = 8 * offA, offB8 = 8 * offB;
 
   if (!FILL_LEAN_LDS)
     for (int i = threadIdx.x; i < kAcc * 64; i += kThreads) dsc[i] = dtab[i];
@@ -280,15 +287,16 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
   unsigned long long stamp_t_ = __builtin_readcyclecounter();
   unsigned long long stamp_acc_[9] = {};
 #endif
+  // the cell block of this wave: zeroed here and again right behind the merge that consumes it (zeroing at the top of
+  // the chunk made the compiler clear all 36 twice: once for the path around the pass loop and once in front of it)
+  double acc[kAcc];
+#pragma unroll
+  for (int e = 0; e < kAcc; ++e) acc[e] = 0.0;
   const int nch = (g.nx + kW - 1) / kW;
   for (int j = 0; j < nch; ++j) {
     STAMP(0);
     const int i = j * kW + wave;
-    const bool active = i < g.nx;
-
-    double acc[kAcc];
-#pragma unroll
-    for (int e = 0; e < kAcc; ++e) acc[e] = 0.0;
+    const bool active = FX || i < g.nx; // full chunks: every wave has a cell
 
     if (active) {
       const int start = pf.start, cnt = pf.cnt;
@@ -409,27 +417,35 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
           const int no = ocnt[o];
           const double* seg = st + ooff[o] * kPitch;
           const int nst = lastpass ? (no + 3) >> 2 : no >> 2;
-          for (int t = 0; t < nst; ++t) {
-            const int r = 4 * t + kk;
-            const double* sp = r < no ? seg + r * kPitch : zslot;
+          // 32-bit LDS addresses: the lane's read positions inside a slot are fixed byte offsets, a step moves 4 slots on,
+          // and "is there a particle for my row" is one compare of the lane's slot address with the end of the segment
+          LdsBytes spr = (LdsBytes)(const char*)(seg + kk * kPitch);
+          const LdsBytes seg_end = (LdsBytes)(const char*)(seg + no * kPitch);
+          for (int t = 0; t < nst; ++t, spr += 4 * kPitch * 8) {
+            const LdsBytes sb = spr < seg_end ? spr : (LdsBytes)(const char*)zslot;
+            const LdsDouble* sp = (const LdsDouble*)sb;
+            const LdsDouble* spA = (const LdsDouble*)(sb + offA8);
+            const LdsDouble* spB = (const LdsDouble*)(sb + offB8);
             double a[3], b[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { a[c] = sp[c * 8 + offA]; b[c] = sp[c * 8 + offB]; }
-            // the step's 9 A_p*matB and 3 I_p per particle: the same 96 bytes for the 16 lanes of a particle (a DPP row
+            for (int c = 0; c < 3; ++c) { a[c] = spA[c * 8]; b[c] = spB[c * 8]; }
+            // the step's 9 A_p*matB per particle: the same 72 bytes for the 16 lanes of a particle (a DPP row
             // broadcast of one 8-byte read per lane was measured 6 % slower: the VALU is the scarcer resource here)
-            const double2* u = (const double2*)(sp + kOffAB);
-            const double2 u0 = u[0], u1 = u[1], u2 = u[2], u3 = u[3], u4 = u[4], u5 = u[5];
-            const double ab[9] = {u0.x, u0.y, u1.x, u1.y, u2.x, u2.y, u3.x, u3.y, u4.x};
+            const LdsDouble2* u = (const LdsDouble2*)(sp + kOffAB);
+            const dpair u0 = u[0], u1 = u[1], u2 = u[2], u3 = u[3];
+            const double ab[9] = {u0.x, u0.y, u1.x, u1.y, u2.x, u2.y, u3.x, u3.y, sp[kOffAB + 8]};
             // the nine column operands first, then the matrix instructions back to back: a product issued between two
             // MFMAs waits for the fp64 pipe to drain and the next MFMA waits for the product
             double bm[9];
 #pragma unroll
             for (int e = 0; e < 9; ++e) bm[e] = b[e % 3] * ab[e];
             // currI operands: block b of instruction 1 is (X or Y, h = b & 1), of instruction 2 (Z, h = b & 1): their
-            // row weights are column weights already loaded; the multiplier I_p[c] sits in column j = 0
+            // row weights are column weights already loaded.  The multiplier I_p[c] belongs in column j = 0 only, but a
+            // column j of D depends on column j of the B operand alone and the columns j != 0 of these two accumulators
+            // (and the blocks 2, 3 of the second) have no target in the merge (they go to the lane's dummy double): every
+            // lane passes I_p[c], read at a lane-dependent offset, and nothing has to be selected or zeroed
             const double ai1 = qb < 2 ? b[0] : b[1], ai2 = b[2];
-            const double ip01 = qb < 2 ? u4.y : u5.x;
-            const double bi1 = cur1_lane ? ip01 : 0.0, bi2 = cur2_lane ? u5.y : 0.0;
+            const double bi1 = *(const LdsDouble*)(sb + offI18), bi2 = sp[kOffAB + 11];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c1 = 0; c1 < 3; ++c1)
@@ -501,7 +517,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
         const unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
         for (int h = 0; h < 8; ++h)
-          if (k * 8 + h < kAcc) wdst[k * 8 + h] = (w[h >> 1] >> (16 * (h & 1))) & 0xffffu;
+          if (k * 8 + h < kAcc) wdst[k * 8 + h] = (w[h >> 1] >> (16 * (h & 1))) & 0xffffu; // byte offset
       }
     }
     else {
@@ -528,9 +544,12 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
       // row node x of cell (unwrapped) u = i+1 with offset o is column u+o; window column 0 is kW*j: the lane's element
       // of accumulator e goes to window byte wdst[e] (+ 8 * wave); elements without a target (currI instructions,
       // idle blocks) add into a per-lane dummy double behind the window.  No branches, no waits between the atomics.
-      double* wv = win + wave;
+      char* wv = (char*)(win + wave);
 #pragma unroll
-      for (int e = 0; e < kAcc; ++e) unsafeAtomicAdd(wv + wdst[e], acc[e]);
+      for (int e = 0; e < kAcc; ++e) {
+        unsafeAtomicAdd((double*)(wv + (FILL_LEAN_LDS ? wdst[e] : 8 * wdst[e])), acc[e]);
+        acc[e] = 0.0;
+      }
     }
     lds_barrier();
     STAMP(6);
@@ -701,10 +720,11 @@ int build_ltab(xpic_ctx* c)
       for (int c2 = 0; c2 < 3; ++c2) seen[acc_main(c1, c2, o)] = 1;
   }
   static_assert((kLines * kSlots + 64) <= kW * kStage, "the dummy doubles must lie inside the stage area");
-  if (FILL_LEAN_LDS) { // [lane][kDtabPitch] instead of [e][64]
+  if (FILL_LEAN_LDS) { // [lane][kDtabPitch] instead of [e][64], and BYTE offsets (one add per atomic in the kernel)
+    static_assert((kLines * kSlots + 64 + kW) * 8 <= 0xffff, "window byte offsets must fit 16 bits");
     std::vector<unsigned short> t(64 * kDtabPitch, 0);
     for (int e = 0; e < kAcc; ++e)
-      for (int lane = 0; lane < 64; ++lane) t[lane * kDtabPitch + e] = dtab[e * 64 + lane];
+      for (int lane = 0; lane < 64; ++lane) t[lane * kDtabPitch + e] = (unsigned short)(8 * dtab[e * 64 + lane]);
     dtab.swap(t);
   }
   const size_t total = linetab.size() + cowr.size() + (dtab.size() + 1) / 2;
