@@ -32,6 +32,10 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", type=int, default=None, help="cells per axis (default 256; 128 for the side schemes)")
+    ap.add_argument("--grid-xyz", type=int, nargs=3, default=None, metavar=("NX", "NY", "NZ"),
+                    help="non-cubic box, e.g. 512 512 64 = one GPU's slab of BASELINE configs[4] (overrides --grid)")
+    ap.add_argument("--rank-timeout", type=float, default=1500.0,
+                    help="wall-clock limit (s) of a --gpus N run started by this launcher: on expiry the ranks are stopped")
     ap.add_argument("--ppc", type=int, default=None, help="particles per cell (default 64; 32 for the side schemes)")
     ap.add_argument("--dx", type=float, default=0.5)
     ap.add_argument("--dt", type=float, default=None, help="default 1.0 (ecsim, ecsimcorr), 0.1 (basic: explicit, CFL)")
@@ -57,6 +61,7 @@ def parse_args(argv=None):
         args.ppc = 32 if side else 64
     if args.dt is None:
         args.dt = 0.1 if args.scheme == "basic" else 1.0
+    args.n3 = tuple(args.grid_xyz) if args.grid_xyz else (args.grid,) * 3
     return args
 
 
@@ -65,43 +70,116 @@ def parse_args(argv=None):
 # waits; it never initialises the GPU and never execs.  Mirrors `mpiexec -np N ... -da_processors_z N`
 # (tests/ecsim/CMakeLists.txt:15-17 of the reference).
 # ---------------------------------------------------------------------------------------------------------
+def count_gpus():
+    """Number of GPU agents of this machine WITHOUT loading the HIP runtime in this process: the KFD topology in sysfs
+    (a node with simd_count > 0 is a GPU), narrowed by HIP_/ROCR_VISIBLE_DEVICES.  Falls back to a short-lived child that
+    asks torch (the child may initialise HIP; the launcher itself must not: its children are fresh processes, but a parent
+    holding a HIP context would sit on the card next to them)."""
+    n = None
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        n = 0
+        for node in os.listdir(base):
+            for line in open(os.path.join(base, node, "properties")):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+    except (OSError, ValueError):
+        n = None
+    if n is None:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
+                             text=True, timeout=300)
+        n = int(out.stdout.strip() or 0) if out.returncode == 0 else 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if os.environ.get(var, "") != "":
+            n = min(n, len([x for x in os.environ[var].split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(args, argv):
-    import torch
+    import signal
+    import tempfile
 
     n = args.gpus
     rehearsal = os.environ.get("XPIC_BENCH_COMM", "rccl") == "gloo"
-    ndev = torch.cuda.device_count()
+    ndev = count_gpus()
     need = 1 if rehearsal else n
     if ndev < need:
         print(f"bench.py --gpus {n}: needs {need} MI355X device(s), found {ndev}; the xpic HIP path has no CPU "
               f"fallback and will not run fewer ranks than asked", file=sys.stderr, flush=True)
         return 3
-    if args.grid % n or args.grid // n < 6:
-        print(f"bench.py --gpus {n}: the {args.grid}^3 box cannot be cut into {n} z-slabs of >= 6 planes",
+    nz = args.n3[2]
+    if nz % n or nz // n < 6:
+        print(f"bench.py --gpus {n}: the {args.n3[0]} x {args.n3[1]} x {nz} box cannot be cut into {n} z-slabs of >= 6 planes",
               file=sys.stderr, flush=True)
         return 3
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    # rendezvous through a file in a private directory: no port to pick, free and hand over (bind/close/reuse is a race)
+    rdv = tempfile.mkdtemp(prefix="xpic_bench_")
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   XPIC_BENCH_RDV=os.path.join(rdv, "store"))
+        env.pop("MASTER_PORT", None)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+
+    def stop_all(grace=10.0):
+        """terminate our own children (exact PIDs), give them `grace` seconds, then kill what is left"""
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        t_end = time.monotonic() + grace
+        for q in procs:
+            try:
+                q.wait(timeout=max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                q.kill()
+        for q in procs:
+            try:
+                q.wait(timeout=5.0)
+            except subprocess.TimeoutExpired:
+                pass
+
+    stopping = []
+
+    def on_signal(signum, frame):
+        stopping.append(signum)
+
+    old_handlers = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGINT, signal.SIGTERM)}
     rc = 0
-    live = set(range(n))
-    while live:
-        for r in sorted(live):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            live.discard(r)
-            if code != 0 and rc == 0:
-                rc = code if code > 0 else 1
+    deadline = time.monotonic() + args.rank_timeout
+    try:
+        while any(q.poll() is None for q in procs):
+            if stopping:
+                print(f"bench.py: signal {stopping[0]}: stopping the ranks", file=sys.stderr, flush=True)
+                stop_all()
+                rc = 128 + stopping[0]
+                break
+            if time.monotonic() > deadline:
+                print(f"bench.py: the {n} ranks did not finish within {args.rank_timeout:.0f} s (a rank stuck in a "
+                      f"collective?): stopping them", file=sys.stderr, flush=True)
+                stop_all()
+                rc = 124
+                break
+            bad = [(r, q.returncode) for r, q in enumerate(procs) if q.poll() is not None and q.returncode != 0]
+            if bad:
+                r, code = bad[0]
                 print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
-                for q in live:
-                    procs[q].terminate()  # exact PIDs of our own children
-        time.sleep(0.2)
+                stop_all()
+                rc = code if code > 0 else 1
+                break
+            time.sleep(0.2)
+        else:
+            bad = [q.returncode for q in procs if q.returncode != 0]
+            rc = 0 if not bad else (bad[0] if bad[0] > 0 else 1)
+    finally:
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
+        try:
+            for f in os.listdir(rdv):
+                os.unlink(os.path.join(rdv, f))
+            os.rmdir(rdv)
+        except OSError:
+            pass
     return rc
 
 
@@ -117,15 +195,18 @@ def cpu_baseline(args):
     ppc = args.ppc
     threads = oracle_lib.default_threads()
     o = oracle_lib.OracleSim(args.scheme, (n, n, n), (args.dx,) * 3, args.dt)
-    s = o.add_sort(ppc, 1.0, -1.0, 1.0)
     rng = np.random.default_rng(1)
-    npart = ppc * n ** 3
-    pts = np.empty((npart, 6))
-    pts[:, :3] = rng.random((npart, 3)) * (n * args.dx)
-    v = rng.normal(0, args.vth, (npart, 3))
-    pts[:, 3:] = v / np.sqrt(1.0 + (v * v).sum(1, keepdims=True))
-    o.add_particles(s, pts)
-    del pts, v
+    npart = 0
+    for (Np, dens, q, m) in species(args):
+        s = o.add_sort(Np, dens, q, m)
+        k = Np * n ** 3
+        pts = np.empty((k, 6))
+        pts[:, :3] = rng.random((k, 3)) * (n * args.dx)
+        v = rng.normal(0, args.vth, (k, 3))
+        pts[:, 3:] = v / np.sqrt(1.0 + (v * v).sum(1, keepdims=True))
+        o.add_particles(s, pts)
+        npart += k
+        del pts, v
     B = np.zeros(o.fshape())
     B[..., 2] = args.b0
     o.set_field("B", B)
@@ -142,7 +223,13 @@ def cpu_baseline(args):
     return {
         "value": npart * nsteps / dt,
         "unit": "particles/s",
-        "cores": threads,
+        "cores": threads,  # OpenMP threads actually used = the CPUs this process has (affinity mask and cgroup quota)
+        "host_logical_cpus": os.cpu_count(), "affinity_cpus": oracle_lib.affinity_cpus(),
+        "cgroup_cpus": oracle_lib.cgroup_cpus(),
+        "threads_capped_by": "XPIC_ORACLE_THREADS" if os.environ.get("XPIC_ORACLE_THREADS") else
+                             ("cgroup quota / affinity mask" if oracle_lib.cgroup_cpus() is not None or
+                              oracle_lib.affinity_cpus() <= 2 * oracle_lib.POOL_CPU_SHARE else
+                              f"pool CPU share of a one-GPU box ({oracle_lib.POOL_CPU_SHARE}): the affinity mask shows the whole host"),
         "kind": "port",
         "sample": f"oracle {args.scheme} step, {n}^3 cells x {ppc} ppc ({npart} particles), {nsteps} steps, "
                   f"{its} Krylov iterations ({solver}), {dt:.1f} s on {threads} OpenMP threads",
@@ -152,19 +239,39 @@ def cpu_baseline(args):
     }
 
 
-def pmc_traffic(scheme, grid, kernel):
-    """HBM bytes per launch of `kernel` from this round's committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    separate passes, KiB units, FETCH_SIZE x 2 on gfx950 -- tools/pmc_summary.py); valid only for the grid and scheme
-    the file was taken on."""
-    name = {"ecsim": "r02_pmc_traffic_256.txt", "basic": "r02_pmc_traffic_basic_128.txt",
-            "ecsimcorr": "r02_pmc_traffic_ecsimcorr_128.txt"}[scheme]
-    path = os.path.join(ROOT, "profiles", name)
-    if grid != (256 if scheme == "ecsim" else 128) or not os.path.exists(path):
+def species(args):
+    """(Np, n, q, m) of the species the workload loads.  basic = BASELINE configs[1], the two-stream set-up: two electron
+    species of ppc / 2 each (SURVEY 8d Config 2; the reference's config surface has no drift, so both are thermal)."""
+    if args.scheme == "basic" and args.ppc % 2 == 0:
+        return [(args.ppc // 2, 0.5, -1.0, 1.0), (args.ppc // 2, 0.5, -1.0, 1.0)]
+    return [(args.ppc, 1.0, -1.0, 1.0)]
+
+
+PMC_FILES = {"ecsim": "pmc_traffic_256.txt", "basic": "pmc_traffic_basic_128.txt", "ecsimcorr": "pmc_traffic_ecsimcorr_128.txt"}
+
+
+def pmc_traffic(scheme, n3, kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate passes, KiB units, FETCH_SIZE x 2 on gfx950 -- tools/pmc_summary.py).  The file carries the hash of the
+    kernel sources it was taken on (`# csrc-hash`): quoted only for that grid and scheme AND while xpic_amd/csrc still
+    hashes to the same value; otherwise null (counters are not collected inside this run)."""
+    import glob
+
+    from xpic_amd import csrc_hash
+
+    want = 256 if scheme == "ecsim" else 128
+    if tuple(n3) != (want,) * 3:
         return None
-    for line in open(path):
-        if line.startswith(kernel):
-            return float(line.split()[-2]) * 1e9
-    return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_" + PMC_FILES[scheme])))
+    if not files:
+        return None
+    stamp, val = None, None
+    for line in open(files[-1]):
+        if line.startswith("# csrc-hash"):
+            stamp = line.split()[2]
+        elif line.startswith(kernel) and val is None:
+            val = float(line.split()[-2]) * 1e9
+    return val if stamp == csrc_hash() else None
 
 
 def main():
@@ -193,17 +300,22 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        rdv = os.environ.get("XPIC_BENCH_RDV")  # set by launch_ranks: file rendezvous; under torch.distributed.run: env://
+        kw = dict(init_method="file://" + rdv) if rdv else {}
         if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, **kw)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), **kw)
 
     import numpy as np
     import xpic_amd as X
 
-    n = args.grid
+    n3 = args.n3
+    n = n3[0]
+    cubic = n3[0] == n3[1] == n3[2]
+    gname = f"{n}^3" if cubic else f"{n3[0]} x {n3[1]} x {n3[2]}"
     # N > 1: the SAME global grid, cut into z-slabs (BASELINE.json configs[3]); one slab, one process, one GPU
-    ctx = X.Context(args.scheme, (n, n, n), (args.dx,) * 3, args.dt, device=local_rank, rank=rank, nranks=world)
+    ctx = X.Context(args.scheme, n3, (args.dx,) * 3, args.dt, device=local_rank, rank=rank, nranks=world)
     if world > 1:
         from xpic_amd.parallel import GlooRing, init_rccl
 
@@ -216,8 +328,11 @@ def main():
         raise SystemExit(f"the communicator holds {comm_ranks} ranks, expected {world}")
     N = ctx.N  # local cells
     npart = args.ppc * N
-    s = ctx.add_sort(args.ppc, 1.0, -1.0, 1.0, capacity=int(npart * 1.02) + 1024)
-    ctx.fill_synthetic(s, args.ppc, args.vth, seed=1234 + rank, regular=args.loader == "regular")
+    sorts = []
+    for k, (Np, dens, q, m) in enumerate(species(args)):
+        s = ctx.add_sort(Np, dens, q, m, capacity=int(Np * N * 1.02) + 1024)
+        ctx.fill_synthetic(s, Np, args.vth, seed=1234 + rank + 7919 * k, regular=args.loader == "regular")
+        sorts.append(s)
 
     # SetMagneticField(SetUniformField): B = B0 = (0, 0, b0)
     B = np.zeros(ctx.fshape())
@@ -264,7 +379,8 @@ def main():
         # BASELINE.json configs[1] asks for "Poisson CG": the reference has no Poisson solve; its SPD operator is
         # matM = 2 I + 0.5 dt^2 rot- rot+ (Config 2) -> CG on matM with a manufactured right-hand side
         rng = np.random.default_rng(7)
-        kctx = X.Context("ecsim", (n, n, n), (args.dx,) * 3, args.dt, device=local_rank)  # owns the Krylov workspace
+        kctx = X.Context("ecsim", n3, (args.dx,) * 3, args.dt, device=local_rank)  # owns the Krylov workspace
+        kctx.set_preconditioner(0)  # CG is unpreconditioned: no flexible-GMRES workspace
         kctx.set_field(X.W0, rng.normal(0.0, 1.0, kctx.fshape()))
         kctx.solve(X.OP_MATM_CG, X.W0, X.W1, 1e-10, 1e-50, 500)
         kctx.synchronize()
@@ -282,8 +398,9 @@ def main():
     prof = {k: ctx.profile_get(k) for k in ("matA_apply", "solve_matA", "fill_current", "move_bin", "scatter",
                                             "second_push", "mdot", "maxpy", "matL_zero", "scan", "rot_apply",
                                             "halo", "migrate", "matL_ghost_rows", "basic_push", "corr_first_push",
-                                            "corr_second_push", "solve_matM", "precond", "matL_apply", "rebin")}
-    count_local = ctx.count(s)
+                                            "corr_second_push", "solve_matM", "precond", "matL_apply", "rebin",
+                                            "allreduce")}
+    count_local = sum(ctx.count(s) for s in sorts)
     count = count_local
     if world > 1:
         ct = torch.tensor([count], dtype=torch.float64, device=red_dev)
@@ -295,11 +412,12 @@ def main():
                 "basic": "particles pushed/sec (basic full step: Boris + Esirkepov + FDTD)",
                 "ecsimcorr": "particles pushed/sec (ecsimcorr full step) + KSP iters/sec"}[args.scheme]
     workload = {
-        "ecsim": f"3D ECSIM electromagnetic, {n}^3 cells, {args.ppc} ppc, 1 electron species, GMRES(30) on matL+matM "
+        "ecsim": f"3D ECSIM electromagnetic, {gname} cells, {args.ppc} ppc, 1 electron species, GMRES(30) on matL+matM "
                  f"rtol=atol=1e-7 (BASELINE.json configs[2])",
-        "basic": f"3D explicit (basic) scheme, {n}^3 cells, {args.ppc} ppc, Boris push + Esirkepov deposit + FDTD, "
-                 f"and CG on matM as the SPD solve (BASELINE.json configs[1]; side measurement)",
-        "ecsimcorr": f"3D ecsimcorr charge-conserving scheme, {n}^3 cells, {args.ppc} ppc, two Esirkepov deposits + two "
+        "basic": f"3D explicit (basic) scheme, {gname} cells, {len(sorts)} electron species x {args.ppc // len(sorts)} ppc "
+                 f"(two-stream set-up), Boris push + Esirkepov deposit + FDTD, and CG on matM as the SPD solve "
+                 f"(BASELINE.json configs[1]; side measurement)",
+        "ecsimcorr": f"3D ecsimcorr charge-conserving scheme, {gname} cells, {args.ppc} ppc, two Esirkepov deposits + two "
                      f"solves per step (one GPU's share of BASELINE.json configs[4]; side measurement)",
     }[args.scheme]
     ms_solve = prof["solve_matA"][1] + prof["solve_matM"][1]
@@ -318,11 +436,11 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": workload,
-            "grid": [n, n, n], "ppc": args.ppc, "particles_per_gpu": npart, "dx": args.dx, "dt": args.dt,
+            "grid": list(n3), "ppc": args.ppc, "species": len(sorts), "particles_per_gpu": npart, "dx": args.dx, "dt": args.dt,
             "loader": "uniform over the box (Poisson cell occupancy, as CoordinateInBox)" if args.loader == "poisson"
                       else "exactly ppc particles in every cell",
             "parallelism": "1 GPU" if world == 1 else
-                           f"{world} z-slabs of {n // world} planes, RCCL halo / migration / dot all-reduce over xGMI"
+                           f"{world} z-slabs of {n3[2] // world} planes, RCCL halo / migration / dot all-reduce over xGMI"
                            + (" [gloo rehearsal: all ranks share one GPU]" if rehearsal else ""),
         },
         "ksp_iters_per_s": its_total / world / (ms_solve * 1e-3) if ms_solve else None,  # iterations are global
@@ -330,7 +448,8 @@ def main():
                       ("flexible GMRES(30), right-preconditioned by a Chebyshev polynomial in matM on fp32 work vectors (outer iterations; each = 1 matA "
                        "apply + the polynomial's matM applies)" if not args.plain_gmres else "GMRES(30), no preconditioner"),
         "ksp_iterations_per_step": its_total / world / args.steps,
-        "phase_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},
+        "phase_ms_per_step": {k: v[1] / args.steps for k, v in prof.items() if k != "allreduce"},
+        "allreduces_per_step": prof["allreduce"][0] / args.steps,  # reductions that are all-reduces on slabs (counted on 1 GPU too)
         "device_copy_GBps": copy_rate / 1e9 if copy_rate else None,
         "cg_matM": cg_line,
     }
@@ -349,7 +468,7 @@ def main():
         fill = {
             "kernel": "k_ecsim_fill (mass matrix + currI; one colour launch)", "bound": "mfma",
             "achieved": tf, "peak": FP64_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TF,
-            "traffic": pmc_traffic(args.scheme, n, "k_ecsim_fill") if world == 1 else None,
+            "traffic": pmc_traffic(args.scheme, n3, "k_ecsim_fill") if world == 1 else None,
             "flop_per_particle": FILL_FLOP_PER_PARTICLE, "flop_per_launch": flop_launch,
             "launches": n_fill, "launches_per_step": launches_per_step, "avg_ms": avg_ms,
             "ms_per_assembly": ms_fill / args.steps,
@@ -365,7 +484,7 @@ def main():
         spmv = {
             "kernel": "k_matA (matL+matM SpMV)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(args.scheme, n, "k_matA<true, true>") if world == 1 else None,
+            "traffic": pmc_traffic(args.scheme, n3, "k_matA<true, true>") if world == 1 else None,
             "bytes_per_launch": bytes_apply, "launches": n_apply, "avg_ms": ms_apply / n_apply,
         }
     esk = {}
@@ -377,13 +496,13 @@ def main():
             continue
         # R 48 + W 48 B per particle (first_push of ecsimcorr writes positions only: W 24) + the E/B
         # read and J write of a cell, once per cell
-        bytes_launch = bpp * count_local + bpc * N
+        bytes_launch = bpp * count_local / len(sorts) + bpc * N  # one launch per species
         gbs = bytes_launch / (ms / nl * 1e-3) / 1e9
         esk[key] = {
             "kernel": f"{kern}, ...> ({key})", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(args.scheme, n, kern) if world == 1 else None,
+            "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(args.scheme, n3, kern) if world == 1 else None,
             "bytes_per_launch": bytes_launch, "bytes_per_particle": bpp, "launches": nl, "avg_ms": ms / nl,
-            "particles_per_s": count_local / (ms / nl * 1e-3),
+            "particles_per_s": count_local / len(sorts) / (ms / nl * 1e-3),
         }
     if args.scheme == "ecsim":
         line["roofline"] = fill

@@ -157,6 +157,10 @@ int xpic_set_tolerances(xpic_ctx* ctx, double rtol, double atol, int maxit);
  * P v_j stored): the result does not depend on how exactly P is applied, only the iteration count could.
  * degree <= 0 keeps the automatic choice.  The stopping rule of xpic_solve is unchanged: true residual norm. */
 int xpic_set_preconditioner(xpic_ctx* ctx, int kind, int degree);
+/* MatMult on a z-slab with neighbours: on = 1 (default) posts the ghost exchange of the operand (VecScatterBegin), applies
+ * the rows of the interior planes meanwhile and the rows of the boundary planes after it (VecScatterEnd), as PETSc's
+ * MPIAIJ MatMult does (the reference's KSPSolve, src/impls/ecsim/simulation.cpp:266); on = 0 exchanges first. Same result. */
+int xpic_set_overlap(xpic_ctx* ctx, int on);
 
 /* timestep_implementation of the context's scheme (basic/simulation.cpp:30-43, ecsim/simulation.cpp:145-155,
  * ecsimcorr/simulation.cpp:21-32); *ksp_iterations = Krylov iterations spent in this step */

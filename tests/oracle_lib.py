@@ -32,12 +32,48 @@ def build():
 _lib = None
 
 
-def default_threads():
+def affinity_cpus():
+    """logical CPUs this process may run on"""
     try:
-        n = len(os.sched_getaffinity(0))
+        return len(os.sched_getaffinity(0))
     except AttributeError:
-        n = os.cpu_count() or 1
-    return max(1, min(n, int(os.environ.get("XPIC_ORACLE_THREADS", "16"))))
+        return os.cpu_count() or 1
+
+
+def cgroup_cpus():
+    """CPU quota of this process's cgroup (cgroup v2 cpu.max / v1 cfs quota), or None when there is none"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, -(-int(q) // int(per)))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, -(-q // per))
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+POOL_CPU_SHARE = 16  # CPU share of a one-GPU box of the pool when neither the affinity mask nor a cgroup quota says so
+
+
+def default_threads():
+    """OpenMP team of the oracle = the CPUs this process really has: min(affinity mask, cgroup quota).  The GPU box shows
+    every logical CPU of the host in its affinity mask while its share is a fraction of them (an oversubscribed team makes
+    the thousands of small parallel regions of the oracle's GMRES crawl): without a quota to read, a mask wider than
+    2 x POOL_CPU_SHARE is cut to POOL_CPU_SHARE.  XPIC_ORACLE_THREADS overrides all of it."""
+    cap = os.environ.get("XPIC_ORACLE_THREADS")
+    if cap:
+        return max(1, int(cap))
+    n = affinity_cpus()
+    q = cgroup_cpus()
+    if q is not None:
+        return max(1, min(n, q))
+    return n if n <= 2 * POOL_CPU_SHARE else POOL_CPU_SHARE
 
 
 def lib():

@@ -46,9 +46,39 @@ def test_launcher_does_not_touch_the_gpu_or_exec():
     sys.path.insert(0, ROOT)
     import bench
 
-    src = inspect.getsource(bench.launch_ranks)
+    src = inspect.getsource(bench.launch_ranks) + inspect.getsource(bench.count_gpus)
     assert "is_available" not in src and "set_device" not in src and "os.exec" not in src and "Context(" not in src
-    assert "device_count" in src and "Popen" in src
+    assert "import torch\n" not in src  # the HIP runtime is never loaded by the launcher itself
+    assert "Popen" in src and "kill()" in src and "rank_timeout" in src
+    # the launcher process must really stay off the GPU runtime: counting devices loads neither torch nor libamdhip64
+    code = ("import sys; sys.path.insert(0, %r); import bench; n = bench.count_gpus(); "
+            "maps = open('/proc/self/maps').read(); "
+            "assert 'libamdhip64' not in maps and 'libtorch' not in maps, 'GPU runtime loaded'; print('gpus', n)" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("gpus"), out.stdout + out.stderr
+
+
+def test_launcher_stops_ranks_that_hang():
+    """A rank stuck in a collective must not hang the parent: on the wall-clock limit the launcher terminates (then kills)
+    the children it started and exits non-zero.  Here the 'ranks' are stand-ins that ignore SIGTERM and sleep."""
+    code = r"""
+import os, sys, time
+sys.path.insert(0, %r)
+import bench
+bench.count_gpus = lambda: 2
+hang = os.path.join(%r, 'tests', '_hang_rank.py')
+open(hang, 'w').write('import signal, time\nsignal.signal(signal.SIGTERM, signal.SIG_IGN)\ntime.sleep(600)\n')
+real_popen = bench.subprocess.Popen
+bench.subprocess.Popen = lambda cmd, env=None: real_popen([sys.executable, hang], env=env)
+args = bench.parse_args(['--gpus', '2', '--grid', '32', '--rank-timeout', '2'])
+t0 = time.time()
+rc = bench.launch_ranks(args, [])
+os.unlink(hang)
+print('rc', rc, 'after', round(time.time() - t0, 1))
+""" % (ROOT, ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rc 124" in out.stdout and "did not finish within" in out.stderr
 
 
 @pytest.mark.gpu

@@ -249,6 +249,27 @@ def test_default_step_uses_preconditioner_and_matches_oracle(oracle):
             assert np.abs(a - b).max() <= 1e-7 * np.abs(a).max()
 
 
+def test_one_reduction_per_gmres_iteration(oracle):
+    """one all-reduce per Krylov iteration.  The Gram-Schmidt dot products and w . w travel in one
+    reduction (|w - sum h_i V_i|^2 = w.w - sum h_i^2); the counter sits in comm_allreduce_sum and also counts on a
+    single slab.  Expected: 1 (|b|) + one per iteration; the explicit-norm fallback may add a few."""
+    import xpic_amd as X
+
+    n, d, dt = GRID
+    o, g = make_pair(oracle, "ecsim", n, d, 1.0, [(8, 1.0, -1.0, 1.0)], B0=(0.0, 0.0, 0.2), vth=0.03)
+    g.ecsim_fill_current()
+    for kind in (0, 1):
+        g.set_preconditioner(kind)
+        g.profile_enable(True)
+        g.profile_reset()
+        its, reason, _ = g.solve(0, X.E, X.W2, 1e-9, 1e-50, 300)
+        nred, _ = g.profile_get("allreduce")
+        g.profile_enable(False)
+        assert reason > 0 and its > 3
+        restarts = (its - 1) // 30  # each restart: one more norm
+        assert its + 1 <= nred <= its + 1 + restarts + 2, (kind, its, nred)
+
+
 def test_solve_reports_non_convergence(oracle):
     """KSPSetErrorIfNotConverged(TRUE) (ecsim/simulation.cpp:562): hitting maxit is an error."""
     import xpic_amd as X

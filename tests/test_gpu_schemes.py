@@ -125,8 +125,6 @@ def test_reference_golden_basic_ex1(oracle):
     for t in range(1, 21):
         g.step()
         assert np.abs(row(g.energy()) - gold[t, 1:]).max() < 1e-10, t
-    for name, fid in (("E", X.E), ("B", X.B)):
-        pass
     for t in range(21, 51):
         g.step()
     for name, fid in (("E", X.E), ("B", X.B)):

@@ -25,6 +25,10 @@ def load(d):
 
 
 fetch, write = load(sys.argv[1]), load(sys.argv[2])
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from xpic_amd import csrc_hash
+print("# csrc-hash %s   (bench.py quotes this file as roofline.traffic only while xpic_amd/csrc still hashes to this)" % csrc_hash())
 print("%-28s %6s %12s %12s %12s %10s" % ("kernel", "calls", "read GB", "write GB", "total GB", "avg ms"))
 for k in sorted(fetch, key=lambda k: -sum(v[1] for v in fetch[k])):
     fv, wv = fetch[k], write.get(k, [])

@@ -27,11 +27,25 @@ SYMBOLS = [
     "xpic_matL_apply", "xpic_matA_apply", "xpic_matL_get", "xpic_lstencil_decode", "xpic_ecsim_first_push",
     "xpic_update_cells", "xpic_ecsim_fill_current", "xpic_ecsim_second_push", "xpic_basic_push",
     "xpic_ecsimcorr_first_push", "xpic_ecsimcorr_second_push", "xpic_ecsimcorr_final_update",
-    "xpic_calculate_energy", "xpic_ecsimcorr_scalars", "xpic_solve", "xpic_set_tolerances", "xpic_set_preconditioner", "xpic_step",
+    "xpic_calculate_energy", "xpic_ecsimcorr_scalars", "xpic_solve", "xpic_set_tolerances", "xpic_set_preconditioner", "xpic_set_overlap", "xpic_step",
     "xpic_energy", "xpic_momentum", "xpic_charge_density", "xpic_moment_density", "xpic_cell_traversal", "xpic_implicit_esirkepov_interpolate",
     "xpic_implicit_esirkepov_decompose", "xpic_charge_collect", "xpic_charge_columns", "xpic_comm_rccl_unique_id", "xpic_comm_init_rccl", "xpic_comm_init_callbacks", "xpic_comm_size",
     "xpic_profile_enable", "xpic_profile_reset", "xpic_profile_get", "xpic_probe_copy_bandwidth",
 ]
+
+
+def csrc_hash():
+    """sha1 over the kernel sources (xpic_amd/csrc/*, sorted by name): the code version a PMC traffic file under
+    profiles/ was taken on is stamped with it, and bench.py quotes that file only while the hash still matches."""
+    import hashlib
+
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    h = hashlib.sha1()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
 
 
 class XpicError(RuntimeError):
@@ -288,6 +302,9 @@ class Context:
 
     def set_preconditioner(self, kind, degree=0):
         self._ck(self.L.xpic_set_preconditioner(self.h, int(kind), int(degree)))
+
+    def set_overlap(self, on):
+        self._ck(self.L.xpic_set_overlap(self.h, int(bool(on))))
 
     def step(self):
         its = C.c_int()

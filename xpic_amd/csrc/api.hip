@@ -61,6 +61,20 @@ static int resolve_profile(xpic_ctx* c)
 // this rank's cells contribute to)
 static size_t matL_doubles(const GridDev& g) { return (size_t)3 * g.nzp() * g.lplane(); }
 
+// the 30 preconditioned basis vectors z_j = P v_j of the flexible GMRES exist exactly while a preconditioner is
+// selected: allocated with the context, not by the first solve (every slab sizes its memory up front, the same way)
+static int ensure_flexible_workspace(xpic_ctx* c)
+{
+  if (c->precond == 0 || !c->kry_V) {
+    if (c->kry_Z) { XPIC_HIP(hipStreamSynchronize(c->stream)); XPIC_HIP(hipFree(c->kry_Z)); c->kry_Z = nullptr; }
+    return 0;
+  }
+  if (c->kry_Z) return 0;
+  XPIC_HIP(hipMalloc(&c->kry_Z, sizeof(double) * c->nvec * 30));
+  XPIC_HIP(hipMemsetAsync(c->kry_Z, 0, sizeof(double) * c->nvec * 30, c->stream));
+  return 0;
+}
+
 static bool valid_field(int f) { return f >= 0 && f < XPIC_NFIELDS; }
 
 #define CTX_CHECK(c) XPIC_CHECK((c) != nullptr, "null context")
@@ -309,6 +323,7 @@ int xpic_create(const xpic_geometry* geom, int scheme, xpic_ctx** out)
       c->cheb_degree = k < 2 ? 2 : (k > 32 ? 32 : k);
     }
     XPIC_CALL(build_ltab(c));
+    XPIC_CALL(ensure_flexible_workspace(c));
   }
   XPIC_HIP(hipStreamSynchronize(c->stream));
   *out = c;
@@ -620,6 +635,13 @@ int xpic_set_preconditioner(xpic_ctx* ctx, int kind, int degree)
   XPIC_CHECK(kind >= 0 && kind <= 2, "unknown preconditioner kind");
   ctx->precond = kind;
   if (degree > 0) ctx->cheb_degree = degree > 64 ? 64 : degree;
+  return ensure_flexible_workspace(ctx);
+}
+
+int xpic_set_overlap(xpic_ctx* ctx, int on)
+{
+  CTX_CHECK(ctx);
+  ctx->overlap = on != 0;
   return 0;
 }
 

@@ -69,6 +69,8 @@ int comm_ring(xpic_ctx* c, const void* down, size_t ndown, const void* up, size_
 int comm_allreduce_sum(xpic_ctx* c, double* dbuf, int n)
 {
   Comm& m = c->comm;
+  // every reduction that is an MPI_Allreduce on slabs is counted (on a single slab too): xpic_profile_get("allreduce")
+  if (c->profiling) c->prof["allreduce"].launches += 1;
   if (m.kind == 0 || n == 0) return 0;
   if (m.kind == 1) {
     XPIC_NCCL(ncclAllReduce(dbuf, dbuf, n, ncclDouble, ncclSum, (ncclComm_t)m.nccl, c->stream));
@@ -97,6 +99,12 @@ int comm_allreduce_sum_host(xpic_ctx* c, double* hbuf, int n)
 
 void comm_free(xpic_ctx* c)
 {
+  if (c->comm_stream) {
+    (void)hipStreamSynchronize(c->comm_stream);
+    for (int i = 0; i < 2; ++i) (void)hipEventDestroy(c->comm_ev[i]);
+    (void)hipStreamDestroy(c->comm_stream);
+    c->comm_stream = nullptr;
+  }
   if (c->comm.kind == 1 && c->comm.nccl) (void)ncclCommDestroy((ncclComm_t)c->comm.nccl);
   for (int i = 0; i < 4; ++i)
     if (c->comm.host[i]) (void)hipHostFree(c->comm.host[i]);
@@ -127,6 +135,10 @@ int xpic_comm_init_rccl(xpic_ctx* ctx, const void* id128)
   ncclComm_t nc;
   XPIC_HIP(hipSetDevice(ctx->geom.device));
   XPIC_NCCL(ncclCommInitRank(&nc, ctx->geom.nranks, id, ctx->geom.rank));
+  if (!ctx->comm_stream) {
+    XPIC_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) XPIC_HIP(hipEventCreateWithFlags(&ctx->comm_ev[i], hipEventDisableTiming));
+  }
   ctx->comm.kind = 1;
   ctx->comm.nccl = nc;
   ctx->comm.rank = ctx->geom.rank;

@@ -167,6 +167,11 @@ struct xpic_ctx {
   xpic::Comm comm;
   double* halo_buf[4] = {}; // send down, send up, recv from up, recv from down
   size_t halo_bytes = 0;
+  // overlapped operator applies (fields.hip: op_apply_overlapped): RCCL traffic of a posted halo runs on its own stream
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t comm_ev[2] = {nullptr, nullptr}; // packed (compute -> comm), ghosts in place (comm -> compute)
+  bool halo_posted = false;
+  bool overlap = true;
   bool profiling = false;
   std::map<std::string, xpic::ProfileEntry> prof;
   std::vector<hipEvent_t> event_pool;
@@ -197,12 +202,16 @@ int vec_waxpby(xpic_ctx* c, double* w, double a, const double* x, double b, cons
 int vec_scale_to(xpic_ctx* c, double* y, double a, const double* x);                 // y = a x
 int vec_dot_host(xpic_ctx* c, const double* x, const double* y, double* out);
 int vec_mdot_host(xpic_ctx* c, const double* w, const double* V, int nv, double* out); // out[i] = w . V_i
+int vec_mdot_ww_host(xpic_ctx* c, const double* w, const double* V, int nv, double* out, double* ww); // + w . w, ONE reduction
 int vec_maxpy_norm_host(xpic_ctx* c, double* w, const double* V, int nv, const double* h, double* nrm2); // w -= sum h_i V_i
+int vec_maxpy_scaled(xpic_ctx* c, const double* w, const double* V, int nv, const double* h, double* out, double scale,
+  double* nrm2); // out = (w - sum h_i V_i) * scale
 int vec_maxpy(xpic_ctx* c, double* x, const double* V, int nv, const double* y);     // x += sum y_i V_i
 int rot_apply(xpic_ctx* c, int sign, double alpha, const double* x, double* y, bool add);
 int matM_apply(xpic_ctx* c, const double* x, double* y, bool add);
 int matL_apply(xpic_ctx* c, const double* x, double* y, bool add);
 int matA_apply(xpic_ctx* c, const double* x, double* y);
+int op_apply_overlapped(xpic_ctx* c, bool with_L, double* x, double* y); // halo exchange of x beside the interior rows
 int cheb_matM_inverse(xpic_ctx* c, const double* r, double* out);
 int cg_apply_dot_host(xpic_ctx* c, const double* p, double* Ap, double* pAp);                       // Ap = matM p, p . Ap
 int cg_update_host(xpic_ctx* c, double alpha, const double* p, const double* Ap, double* x, double* r, double* rr);

@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
 #endif
         wave_sync(); // the previous pass's operand reads (and the neighbourhood store) are done
         // CIC weights and the half-cell octant first: the octant decides the particle's stage slot
-        const W1T<P2> w(g, real ? cur[0] : 0.0, real ? cur[1] : 0.0, real ? cur[2] : 0.0);
+        const W1T<P2> w(g, cur[0], cur[1], cur[2]); // lanes without a particle: garbage in, masked by oct = 8
         const int ox = w.is[0] - w.in[0] + 1, oy = w.is[1] - w.in[1] + 1, oz = w.is[2] - w.in[2] + 1;
         const int oct = real ? (ox | (oy << 1) | (oz << 2)) : 8;
         // compaction by octant: the particles of octant o take the stage slots ooff[o] .. ooff[o] + ocnt[o] - 1
@@ -347,6 +347,22 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
         }
         if (real) {
           double2* dst = (double2*)(st + slot * kPitch);
+          // The 24 values of the cell's B neighbourhood this particle's octant touches are requested FIRST (their
+          // addresses depend on the octant alone) and consumed last: the LDS latency runs under the 36 weight products
+          // and their stores instead of being waited for batch by batch in the middle of the gather.
+          const double* nb = bnb[wave];
+          double nbv[3][8];
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+              for (int ii = 0; ii < 2; ++ii) {
+                nbv[0][(k * 2 + jj) * 2 + ii] = nb[((oz + k) * 3 + (oy + jj)) * 2 + ii];
+                nbv[1][(k * 2 + jj) * 2 + ii] = nb[18 + ((oz + k) * 2 + jj) * 3 + (ox + ii)];
+                nbv[2][(k * 2 + jj) * 2 + ii] = nb[36 + (k * 3 + (oy + jj)) * 3 + (ox + ii)];
+              }
+          asm volatile("" ::: "memory"); // the reads are issued before anything below
           // the 8 weights per component (:138-140, :145-147), [i][h]: i = the 2 x 2 transverse nodes, h = lower /
           // upper node along the component's staggered axis; stored as they are formed
 #pragma unroll
@@ -364,16 +380,15 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
           // interpolate_B_s1 (ecsim/simulation.cpp:64-118) out of the cell's LDS neighbourhood, same loop
           // and product order as the global-memory gather
           double Bp[3] = {0.0, 0.0, 0.0};
-          const double* nb = bnb[wave];
 #pragma unroll
           for (int k = 0; k < 2; ++k)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
               for (int ii = 0; ii < 2; ++ii) {
-                Bp[0] += nb[((oz + k) * 3 + (oy + jj)) * 2 + ii] * (w.ws[2][k] * w.ws[1][jj] * w.wn[0][ii]);
-                Bp[1] += nb[18 + ((oz + k) * 2 + jj) * 3 + (ox + ii)] * (w.ws[2][k] * w.wn[1][jj] * w.ws[0][ii]);
-                Bp[2] += nb[36 + (k * 3 + (oy + jj)) * 3 + (ox + ii)] * (w.wn[2][k] * w.ws[1][jj] * w.ws[0][ii]);
+                Bp[0] += nbv[0][(k * 2 + jj) * 2 + ii] * (w.ws[2][k] * w.ws[1][jj] * w.wn[0][ii]);
+                Bp[1] += nbv[1][(k * 2 + jj) * 2 + ii] * (w.ws[2][k] * w.wn[1][jj] * w.ws[0][ii]);
+                Bp[2] += nbv[2][(k * 2 + jj) * 2 + ii] * (w.wn[2][k] * w.ws[1][jj] * w.ws[0][ii]);
               }
           const double bx = Bp[0] * fb, by = Bp[1] * fb, bz = Bp[2] * fb;
           const double b2 = bx * bx + by * by + bz * bz;

@@ -727,6 +727,13 @@ int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double
 {
   s.prebinned = false;
   if (pred_w_host) *pred_w_host = 0.0;
+  // rank-uniform checks first: every slab fails them alike, BEFORE anyone enters the collective below (a slab that
+  // returned from here alone would leave an empty neighbour waiting in its all-reduce)
+  const GridDev& g = c->g;
+  XPIC_CHECK(g.nx >= 6 && g.ny >= 6 && g.nzl >= 6, "the Esirkepov tile needs every grid extent >= 6");
+  const long nblocks = (long)g.ny * g.nzl; // one workgroup per x-pencil
+  XPIC_CHECK(nblocks < 2147483647L, "too many pencils for one launch");
+  XPIC_CHECK(mode != 2 || c->kry_w, "second_push needs the ecsimcorr scheme's work vectors");
   if (s.n == 0) {
     // an empty slab still takes part in the collective (pred_w and the error count)
     double red[2] = {0.0, 0.0};
@@ -738,15 +745,11 @@ int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double
     }
     return 0;
   }
-  const GridDev& g = c->g;
-  XPIC_CHECK(g.nx >= 6 && g.ny >= 6 && g.nzl >= 6, "the Esirkepov tile needs every grid extent >= 6");
   const double qm = s.par.q / s.par.m;
   const double qn_Np = s.par.q * s.par.n / s.par.Np;
   const double alpha = qn_Np / (6.0 * g.dt); // basic/particles.cpp:44, ecsimcorr/particles.cpp:130
   double* scal = c->red_out;                  // [0] pred_w, [1] bad count (as int)
   XPIC_HIP(hipMemsetAsync(scal, 0, sizeof(double) * 2, c->stream));
-  const long nblocks = (long)g.ny * g.nzl; // one workgroup per x-pencil
-  XPIC_CHECK(nblocks < 2147483647L, "too many pencils for one launch");
   const char* name = mode == 0 ? "basic_push" : (mode == 1 ? "corr_first_push" : "corr_second_push");
   {
     Timed t(c, name);
@@ -756,7 +759,6 @@ int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double
     else if (mode == 1) hipLaunchKernelGGL(ESK(1), grid, block, 0, c->stream, g, s.d, E, B, J, qm, alpha, qn_Np, scal, (int*)(scal + 1));
     else {
       // per-workgroup pred_w partials go to the (idle) Krylov work vector: one double per pencil
-      XPIC_CHECK(c->kry_w, "second_push needs the ecsimcorr scheme's work vectors");
       hipLaunchKernelGGL(ESK(2), grid, block, 0, c->stream, g, s.d, E, B, J, qm, alpha, qn_Np, c->kry_w, (int*)(scal + 1));
 #undef ESK
       hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, c->stream, c->kry_w, nblocks, scal);

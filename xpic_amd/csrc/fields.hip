@@ -76,26 +76,29 @@ __device__ inline void block_reduce_store(double (&acc)[NV], double* partial, in
 struct VPtrs { const double* p[8]; };
 struct HVals { double h[8]; };
 
-// partial[j][blk] = sum_i w[i] * V_j[i]
-template <int NV>
+// partial[j][blk] = sum_i w[i] * V_j[i];  WW: one more row, sum_i w[i]^2 (the norm of the Gram-Schmidt step comes out of the
+// same reduction: |w - sum h_j V_j|^2 = w.w - sum h_j^2 for an orthonormal V)
+template <int NV, bool WW>
 __global__ void __launch_bounds__(kBlock) k_mdot(GridDev g, const double* w, VPtrs V, double* partial)
 {
-  double acc[NV];
+  double acc[NV + (WW ? 1 : 0)];
 #pragma unroll
-  for (int j = 0; j < NV; ++j) acc[j] = 0.0;
+  for (int j = 0; j < NV + (WW ? 1 : 0); ++j) acc[j] = 0.0;
   const long off = (long)blockIdx.y * g.cstride + (long)g.G * g.plane;
   const long stride = (long)gridDim.x * kBlock;
   for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < g.nown; i += stride) {
     double wi = w[off + i];
 #pragma unroll
     for (int j = 0; j < NV; ++j) acc[j] += wi * V.p[j][off + i];
+    if (WW) acc[NV] += wi * wi;
   }
-  block_reduce_store<NV>(acc, partial, gridDim.x * gridDim.y, blockIdx.y * gridDim.x + blockIdx.x);
+  block_reduce_store<NV + (WW ? 1 : 0)>(acc, partial, gridDim.x * gridDim.y, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
-// w -= sum_j h_j V_j ; optionally partial[blk] = sum w^2 (after the update)
+// out = (w - sum_j h_j V_j) * scale (out may be w itself); optionally partial[blk] = sum out^2
 template <int NV, bool NORM>
-__global__ void __launch_bounds__(kBlock) k_maxpy(GridDev g, double* w, VPtrs V, HVals h, double* partial)
+__global__ void __launch_bounds__(kBlock) k_maxpy(GridDev g, const double* w, VPtrs V, HVals h, double* partial, double* out,
+  double scale)
 {
   double acc[1] = {0.0};
   const long off = (long)blockIdx.y * g.cstride + (long)g.G * g.plane;
@@ -104,7 +107,8 @@ __global__ void __launch_bounds__(kBlock) k_maxpy(GridDev g, double* w, VPtrs V,
     double wi = w[off + i];
 #pragma unroll
     for (int j = 0; j < NV; ++j) wi -= h.h[j] * V.p[j][off + i];
-    w[off + i] = wi;
+    wi *= scale;
+    out[off + i] = wi;
     if (NORM) acc[0] += wi * wi;
   }
   if (NORM) block_reduce_store<1>(acc, partial, gridDim.x * gridDim.y, blockIdx.y * gridDim.x + blockIdx.x);
@@ -234,12 +238,13 @@ __device__ inline void matM_at(const GridDev& g, const T* F, int x, int y, int z
   mz = 2.0 * (double)F[c0 + 2 * g.cstride] + s * rz;
 }
 
-__global__ void __launch_bounds__(kBlock) k_matM(GridDev g, const double* F, double* out, int add)
+// owned planes [z0r, z0r + nzr) (the whole slab, or its interior / boundary planes when the apply runs beside the halo exchange)
+__global__ void __launch_bounds__(kBlock) k_matM(GridDev g, const double* F, double* out, int add, int z0r, int nzr)
 {
-  const long n = g.nown;
+  const long n = (long)nzr * g.plane;
   const long stride = (long)gridDim.x * kBlock;
   for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    int x = (int)(i % g.nx), y = (int)((i / g.nx) % g.ny), z = (int)(i / g.plane);
+    int x = (int)(i % g.nx), y = (int)((i / g.nx) % g.ny), z = z0r + (int)(i / g.plane);
     double mx, my, mz;
     matM_at(g, F, x, y, z, mx, my, mz);
     const long o = g.node(x, y, g.wz(z));
@@ -421,28 +426,30 @@ constexpr int kBandY = 4; // y-chunks per band: 16 rows
 
 template <bool WITH_L, bool WITH_M>
 __global__ void __launch_bounds__(kRowX* kRowY, 4) k_matA(GridDev g, const double* __restrict__ L,
-  const double* __restrict__ X, double* __restrict__ Y, int add)
+  const double* __restrict__ X, double* __restrict__ Y, int add, int z0r, int nzr)
 {
+  // rows of the owned planes [z0r, z0r + nzr): the whole slab, or its interior / boundary planes (matA_apply_overlapped)
   // 1-D grid.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  XCD r sweeps its own
   // run of z-planes, and inside the run a band of 16 y-rows at a time along z: the operand footprint of a band
   // (20 rows x 5 planes x 3 components) stays in that XCD's 4 MiB L2 while the coefficient streams pass through.
   // Order inside a band position: component fastest (the three rows of a node share their operand footprint), x, y.
   const int nxc = (g.nx + kRowX - 1) / kRowX, nyc = (g.ny + kRowY - 1) / kRowY;
   const int nyt = (nyc + kBandY - 1) / kBandY;         // y-bands
-  const int P = (g.nzl + 7) / 8;                       // planes per XCD run
+  const int P = (nzr + 7) / 8;                         // planes per XCD run
   const int per_z = kBandY * nxc * 3, per_band = P * per_z;
   const int xcd = blockIdx.x % 8;
   const long q = blockIdx.x / 8;
   const int yt = (int)(q / per_band);
   const int rem = (int)(q % per_band);
-  const int z = xcd * P + rem / per_z;
+  const int zr = xcd * P + rem / per_z;
+  const int z = z0r + zr;
   const int rem2 = rem % per_z;
   const int c1 = rem2 % 3;
   const int x = ((rem2 / 3) % nxc) * kRowX + threadIdx.x;
   // y is the same for the 64 lanes of a wave (blockDim.x == 64): tell the compiler, so that every row base
   // below is scalar arithmetic
   const int y = (yt * kBandY + rem2 / (3 * nxc)) * kRowY + __builtin_amdgcn_readfirstlane(threadIdx.y);
-  if (yt >= nyt || z >= g.nzl) return;
+  if (yt >= nyt || zr >= nzr) return;
   if (x >= g.nx || y >= g.ny) return;
   using Seq = std::make_integer_sequence<int, kLStencil>;
   double r = 0.0;
@@ -523,24 +530,40 @@ int vec_axpby(xpic_ctx* c, double* y, double a, double b, const double* x) { ret
 int vec_waxpby(xpic_ctx* c, double* w, double a, const double* x, double b, const double* y) { return launch_ew(c, FWaxpby{w, a, x, b, y}); }
 int vec_scale_to(xpic_ctx* c, double* y, double a, const double* x) { return launch_ew(c, FScaleTo{y, a, x}); }
 
-int vec_mdot_host(xpic_ctx* c, const double* w, const double* V, int nv, double* out)
+// out[i] = w . V_i; with ww != nullptr also *ww = w . w, out of the same (single) reduction
+int vec_mdot_ww_host(xpic_ctx* c, const double* w, const double* V, int nv, double* out, double* ww)
 {
   Timed t(c, "mdot");
   dim3 grid = red_grid(c->g);
   const int nblocks = grid.x * grid.y;
   for (int j0 = 0; j0 < nv; j0 += 8) {
     int m = nv - j0 < 8 ? nv - j0 : 8;
+    const bool last = j0 + 8 >= nv && ww; // the last group carries w.w: its row lands behind the nv dot products
     VPtrs P{};
     for (int j = 0; j < m; ++j) P.p[j] = V + (long)(j0 + j) * c->nvec;
     double* part = c->red_partial + (long)j0 * nblocks;
     switch (m) {
-#define CASE(N) case N: hipLaunchKernelGGL(k_mdot<N>, grid, dim3(kBlock), 0, c->stream, c->g, w, P, part); break;
+#define CASE(N)                                                                                           \
+  case N:                                                                                                 \
+    if (last) hipLaunchKernelGGL((k_mdot<N, true>), grid, dim3(kBlock), 0, c->stream, c->g, w, P, part);  \
+    else hipLaunchKernelGGL((k_mdot<N, false>), grid, dim3(kBlock), 0, c->stream, c->g, w, P, part);      \
+    break;
       CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
     }
     XPIC_HIP(hipGetLastError());
   }
-  return finish_reduce(c, nv, nblocks, 1, out);
+  if (!ww) return finish_reduce(c, nv, nblocks, 1, out);
+  double tmp[kMaxDots + 1];
+  XPIC_CALL(finish_reduce(c, nv + 1, nblocks, 1, tmp));
+  for (int i = 0; i < nv; ++i) out[i] = tmp[i];
+  *ww = tmp[nv];
+  return 0;
+}
+
+int vec_mdot_host(xpic_ctx* c, const double* w, const double* V, int nv, double* out)
+{
+  return vec_mdot_ww_host(c, w, V, nv, out, nullptr);
 }
 
 int vec_dot_host(xpic_ctx* c, const double* x, const double* y, double* out)
@@ -548,30 +571,41 @@ int vec_dot_host(xpic_ctx* c, const double* x, const double* y, double* out)
   return vec_mdot_host(c, x, y, 1, out);
 }
 
-int vec_maxpy_norm_host(xpic_ctx* c, double* w, const double* V, int nv, const double* h, double* nrm2)
+// out = (w - sum h_i V_i) * scale; out may be w.  With nrm2 != nullptr: *nrm2 = |out|^2 (one more reduction)
+int vec_maxpy_scaled(xpic_ctx* c, const double* w, const double* V, int nv, const double* h, double* out, double scale,
+  double* nrm2)
 {
   Timed t(c, "maxpy");
   dim3 grid = red_grid(c->g);
   const int nblocks = grid.x * grid.y;
+  const double* src = w;
   for (int j0 = 0; j0 < nv; j0 += 8) {
     int m = nv - j0 < 8 ? nv - j0 : 8;
-    bool last = (j0 + 8 >= nv) && nrm2;
+    const bool lastg = j0 + 8 >= nv;
+    const bool last = lastg && nrm2;
     VPtrs P{};
     HVals H{};
     for (int j = 0; j < m; ++j) { P.p[j] = V + (long)(j0 + j) * c->nvec; H.h[j] = h[j0 + j]; }
+    const double sc = lastg ? scale : 1.0;
     switch (m) {
 #define CASE(N)                                                                                                \
   case N:                                                                                                      \
-    if (last) hipLaunchKernelGGL((k_maxpy<N, true>), grid, dim3(kBlock), 0, c->stream, c->g, w, P, H, c->red_partial); \
-    else hipLaunchKernelGGL((k_maxpy<N, false>), grid, dim3(kBlock), 0, c->stream, c->g, w, P, H, c->red_partial);     \
+    if (last) hipLaunchKernelGGL((k_maxpy<N, true>), grid, dim3(kBlock), 0, c->stream, c->g, src, P, H, c->red_partial, out, sc); \
+    else hipLaunchKernelGGL((k_maxpy<N, false>), grid, dim3(kBlock), 0, c->stream, c->g, src, P, H, c->red_partial, out, sc);     \
     break;
       CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
     }
     XPIC_HIP(hipGetLastError());
+    src = out; // later groups continue on the partial result
   }
   if (nrm2) return finish_reduce(c, 1, nblocks, 1, nrm2);
   return 0;
+}
+
+int vec_maxpy_norm_host(xpic_ctx* c, double* w, const double* V, int nv, const double* h, double* nrm2)
+{
+  return vec_maxpy_scaled(c, w, V, nv, h, w, 1.0, nrm2);
 }
 
 int vec_maxpy(xpic_ctx* c, double* x, const double* V, int nv, const double* y)
@@ -625,27 +659,42 @@ int rot_apply(xpic_ctx* c, int sign, double alpha, const double* x, double* y, b
   return 0;
 }
 
-int matM_apply(xpic_ctx* c, const double* x, double* y, bool add)
+static int matM_planes(xpic_ctx* c, const double* x, double* y, bool add, int z0r, int nzr)
 {
-  Timed t(c, "matM_apply");
-  long blocks = (c->g.nown + kBlock - 1) / kBlock;
+  if (nzr <= 0) return 0;
+  long blocks = ((long)nzr * c->g.plane + kBlock - 1) / kBlock;
   if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(k_matM, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, c->g, x, y, add ? 1 : 0);
+  hipLaunchKernelGGL(k_matM, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, c->g, x, y, add ? 1 : 0, z0r, nzr);
   XPIC_HIP(hipGetLastError());
   return 0;
 }
 
-static dim3 row_grid(const GridDev& g)
+int matM_apply(xpic_ctx* c, const double* x, double* y, bool add)
+{
+  Timed t(c, "matM_apply");
+  return matM_planes(c, x, y, add, 0, c->g.nzl);
+}
+
+static dim3 row_grid(const GridDev& g, int nzr)
 {
   const long nxc = (g.nx + kRowX - 1) / kRowX, nyc = (g.ny + kRowY - 1) / kRowY;
-  const long nyt = (nyc + kBandY - 1) / kBandY, P = (g.nzl + 7) / 8;
+  const long nyt = (nyc + kBandY - 1) / kBandY, P = (nzr + 7) / 8;
   return dim3((unsigned)(8 * nyt * P * kBandY * nxc * 3));
 }
 
 int matL_apply(xpic_ctx* c, const double* x, double* y, bool add)
 {
   Timed t(c, "matL_apply");
-  hipLaunchKernelGGL((k_matA<true, false>), row_grid(c->g), dim3(kRowX, kRowY), 0, c->stream, c->g, c->matL, x, y, add ? 1 : 0);
+  hipLaunchKernelGGL((k_matA<true, false>), row_grid(c->g, c->g.nzl), dim3(kRowX, kRowY), 0, c->stream, c->g, c->matL, x, y,
+    add ? 1 : 0, 0, c->g.nzl);
+  XPIC_HIP(hipGetLastError());
+  return 0;
+}
+
+static int matA_planes(xpic_ctx* c, const double* x, double* y, int z0r, int nzr)
+{
+  if (nzr <= 0) return 0;
+  hipLaunchKernelGGL((k_matA<true, true>), row_grid(c->g, nzr), dim3(kRowX, kRowY), 0, c->stream, c->g, c->matL, x, y, 0, z0r, nzr);
   XPIC_HIP(hipGetLastError());
   return 0;
 }
@@ -653,8 +702,30 @@ int matL_apply(xpic_ctx* c, const double* x, double* y, bool add)
 int matA_apply(xpic_ctx* c, const double* x, double* y)
 {
   Timed t(c, "matA_apply");
-  hipLaunchKernelGGL((k_matA<true, true>), row_grid(c->g), dim3(kRowX, kRowY), 0, c->stream, c->g, c->matL, x, y, 0);
-  XPIC_HIP(hipGetLastError());
+  return matA_planes(c, x, y, 0, c->g.nzl);
+}
+
+int halo_post(xpic_ctx* c, double* f, int width);
+int halo_wait(xpic_ctx* c);
+
+// y = op(x) on a z-slab with neighbours: the exchange of x's `width` boundary planes is POSTED (packed on the compute
+// stream, shipped and unpacked on the communication stream), the rows of the interior planes -- which read no ghost
+// plane -- are computed meanwhile, and the rows of the 2 * width boundary planes follow once the ghosts have arrived
+// (the VecScatterBegin / local part / VecScatterEnd / off-process part structure of PETSc's MatMult).
+int op_apply_overlapped(xpic_ctx* c, bool with_L, double* x, double* y)
+{
+  const GridDev& g = c->g;
+  const int w = with_L ? 2 : 1;
+  Timed t(c, with_L ? "matA_apply" : "matM_apply");
+  const int nin = g.nzl - 2 * w;
+  XPIC_CALL(halo_post(c, x, w));
+  if (with_L) XPIC_CALL(matA_planes(c, x, y, w, nin));
+  else XPIC_CALL(matM_planes(c, x, y, false, w, nin));
+  XPIC_CALL(halo_wait(c));
+  const int nb = nin >= 0 ? w : g.nzl / 2;              // slabs thinner than 2 w planes: two halves, no interior
+  const int ztop = nin >= 0 ? g.nzl - w : nb;
+  if (with_L) { XPIC_CALL(matA_planes(c, x, y, 0, nb)); XPIC_CALL(matA_planes(c, x, y, ztop, g.nzl - ztop)); }
+  else { XPIC_CALL(matM_planes(c, x, y, false, 0, nb)); XPIC_CALL(matM_planes(c, x, y, false, ztop, g.nzl - ztop)); }
   return 0;
 }
 
@@ -846,6 +917,48 @@ int halo_fill_t(xpic_ctx* c, T* f, int width)
 }  // namespace
 
 int halo_fill(xpic_ctx* c, double* f, int width) { return halo_fill_t<double>(c, f, width); }
+
+// Split form of halo_fill for the overlapped operator apply.  With RCCL the exchange and the unpack run on the
+// context's communication stream between two events; with the host-callback transport (tests) the exchange is
+// synchronous and halo_post simply completes it.
+int halo_post(xpic_ctx* c, double* f, int width)
+{
+  const GridDev& g = c->g;
+  if (g.G == 0) return 0;
+  if (c->comm.kind != 1 || !c->comm_stream) return halo_fill(c, f, width);
+  XPIC_CHECK(width <= g.G && width <= g.nzl, "halo width exceeds the ghost layer");
+  const long n = 3L * width * g.plane;
+  const size_t bytes = sizeof(double) * n;
+  XPIC_CALL(ensure_halo_buf(c, bytes));
+  const unsigned nb = plane_grid(n);
+  double* hb[4] = {c->halo_buf[0], c->halo_buf[1], c->halo_buf[2], c->halo_buf[3]};
+  hipLaunchKernelGGL((k_planes<0, double>), dim3(nb), dim3(kBlock), 0, c->stream, g, f, hb[0], g.G, width);
+  hipLaunchKernelGGL((k_planes<0, double>), dim3(nb), dim3(kBlock), 0, c->stream, g, f, hb[1], g.G + g.nzl - width, width);
+  XPIC_HIP(hipGetLastError());
+  XPIC_HIP(hipEventRecord(c->comm_ev[0], c->stream));
+  XPIC_HIP(hipStreamWaitEvent(c->comm_stream, c->comm_ev[0], 0));
+  hipStream_t compute = c->stream;
+  c->stream = c->comm_stream; // comm_ring and the unpack below are enqueued on the communication stream
+  int rc = comm_ring(c, hb[0], bytes, hb[1], bytes, hb[2], bytes, hb[3], bytes);
+  if (rc == 0) {
+    hipLaunchKernelGGL((k_planes<1, double>), dim3(nb), dim3(kBlock), 0, c->stream, g, f, hb[2], g.G + g.nzl, width);
+    hipLaunchKernelGGL((k_planes<1, double>), dim3(nb), dim3(kBlock), 0, c->stream, g, f, hb[3], g.G - width, width);
+  }
+  c->stream = compute;
+  XPIC_CALL(rc);
+  XPIC_HIP(hipGetLastError());
+  XPIC_HIP(hipEventRecord(c->comm_ev[1], c->comm_stream));
+  c->halo_posted = true;
+  return 0;
+}
+
+int halo_wait(xpic_ctx* c)
+{
+  if (!c->halo_posted) return 0;
+  c->halo_posted = false;
+  XPIC_HIP(hipStreamWaitEvent(c->stream, c->comm_ev[1], 0));
+  return 0;
+}
 int halo_fill_f32(xpic_ctx* c, float* f, int width) { return halo_fill_t<float>(c, f, width); }
 
 int halo_add(xpic_ctx* c, double* f, int width)

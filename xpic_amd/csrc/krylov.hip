@@ -15,7 +15,9 @@ constexpr int kRestart = 30;
 
 int apply_op(xpic_ctx* c, int op, double* x, double* y)
 {
-  XPIC_CALL(halo_fill(c, x, 2)); // the VecScatter inside MatMult: matL reaches 2 planes, matM 1
+  // the VecScatter inside MatMult: matL reaches 2 planes, matM 1.  On slabs the exchange runs beside the interior rows.
+  if (c->g.G > 0 && c->overlap) return op_apply_overlapped(c, op == XPIC_OP_MATA_GMRES, x, y);
+  XPIC_CALL(halo_fill(c, x, op == XPIC_OP_MATA_GMRES ? 2 : 1));
   if (op == XPIC_OP_MATA_GMRES) return matA_apply(c, x, y);
   return matM_apply(c, x, y, false);
 }
@@ -32,10 +34,9 @@ int gmres(xpic_ctx* c, int op, const double* b, double* x, double rtol, double a
   // both GMRES solves are right-preconditioned by the Chebyshev polynomial in matM: for the "correct" solve on matM
   // itself it is an approximate inverse (1-2 iterations instead of ~25)
   const bool pc = (op == XPIC_OP_MATA_GMRES || op == XPIC_OP_MATM_GMRES) && c->precond != 0;
-  if (pc && !c->kry_Z) {
-    XPIC_HIP(hipMalloc(&c->kry_Z, sizeof(double) * c->nvec * m));
-    XPIC_HIP(hipMemsetAsync(c->kry_Z, 0, sizeof(double) * c->nvec * m, c->stream));
-  }
+  // kry_Z is sized with the context (xpic_create / xpic_set_preconditioner): an allocation here, in the middle of a step,
+  // could fail on one slab alone and leave the others waiting in the solve's collectives
+  XPIC_CHECK(!pc || c->kry_Z, "flexible GMRES workspace missing (xpic_set_preconditioner allocates it)");
   double* Z = c->kry_Z;
   double* V = c->kry_V;
   double* w = c->kry_w;
@@ -73,11 +74,25 @@ int gmres(xpic_ctx* c, int op, const double* b, double* x, double rtol, double a
         XPIC_CALL(apply_op(c, op, Zj, w));
       }
       else XPIC_CALL(apply_op(c, op, Vj, w));
-      XPIC_CALL(vec_mdot_host(c, w, V, j + 1, h.data()));           // VecMDot
-      double nrm2;
-      XPIC_CALL(vec_maxpy_norm_host(c, w, V, j + 1, h.data(), &nrm2)); // VecMAXPY + VecNorm
-      h[j + 1] = std::sqrt(nrm2);
-      if (h[j + 1] != 0.0) XPIC_CALL(vec_scale_to(c, V + (long)(j + 1) * c->nvec, 1.0 / h[j + 1], w));
+      // Classical Gram-Schmidt with ONE reduction (one all-reduce on slabs) per iteration: the dot products w . V_i and
+      // w . w travel together, and |w - sum h_i V_i|^2 = w.w - sum h_i^2 because V is orthonormal.  The subtraction
+      // loses log10(w.w / h_{j+1}^2) digits: when fewer than ~8 would be left the norm is taken explicitly (a second
+      // reduction, as PETSc's VecNorm after VecMAXPY).  The new basis vector is written scaled in the same pass.
+      double ww;
+      XPIC_CALL(vec_mdot_ww_host(c, w, V, j + 1, h.data(), &ww)); // VecMDot (+ the norm's w . w)
+      double hh = 0.0;
+      for (int i = 0; i <= j; ++i) hh += h[i] * h[i];
+      double nrm2 = ww - hh;
+      double* Vn = V + (long)(j + 1) * c->nvec;
+      if (!(nrm2 > 1e-8 * ww)) {
+        XPIC_CALL(vec_maxpy_norm_host(c, w, V, j + 1, h.data(), &nrm2)); // VecMAXPY + VecNorm
+        h[j + 1] = std::sqrt(nrm2);
+        if (h[j + 1] != 0.0) XPIC_CALL(vec_scale_to(c, Vn, 1.0 / h[j + 1], w));
+      }
+      else {
+        h[j + 1] = std::sqrt(nrm2);
+        XPIC_CALL(vec_maxpy_scaled(c, w, V, j + 1, h.data(), Vn, 1.0 / h[j + 1], nullptr)); // VecMAXPY + VecScale
+      }
       for (int i = 0; i < j; ++i) {
         const double t = cs[i] * h[i] + sn[i] * h[i + 1];
         h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1];

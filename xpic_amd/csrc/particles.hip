@@ -678,7 +678,6 @@ int sort_alloc(xpic_ctx* c, Sort& s, int64_t cap)
   XPIC_HIP(hipMalloc(&s.d.cell_start, sizeof(int) * (c->ncell + 1 + kCellStartPad)));
   XPIC_HIP(hipMemsetAsync(s.d.cell_start, 0, sizeof(int) * (c->ncell + 1 + kCellStartPad), c->stream));
   XPIC_HIP(hipMemsetAsync(s.d.cell_count, 0, sizeof(int) * (c->ncell + 1), c->stream));
-  XPIC_HIP(hipMemsetAsync(s.d.cell_start, 0, sizeof(int) * (c->ncell + 1), c->stream));
   if (c->g.G > 0) {
     int64_t mc = cap / 8;
     if (mc < 65536) mc = 65536;
