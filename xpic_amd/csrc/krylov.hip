@@ -75,16 +75,22 @@ int gmres(xpic_ctx* c, int op, const double* b, double* x, double rtol, double a
       }
       else XPIC_CALL(apply_op(c, op, Vj, w));
       // Classical Gram-Schmidt with ONE reduction (one all-reduce on slabs) per iteration: the dot products w . V_i and
-      // w . w travel together, and |w - sum h_i V_i|^2 = w.w - sum h_i^2 because V is orthonormal.  The subtraction
-      // loses log10(w.w / h_{j+1}^2) digits: when fewer than ~8 would be left the norm is taken explicitly (a second
-      // reduction, as PETSc's VecNorm after VecMAXPY).  The new basis vector is written scaled in the same pass.
-      double ww;
-      XPIC_CALL(vec_mdot_ww_host(c, w, V, j + 1, h.data(), &ww)); // VecMDot (+ the norm's w . w)
+      // w . w travel together, and |w - sum h_i V_i|^2 = w.w - sum h_i^2 for an orthonormal V.  V is orthonormal only up
+      // to CGS's loss of orthogonality, which grows like eps / (relative residual) as GMRES converges (measured: 1e-10
+      // at a relative residual of 1e-6, 1e-7 at 1e-9, and the recurrence then stagnates a decade above the true
+      // residual): the identity is used while the residual entering the iteration is above 1e-6 |b| and the
+      // subtraction keeps 4 digits; after that the norm is taken explicitly, as PETSc's VecNorm behind VecMAXPY (a
+      // second reduction).  At the reference's tolerances (1e-7) that is the last iteration of a solve.  The errors the
+      // identity leaves in H (1e-10 relative) also bound what the recurrence can resolve: for a requested tolerance
+      // below 1e-8 |b| every norm is explicit (measured: rtol 1e-9 took 12 instead of 10 iterations, 1e-11 a restart).
+      const bool pythagoras = tol >= 1e-8 * bnorm && rnorm > 1e-6 * bnorm;
+      double ww = 0.0;
+      XPIC_CALL(vec_mdot_ww_host(c, w, V, j + 1, h.data(), pythagoras ? &ww : nullptr)); // VecMDot (+ the norm's w . w)
       double hh = 0.0;
       for (int i = 0; i <= j; ++i) hh += h[i] * h[i];
-      double nrm2 = ww - hh;
+      double nrm2 = pythagoras ? ww - hh : 0.0;
       double* Vn = V + (long)(j + 1) * c->nvec;
-      if (!(nrm2 > 1e-8 * ww)) {
+      if (!pythagoras || !(nrm2 > 1e-4 * ww)) {
         XPIC_CALL(vec_maxpy_norm_host(c, w, V, j + 1, h.data(), &nrm2)); // VecMAXPY + VecNorm
         h[j + 1] = std::sqrt(nrm2);
         if (h[j + 1] != 0.0) XPIC_CALL(vec_scale_to(c, Vn, 1.0 / h[j + 1], w));
