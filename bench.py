@@ -50,6 +50,8 @@ def parse_args(argv=None):
     ap.add_argument("--probe", action="store_true", help="also run the device copy probes (PMC calibration)")
     ap.add_argument("--plain-gmres", action="store_true", help="unpreconditioned GMRES(30), as the CPU oracle runs")
     ap.add_argument("--cheb-degree", type=int, default=0, help="override the Chebyshev preconditioner degree (experiments)")
+    ap.add_argument("--precond", type=int, default=None, choices=[0, 1, 2, 3],
+                    help="xpic_set_preconditioner kind (default: the library's)")
     ap.add_argument("--scheme", default="ecsim", choices=["ecsim", "ecsimcorr", "basic"],
                     help="ecsim is the headline workload (BASELINE configs[2]); basic = configs[1], ecsimcorr = configs[4] "
                          "at one GPU's share: side measurements")
@@ -349,8 +351,8 @@ def main():
 
     if args.plain_gmres and args.scheme != "basic":
         ctx.set_preconditioner(0)
-    elif args.cheb_degree > 0 and args.scheme != "basic":
-        ctx.set_preconditioner(1, args.cheb_degree)
+    elif (args.cheb_degree > 0 or args.precond is not None) and args.scheme != "basic":
+        ctx.set_preconditioner(args.precond if args.precond is not None else 1, args.cheb_degree)
     copy_rate = ctx.probe_copy_bandwidth(1 << 30, 5) if args.probe else None
     for _ in range(args.warmup):
         ctx.step()
@@ -397,7 +399,7 @@ def main():
 
     prof = {k: ctx.profile_get(k) for k in ("matA_apply", "solve_matA", "fill_current", "move_bin", "scatter",
                                             "second_push", "mdot", "maxpy", "matL_zero", "scan", "rot_apply",
-                                            "halo", "migrate", "matL_ghost_rows", "basic_push", "corr_first_push",
+                                            "halo", "migrate", "matL_ghost_rows", "basic_push", "corr_first_push", "precond_setup",
                                             "corr_second_push", "solve_matM", "precond", "matL_apply", "rebin",
                                             "allreduce")}
     count_local = sum(ctx.count(s) for s in sorts)

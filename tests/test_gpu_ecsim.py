@@ -233,6 +233,42 @@ def test_preconditioned_solve(oracle):
     assert reason_t > 0 and rt <= 2e-12 * np.linalg.norm(rhs), (rt, rn_t)
 
 
+def test_preconditioner_with_the_mean_mass_matrix(oracle):
+    """kind 3: Chebyshev polynomial in matM + <matL> (the translation average of the assembled mass matrix as one
+    constant 123-point stencil, fp32).  The GMRES is flexible and judges the TRUE fp64 residual: same solution as the
+    oracle's plain GMRES within 10 x rtol, fewer iterations than the matM-only polynomial (kind 1) at enough particles
+    per cell for the average to be a good model (64 ppc here, the headline configuration's noise level)."""
+    import xpic_amd as X
+
+    n, d = (12, 10, 8), (0.5, 0.5, 0.5)
+    o, g = make_pair(oracle, "ecsim", n, d, 1.0, [(64, 1.0, -1.0, 1.0)], ppc=64, vth=0.014, B0=(0.0, 0.0, 0.2))
+    oracle.lib().orc_ecsim_fill_current(o.h)
+    g.ecsim_fill_current()
+    rhs = o.get_field("E")
+    xo, its_o, _ = o.solve(0, rhs, 1e-9, 1e-50, 300)
+    g.set_preconditioner(1)
+    its1, reason1, _ = g.solve(0, X.E, X.W1, 1e-7, 1e-50, 300)
+    g.set_preconditioner(3)
+    its3, reason3, rn3 = g.solve(0, X.E, X.W2, 1e-7, 1e-50, 300)
+    assert reason1 > 0 and reason3 > 0 and its3 < its1 and its3 <= 5, (its1, its3)
+    x3 = g.get_field(X.W2)
+    assert np.abs(xo - x3).max() <= 1e-6 * np.abs(xo).max()
+    res = np.linalg.norm(o.matM(x3) + o.matL_apply(x3) - rhs)
+    assert res <= 1.05e-7 * np.linalg.norm(rhs) and abs(res - rn3) <= 0.2 * rn3  # the reported norm is the true residual
+    # tight tolerance: the fp32 polynomial does not limit the residual that can be reached
+    _, reason_t, _ = g.solve(0, X.E, X.W1, 1e-12, 1e-50, 300)
+    xt = g.get_field(X.W1)
+    assert reason_t > 0 and np.linalg.norm(o.matM(xt) + o.matL_apply(xt) - rhs) <= 2e-12 * np.linalg.norm(rhs)
+    # a step with it tracks the oracle
+    for s_ in (o, g):
+        s_.set_tolerances(1e-11, 1e-50, 300)
+    io, ig = o.step(), g.step()
+    assert 0 < ig < io / 3
+    for name, fid in (("E", X.E), ("B", X.B)):
+        a, b = o.get_field(name), g.get_field(fid)
+        assert np.abs(a - b).max() <= 1e-7 * np.abs(a).max()
+
+
 def test_default_step_uses_preconditioner_and_matches_oracle(oracle):
     import xpic_amd as X
 
@@ -259,6 +295,7 @@ def test_one_reduction_per_gmres_iteration(oracle):
 
     n, d, dt = GRID
     o, g = make_pair(oracle, "ecsim", n, d, 1.0, [(8, 1.0, -1.0, 1.0)], B0=(0.0, 0.0, 0.2), vth=0.03)
+    oracle.lib().orc_ecsim_fill_current(o.h)
     g.ecsim_fill_current()
 
     def run(kind, rtol):
@@ -279,7 +316,7 @@ def test_one_reduction_per_gmres_iteration(oracle):
     # a tight tolerance runs on explicit norms (two reductions) and needs the iterations the oracle's GMRES needs
     xo, its_o, _ = o.solve(0, o.get_field("E"), 1e-11, 1e-50, 300)
     its, nred = run(0, 1e-11)
-    assert abs(its - its_o) <= 1 and nred == 2 * its + 1 + 2 * ((its - 1) // 30)
+    assert abs(its - its_o) <= 1 and nred == 2 * its + 1 + (its - 1) // 30
 
 
 def test_solve_reports_non_convergence(oracle):

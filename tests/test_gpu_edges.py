@@ -115,7 +115,9 @@ def test_capacity_and_argument_errors():
     with pytest.raises(X.XpicError, match="in place"):
         g.rot_apply(+1, 1.0, X.E, X.E)
     with pytest.raises(X.XpicError):
-        X.Context("ecsim", (3, 8, 8), (0.5, 0.5, 0.5), 1.0)  # extent below the stencil width
+        X.Context("ecsim", (1, 8, 8), (0.5, 0.5, 0.5), 1.0)  # a CIC footprint cannot fold onto a single cell
+    with pytest.raises(X.XpicError):
+        X.Context("ecsimcorr", (3, 8, 8), (0.5, 0.5, 0.5), 1.0)  # extent below the 2nd-order shapes' width
     with pytest.raises(X.XpicError, match="basic scheme"):
         X.Context("basic", (8, 8, 8), (0.5, 0.5, 0.5), 1.0).ecsim_fill_current()
 
@@ -193,3 +195,39 @@ def test_esirkepov_rounds_ragged_pencils(oracle, scheme):
     po, co = canon(*o.particles(0))
     pg, cg = canon(*g.particles(0))
     assert np.array_equal(co, cg) and np.abs(po - pg).max() < 1e-9
+
+
+@pytest.mark.parametrize("n", [(2, 2, 32), (3, 2, 5), (2, 3, 4), (5, 3, 2)])
+def test_tiny_extents_like_the_reference_default_config(oracle, n):
+    """The reference's shipped config.json is a 2 x 2 x 32 quasi-1D box (config.json:5-7): extents of 2 and 3 cells, where
+    a CIC footprint wraps onto itself.  ecsim assembly (currI, matL through its SpMV), solve and two full steps against
+    the oracle on the same particles."""
+    import xpic_amd as X
+    from test_gpu_ecsim import make_pair, canon
+
+    o, g = make_pair(oracle, "ecsim", n, (0.5, 0.4, 0.25), 0.7, [(8, 1.0, -1.0, 1.0)], ppc=9, B0=(0.1, 0.0, 0.3), vth=0.05)
+    oracle.lib().orc_ecsim_fill_current(o.h)
+    g.ecsim_fill_current()
+    a, b = o.get_field("currI"), g.get_field(X.CURRI)
+    assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
+    x = np.random.default_rng(5).normal(0, 1, o.fshape())
+    g.set_field(X.W0, x)
+    g.matL_apply(X.W0, X.W1)
+    ya, yb = o.matL_apply(x), g.get_field(X.W1)
+    assert np.abs(ya - yb).max() <= 1e-12 * np.abs(ya).max()
+    for s_ in (o, g):
+        s_.set_tolerances(1e-12, 1e-50, 400)
+    for t in range(2):
+        io, ig = o.step(), g.step()
+        assert io > 0 and abs(io - ig) <= 2, (t, io, ig)
+        for name, fid in (("E", X.E), ("B", X.B)):
+            fa, fb = o.get_field(name), g.get_field(fid)
+            assert np.abs(fa - fb).max() <= 1e-8 * np.abs(fa).max(), (t, name)
+    po, co = canon(*o.particles(0))
+    pg, cg = canon(*g.particles(0))
+    assert np.array_equal(co, cg)
+    assert np.abs(po - pg).max() <= 1e-11  # two field solves in: velocities (and the positions they move) agree to the solves
+    # the default preconditioners run there too
+    for kind in (1, 3):
+        g.set_preconditioner(kind)
+        assert g.step() > 0

@@ -231,6 +231,9 @@ def test_momentum_conservation_sums_on_device(oracle, scheme):
     the largest entry, before and after two steps."""
     n, d, dt = GRID
     o, g = make_pair(oracle, scheme, n, d, dt, [(6, 1.0, -1.0, 1.0), (3, 1.0, 1.0, 50.0)], B0=(0.0, 0.1, 0.5), vth=0.1)
+    if scheme != "basic":
+        for s_ in (o, g):  # the sums are compared to 1e-12: the two field solves must agree to better than their default 1e-7
+            s_.set_tolerances(1e-13, 1e-50, 400)
     for t in range(3):
         a, b = o.momentum(), g.momentum()
         assert a.shape == b.shape == (2, 6) and np.abs(a[:, 3:]).max() > 0
@@ -273,17 +276,17 @@ def test_config1_size_properties_basic():
     g.close()
 
 
-def test_config4_size_properties_ecsimcorr():
-    """`ecsimcorr` at 128^3 x 32 ppc (67 M particles; one GPU's particle load of BASELINE configs[4] is 8x this on a
-    512 x 512 x 64 slab): no particle lost over the two re-binnings of a step, both solves converge within maxit, the
-    corrected scheme conserves the total energy to the accuracy of the solves and the Esirkepov current keeps the
-    continuity residual at round-off."""
+@pytest.mark.parametrize("n", [(128, 128, 128), (512, 512, 64)])
+def test_config4_size_properties_ecsimcorr(n):
+    """`ecsimcorr` at 32 ppc on a 128^3 box (67 M particles) and on 512 x 512 x 64 cells = one GPU's REAL share of
+    BASELINE configs[4] (512^3 on 8 GPUs: 16.8 M cells, 537 M particles per GPU; here as one periodic box): no particle
+    lost over the two re-binnings of a step, both solves converge within maxit, the corrected scheme conserves the total
+    energy to the accuracy of the solves and the Esirkepov current keeps the continuity residual at round-off."""
     import xpic_amd as X
 
-    n = (128, 128, 128)
     g = X.Context("ecsimcorr", n, (0.5, 0.5, 0.5), 1.0)
     N = n[0] * n[1] * n[2]
-    s = g.add_sort(32, 1.0, -1.0, 1.0, capacity=int(32 * N * 1.3))
+    s = g.add_sort(32, 1.0, -1.0, 1.0, capacity=int(32 * N * 1.05) + 1024)
     g.fill_synthetic(s, 32, 0.014, seed=31)
     B = np.zeros(g.fshape())
     B[..., 2] = 0.2

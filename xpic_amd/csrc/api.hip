@@ -109,7 +109,8 @@ static int ecsim_fill_current(xpic_ctx* c)
   // top / bottom planes are written only by the neighbour's ghost-row exchange: clear everything, add everywhere.
   bool any = false;
   for (auto& s : c->sorts) any = any || s.n > 0;
-  const bool first_touch = any && g.G == 0;
+  // (and a y or z extent of 2 folds two row offsets of a pencil onto one stream: ecsim.hip adds those with atomics)
+  const bool first_touch = any && g.G == 0 && g.ny >= 3 && g.nzl >= 3;
   if (!first_touch) {
     Timed t(c, "matL_zero");
     XPIC_HIP(hipMemsetAsync(c->matL, 0, sizeof(double) * matL_doubles(g), c->stream));
@@ -257,7 +258,12 @@ int xpic_create(const xpic_geometry* geom, int scheme, xpic_ctx** out)
 {
   XPIC_CHECK(geom && out, "null argument");
   XPIC_CHECK(geom->periodic[0] && geom->periodic[1] && geom->periodic[2], "only DM_BOUNDARY_PERIODIC is supported");
-  XPIC_CHECK(geom->n[0] >= 4 && geom->n[1] >= 4 && geom->n[2] >= 4, "every grid extent must be >= 4 cells");
+  // ecsim runs on the reference's own default geometry (config.json: 2 x 2 x 32 cells): the CIC footprints fold
+  // periodically once (every offset is within [-2, 2] and the extent >= 2).  The 2nd-order shapes of basic / ecsimcorr
+  // need their 6-node tiles (esirkepov.hip).
+  XPIC_CHECK(geom->n[0] >= 2 && geom->n[1] >= 2 && geom->n[2] >= 2, "every grid extent must be >= 2 cells");
+  XPIC_CHECK(scheme == XPIC_ECSIM || (geom->n[0] >= 4 && geom->n[1] >= 4 && geom->n[2] >= 4),
+    "basic and ecsimcorr need every grid extent >= 4 cells (>= 6 for their pushes)");
   XPIC_CHECK(geom->nranks >= 1 && geom->rank >= 0 && geom->rank < geom->nranks, "bad rank / nranks");
   XPIC_CHECK(geom->n[2] % geom->nranks == 0, "nz must be divisible by the number of z-slabs");
   XPIC_CHECK(geom->nranks == 1 || geom->n[2] / geom->nranks >= 6, "a z-slab must hold at least 6 planes");
@@ -340,6 +346,7 @@ int xpic_destroy(xpic_ctx* ctx)
   (void)hipFree(ctx->kry_t); (void)hipFree(ctx->kry_Z); (void)hipFree(ctx->kry_p[0]); (void)hipFree(ctx->kry_p[1]); (void)hipFree(ctx->kry_p[2]);
   (void)hipFree(ctx->red_partial); (void)hipFree(ctx->red_out); (void)hipHostFree(ctx->red_host);
   (void)hipFree(ctx->scan_tmp);
+  (void)hipFree(ctx->abar32); (void)hipFree(ctx->abar_work);
   for (int i = 0; i < 4; ++i) (void)hipFree(ctx->halo_buf[i]);
   comm_free(ctx);
   for (auto& kv : ctx->prof)
@@ -632,9 +639,10 @@ int xpic_solve(xpic_ctx* ctx, int op, int rhs, int x, double rtol, double atol, 
 int xpic_set_preconditioner(xpic_ctx* ctx, int kind, int degree)
 {
   CTX_CHECK(ctx);
-  XPIC_CHECK(kind >= 0 && kind <= 2, "unknown preconditioner kind");
+  XPIC_CHECK(kind >= 0 && kind <= 3, "unknown preconditioner kind");
   ctx->precond = kind;
-  if (degree > 0) ctx->cheb_degree = degree > 64 ? 64 : degree;
+  ctx->cheb_degree_user = degree > 0 ? (degree > 64 ? 64 : degree) : 0;
+  if (degree > 0) ctx->cheb_degree = ctx->cheb_degree_user;
   return ensure_flexible_workspace(ctx);
 }
 

@@ -155,8 +155,14 @@ struct xpic_ctx {
   double* kry_t = nullptr; // preconditioner scratch (fp32 copy of its input)
   double* kry_Z = nullptr; // flexible GMRES: the preconditioned basis z_j = P v_j (allocated by the first preconditioned solve)
   double* kry_p[3] = {nullptr, nullptr, nullptr}; // Chebyshev preconditioner work vectors
-  int precond = 1;     // 0 none, 1 Chebyshev polynomial in matM (right preconditioning)
-  int cheb_degree = 0; // steps of the Chebyshev iteration (set at create from the spectral interval)
+  int precond = 1;     // 0 none; Chebyshev polynomial (right preconditioning) in matM on fp32 (1) / fp64 (2) work vectors,
+                       // 3: in matM + the translation average of matL (precond.hip) for the predict solve
+  int cheb_degree = 0; // steps of the Chebyshev iteration on matM (set at create from the spectral interval)
+  int cheb_degree_user = 0; // explicit degree from xpic_set_preconditioner (0: automatic)
+  float* abar32 = nullptr;    // kind 3: the 3 x 124 coefficients of Abar = matM + <matL>
+  double* abar_work = nullptr; // sums, matM's coefficients, fp64 Abar, per-row partials
+  double abar_lo = 0, abar_hi = 0; // spectral interval of Abar
+  bool abar_valid = false;
   double* red_partial = nullptr; // reduction partials
   double* red_out = nullptr;     // device results (pinned mirror below)
   double* red_host = nullptr;
@@ -213,6 +219,10 @@ int matL_apply(xpic_ctx* c, const double* x, double* y, bool add);
 int matA_apply(xpic_ctx* c, const double* x, double* y);
 int op_apply_overlapped(xpic_ctx* c, bool with_L, double* x, double* y); // halo exchange of x beside the interior rows
 int cheb_matM_inverse(xpic_ctx* c, const double* r, double* out);
+int halo_fill_f32(xpic_ctx* c, float* f, int width);
+// precond.hip
+int abar_update(xpic_ctx* c);                                     // Abar = matM + <matL> from the assembled matL
+int cheb_abar_inverse(xpic_ctx* c, const double* r, double* out); // out ~ Abar^-1 r
 int cg_apply_dot_host(xpic_ctx* c, const double* p, double* Ap, double* pAp);                       // Ap = matM p, p . Ap
 int cg_update_host(xpic_ctx* c, double alpha, const double* p, const double* Ap, double* x, double* r, double* rr);
 int div_neg_add(xpic_ctx* c, double* v3, double* out_scalar);

@@ -170,7 +170,8 @@ __device__ inline double load_bnb(const GridDev& g, const double* __restrict__ B
 template <bool P2, bool FX>
 __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, SortDev s, const double* __restrict__ B,
   double* currI, double* matL, const unsigned short* __restrict__ dtab, const int* __restrict__ linetab, const int* __restrict__ cowr, double q, double m,
-  double mpw, int cy0, int cystep, int ncy, int cz0, int czstep, int my_order, int ncol_y, int per_y, int per_z, int first_sort)
+  double mpw, int cy0, int cystep, int ncy, int cz0, int czstep, int my_order, int ncol_y, int per_y, int per_z, int first_sort,
+  int alias_rows)
 {
   const int cy = cy0 + (int)(blockIdx.x % ncy) * cystep;
   const int cz = cz0 + (int)(blockIdx.x / ncy) * czstep;
@@ -425,7 +426,10 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
             STAMP(1);
 
         // ---- phase 2: octant by octant (compile-time octant = compile-time accumulators), K = 4 particles per step;
-        // a step beyond the octant's last particle reads the zero slot
+        // a step beyond the octant's last particle reads the zero slot.  (A software pipeline over the steps -- one rotating
+        // operand set, the next step's ten reads issued between this step's products and its matrix instructions, also
+        // across octants -- compiled as intended, 6 register moves per step, and was SLOWER: 115.1 against 108.6 ms per
+        // assembly.  The other wave of the SIMD already covers the read latency; what a step costs is issue slots.)
 #if FILL_EXP != 1 && !(FILL_EXP >= 6 && FILL_EXP <= 8)
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
@@ -488,7 +492,11 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     const int ndone = FX ? kW : min(kW, g.nx - j * kW);
     // matL lines: the kW finished columns are the x-block j of the row, 32 contiguous, aligned bytes;
     // currI lines: kW consecutive doubles, 16-byte aligned when nx is even
-    const bool vecL = FX || ndone == kW, vecI = FX || (vecL && (g.nx & 1) == 0);
+    // alias_rows: a y or z extent of 2 cells folds the row offsets -1 and +1 of a pencil onto the SAME row, so two lines of
+    // this workgroup own one stream: their flush adds with atomics instead of the plain read-modify-write (general
+    // instantiation only; such boxes are the reference's quasi-1D set-ups, config.json:5-7)
+    const bool alias = !FX && alias_rows != 0;
+    const bool vecL = FX || (ndone == kW && !alias), vecI = FX || (vecL && (g.nx & 1) == 0);
     double old[kOwn][kW];
     double* ptr[kOwn];
     bool fst[kOwn];
@@ -591,6 +599,11 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
 #pragma unroll
             for (int c = 0; c < kW; c += 2)
               *(double2*)(ptr[mm] + c) = double2{old[mm][c] + w[c], old[mm][c + 1] + w[c + 1]};
+          }
+          else if (alias) {
+#pragma unroll
+            for (int c = 0; c < kW; ++c)
+              if (c < ndone && w[c] != 0.0) unsafeAtomicAdd(ptr[mm] + c, w[c]);
           }
           else {
 #pragma unroll
@@ -783,12 +796,14 @@ int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, d
       else { cz0 = b; czs = 3; ncz = (g.nzl - b + 2) / 3; }
       if (ncy == 0 || ncz == 0) continue;
       Timed t(c, "fill_current"); // one entry per colour launch: the average is the kernel's own launch duration
-      const bool fx = g.nx % kW == 0;
+      const bool alias = g.ny < 3 || (g.G == 0 && g.nzl < 3);
+      const bool fx = g.nx % kW == 0 && !alias;
       auto kern = g.pow2 ? (fx ? k_ecsim_fill<true, true> : k_ecsim_fill<true, false>)
                          : (fx ? k_ecsim_fill<false, true> : k_ecsim_fill<false, false>);
       hipLaunchKernelGGL(kern, dim3((unsigned)(ncy * ncz)), dim3(kThreads), 0, c->stream, g, s.d, B,
         currI_sort, matL, (const unsigned short*)(c->ltab + kLines + kLines * 8), c->ltab, c->ltab + kLines, s.par.q, s.par.m,
-        s.par.n / (double)s.par.Np, cy0, cys, ncy, cz0, czs, b * ncol_y + a, ncol_y, per_y, per_z, first_sort ? 1 : 0);
+        s.par.n / (double)s.par.Np, cy0, cys, ncy, cz0, czs, b * ncol_y + a, ncol_y, per_y, per_z, first_sort && !alias ? 1 : 0,
+        alias ? 1 : 0);
     }
   XPIC_HIP(hipGetLastError());
   return 0;

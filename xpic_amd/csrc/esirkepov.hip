@@ -151,7 +151,8 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
   constexpr int kCols = StageDim<MODE>::kCols, kPitch = StageDim<MODE>::kPitch;
   const int cy = blockIdx.x % g.ny;
   const int cz = blockIdx.x / g.ny;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // the wave index is wave-uniform: said explicitly, the K-step ranges and segment walks of phase 2 become scalar code
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 
   __shared__ double stage[kSRows * kPitch];
   __shared__ double jtile[3 * kJN];

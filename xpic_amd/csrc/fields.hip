@@ -748,7 +748,7 @@ int cheb_matM_inverse(xpic_ctx* c, const double* r, double* out)
   long blocks = (g.nown + kBlock - 1) / kBlock;
   if (blocks > 65536) blocks = 65536;
   const dim3 grid((unsigned)blocks), block(kBlock);
-  if (c->precond == 1) {
+  if (c->precond != 2) {
     float* d = (float*)c->kry_p[0];
     float* z0 = (float*)c->kry_p[1];
     float* z1 = (float*)c->kry_p[2];

@@ -37,6 +37,9 @@ int gmres(xpic_ctx* c, int op, const double* b, double* x, double rtol, double a
   // kry_Z is sized with the context (xpic_create / xpic_set_preconditioner): an allocation here, in the middle of a step,
   // could fail on one slab alone and leave the others waiting in the solve's collectives
   XPIC_CHECK(!pc || c->kry_Z, "flexible GMRES workspace missing (xpic_set_preconditioner allocates it)");
+  // kind 3: the predict solve's polynomial is in matM + <matL>, rebuilt from the matL this solve runs on
+  const bool pc_abar = pc && c->precond == 3 && op == XPIC_OP_MATA_GMRES;
+  if (pc_abar) XPIC_CALL(abar_update(c));
   double* Z = c->kry_Z;
   double* V = c->kry_V;
   double* w = c->kry_w;
@@ -70,7 +73,8 @@ int gmres(xpic_ctx* c, int op, const double* b, double* x, double rtol, double a
       double* Vj = V + (long)j * c->nvec;
       if (pc) {
         double* Zj = Z + (long)j * c->nvec;
-        XPIC_CALL(cheb_matM_inverse(c, Vj, Zj));
+        if (pc_abar) XPIC_CALL(cheb_abar_inverse(c, Vj, Zj));
+        else XPIC_CALL(cheb_matM_inverse(c, Vj, Zj));
         XPIC_CALL(apply_op(c, op, Zj, w));
       }
       else XPIC_CALL(apply_op(c, op, Vj, w));

@@ -1,0 +1,332 @@
+// precond.hip -- the preconditioner of the "predict" solve that sees the mass matrix (kind 3).
+//
+// matA = matM + matL.  A polynomial in matM alone (kinds 1, 2: fields.hip) leaves spec(matA P) = [1, 1.25] at the
+// bench's parameters, i.e. 6 GMRES iterations at rtol 1e-7 whatever its degree: on the null space of the curl matM
+// is 2 I at every wavelength while matL runs from ~0.5 (smooth modes) to ~0.02 (oscillatory ones).  What tells
+// those modes apart is the smoothing stencil of the mass matrix, so the surrogate here is the TRANSLATION AVERAGE
+// of the assembled matL,
+//     Lbar[c1][k] = < matL[node][c1][k] >_nodes        (123 constants per row component),
+// which for a uniform plasma is the 27 / 48-point CIC overlap stencil times the mean A_p matB_p rotation, and
+//     Abar = matM + Lbar
+// is ONE constant-coefficient 123-point stencil (matM's 13 points are a subset of the pattern).  P = p_k(Abar), a
+// fixed Chebyshev polynomial, is applied matrix-free: no coefficient stream, no inner products, one 2-plane halo per
+// step on slabs.  What is left for GMRES is matA - Abar = the particle noise of matL: spec(matA Abar^-1) = [0.98, 1.02]
+// at 64 ppc (tools/precond_spectrum.py, dense eigenvalues on a 10^3 box), 4 iterations instead of 6 -- each of
+// them costs a 50 GB sweep of matL.  The GMRES around it is flexible (krylov.hip): the polynomial runs on fp32
+// copies of its vectors with fp32 arithmetic, the stopping rule stays the true fp64 residual.
+#include <cmath>
+#include <utility>
+#include <vector>
+
+#include "common.h"
+#include "lstencil.h"
+
+namespace xpic {
+
+namespace {
+
+constexpr int kB = 256;
+#ifndef BAR_SCHED_GROUP
+#define BAR_SCHED_GROUP 1 // scheduling regions of k_cheb_bar: 1 = one per (c2, dz) group of lines, 5 = one per c2, 0 = none
+#endif
+
+// ---- matM as a 123-pattern stencil (host): probe 2 I + 0.5 dt^2 rot- rot+ with unit impulses on a 5^3 periodic box,
+// same difference formulas as fields.hip: rot_at / matM_at (src/utils/operators.cpp:155-215, ecsim/simulation.cpp:544-551)
+void matM_stencil(const GridDev& g, double* co /* [3][kLPad] */)
+{
+  constexpr int n = 5;
+  auto id = [](int x, int y, int z) { return ((z + n) % n * n + (y + n) % n) * n + (x + n) % n; };
+  const double ih[3] = {g.inv[0], g.inv[1], g.inv[2]};
+  for (int i = 0; i < 3 * kLPad; ++i) co[i] = 0.0;
+  for (int c2 = 0; c2 < 3; ++c2) {
+    std::vector<double> F(3 * n * n * n, 0.0), G(3 * n * n * n, 0.0), H(3 * n * n * n, 0.0);
+    F[c2 * n * n * n + id(2, 2, 2)] = 1.0;
+    auto at = [&](const std::vector<double>& v, int c, int x, int y, int z) { return v[c * n * n * n + id(x, y, z)]; };
+    for (int z = 0; z < n; ++z)
+      for (int y = 0; y < n; ++y)
+        for (int x = 0; x < n; ++x) { // G = rot+ F (forward differences)
+          G[0 * n * n * n + id(x, y, z)] = ih[1] * (at(F, 2, x, y + 1, z) - at(F, 2, x, y, z)) - ih[2] * (at(F, 1, x, y, z + 1) - at(F, 1, x, y, z));
+          G[1 * n * n * n + id(x, y, z)] = -ih[0] * (at(F, 2, x + 1, y, z) - at(F, 2, x, y, z)) + ih[2] * (at(F, 0, x, y, z + 1) - at(F, 0, x, y, z));
+          G[2 * n * n * n + id(x, y, z)] = ih[0] * (at(F, 1, x + 1, y, z) - at(F, 1, x, y, z)) - ih[1] * (at(F, 0, x, y + 1, z) - at(F, 0, x, y, z));
+        }
+    for (int z = 0; z < n; ++z)
+      for (int y = 0; y < n; ++y)
+        for (int x = 0; x < n; ++x) { // H = rot- G (backward differences)
+          H[0 * n * n * n + id(x, y, z)] = ih[1] * (at(G, 2, x, y, z) - at(G, 2, x, y - 1, z)) - ih[2] * (at(G, 1, x, y, z) - at(G, 1, x, y, z - 1));
+          H[1 * n * n * n + id(x, y, z)] = -ih[0] * (at(G, 2, x, y, z) - at(G, 2, x - 1, y, z)) + ih[2] * (at(G, 0, x, y, z) - at(G, 0, x, y, z - 1));
+          H[2 * n * n * n + id(x, y, z)] = ih[0] * (at(G, 1, x, y, z) - at(G, 1, x - 1, y, z)) - ih[1] * (at(G, 0, x, y, z) - at(G, 0, x, y - 1, z));
+        }
+    // row (c1, node q) couples to column (c2, node p = (2,2,2)) with offset d = p - q
+    for (int c1 = 0; c1 < 3; ++c1)
+      for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dx = -1; dx <= 1; ++dx) {
+            const int k = lencode(c1, c2, dx, dy, dz);
+            if (k < 0) continue;
+            double v = 0.5 * g.dt * g.dt * at(H, c1, 2 - dx, 2 - dy, 2 - dz);
+            if (c1 == c2 && dx == 0 && dy == 0 && dz == 0) v += 2.0;
+            co[c1 * kLPad + k] = v;
+          }
+  }
+}
+
+// ---- translation average of matL over a sample of its rows ------------------------------------------------------
+// stage 1: one workgroup per sampled row block (c1, zp, y): sums the row's x-blocks; thread t = k * 4 + x % 4
+__global__ void __launch_bounds__(512) k_lbar_rows(GridDev g, const double* __restrict__ matL, int sy, int sz, int nys,
+  double* __restrict__ partial)
+{
+  const int t = threadIdx.x;
+  const int row = blockIdx.x, c1 = blockIdx.y;
+  const int y = (row % nys) * sy, z = (row / nys) * sz;
+  if (t >= kLBlock) return;
+  const double* base = matL + g.lindex(c1, z + (g.G ? 1 : 0), y, 0, 0) + t;
+  double s = 0.0;
+  const int nb = g.nbx();
+  for (int b = 0; b < nb; ++b) s += base[(long)b * kLBlock];
+  partial[((long)row * 3 + c1) * kLBlock + t] = s;
+}
+
+// stage 2: fixed-order sum over the sampled rows, then over x % 4: sums[c1][k] (deterministic)
+__global__ void __launch_bounds__(512) k_lbar_final(const double* __restrict__ partial, int nrows, double* __restrict__ sums)
+{
+  __shared__ double sm[kLBlock];
+  const int t = threadIdx.x, c1 = blockIdx.x;
+  if (t < kLBlock) {
+    double s = 0.0;
+    for (int r = 0; r < nrows; ++r) s += partial[((long)r * 3 + c1) * kLBlock + t];
+    sm[t] = s;
+  }
+  __syncthreads();
+  if (t < kLPad) sums[c1 * kLPad + t] = (sm[4 * t] + sm[4 * t + 1]) + (sm[4 * t + 2] + sm[4 * t + 3]);
+}
+
+__global__ void k_abar(const double* __restrict__ sums, const double* __restrict__ mco, double inv_count, float* abar32,
+  double* abar64)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * kLPad) return;
+  const double v = mco[i] + sums[i] * inv_count;
+  abar64[i] = v;
+  abar32[i] = (float)v;
+}
+
+// ---- one Chebyshev step on Abar:  res = r - Abar z ; d = cd d + cr res ; z_out = z + d  (fp32 vectors) -------------
+// A workgroup owns a (128 x, 4 y) column of nodes and marches along z with a sliding window of 5 planes of the three
+// components in LDS (radius 2 in every direction); a lane computes two neighbouring x nodes of one row: every line
+// (c2, dy, dz) of the stencil is three 8-byte LDS reads for 2 x 5 taps.  The coefficients are wave-uniform (scalar
+// loads).  ~370 fp32 FMAs per node against ~70 LDS reads: bound by FMA issue, and by the 5 V / 2 of vector traffic.
+constexpr int kTX = 128, kTY = 4, kH = 2, kPX = kTX + 2 * kH, kPY = kTY + 2 * kH, kZW = 5;
+constexpr int kPlaneF = 3 * kPY * kPX; // floats of one window plane
+
+__host__ __device__ constexpr bool line_used(int c2, int dy, int dz)
+{
+  for (int c1 = 0; c1 < 3; ++c1)
+    for (int dx = -2; dx <= 2; ++dx)
+      if (lencode(c1, c2, dx, dy, dz) >= 0) return true;
+  return false;
+}
+
+using UniformFloats = const __attribute__((address_space(4))) float*;
+typedef float fpair __attribute__((ext_vector_type(2)));
+
+// The stencil is expanded at compile time (integer sequences, as k_matA's term list): tap I = (dx + 2) * 3 + c1 of the
+// line (C2, DZ, DY) exists iff lencode() >= 0 -- a constant expression here, not a run-time test.
+template <int C2, int DZ, int DY, int I>
+__device__ __forceinline__ void bar_tap(float (&acc)[2][3], const float (&v)[6], UniformFloats coef)
+{
+  constexpr int dx = I / 3 - 2, c1 = I % 3;
+  constexpr int k = lencode(c1, C2, dx, DY, DZ);
+  if constexpr (k >= 0) {
+    const float a = coef[c1 * kLPad + k]; // wave-uniform: a scalar load
+    acc[0][c1] += a * v[dx + 2];
+    acc[1][c1] += a * v[dx + 3];
+  }
+}
+
+template <int C2, int DZ, int DY, int... Is>
+__device__ __forceinline__ void bar_line(std::integer_sequence<int, Is...>, float (&acc)[2][3], const fpair* tile,
+  const int (&sbase)[kZW], int lbase, UniformFloats coef)
+{
+  if constexpr (line_used(C2, DY, DZ)) {
+    // float-pair units: every offset here is even, and saying so (a pair-typed array) makes the reads ds_read_b64
+    const fpair* src = tile + (sbase[DZ + 2] + (C2 * kPY + DY) * kPX + lbase) / 2;
+    const fpair v01 = src[0], v23 = src[1], v45 = src[2];
+    const float v[6] = {v01.x, v01.y, v23.x, v23.y, v45.x, v45.y}; // x - 2 .. x + 3
+    (bar_tap<C2, DZ, DY, Is>(acc, v, coef), ...);
+  }
+  // one scheduling region per (c2, dz) group of lines: left alone the scheduler hoists all 135 reads of a plane to the
+  // top (270 VGPRs: spills); a group is <= 15 reads in flight over ~150 FMAs, and the other wave of the SIMD covers the rest
+  if constexpr (DY == 2 && (BAR_SCHED_GROUP == 1 || (BAR_SCHED_GROUP == 5 && DZ == 2))) __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int... Ls> // L = (c2 * 5 + dz + 2) * 5 + dy + 2
+__device__ __forceinline__ void bar_apply(std::integer_sequence<int, Ls...>, float (&acc)[2][3], const fpair* tile,
+  const int (&sbase)[kZW], int lbase, UniformFloats coef)
+{
+  (bar_line<Ls / 25, (Ls / 5) % 5 - 2, Ls % 5 - 2>(std::make_integer_sequence<int, 15>{}, acc, tile, sbase, lbase, coef), ...);
+}
+
+template <bool FIRST, bool LAST>
+__global__ void __launch_bounds__(kB, 2) k_cheb_bar(GridDev g, const float* __restrict__ coef_, const double* __restrict__ r64,
+  float* __restrict__ r32, const float* __restrict__ zin, float* __restrict__ d, float* __restrict__ zout,
+  double* __restrict__ out64, double cd, double cr, double itheta, int nbx, int nby, int zc)
+{
+  __shared__ __attribute__((aligned(16))) fpair tile2[kZW * kPlaneF / 2];
+  float* tile = (float*)tile2;
+  UniformFloats coef = (UniformFloats)coef_;
+  const int lane = threadIdx.x & 63, wy = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bx = blockIdx.x % nbx, by = (blockIdx.x / nbx) % nby, bz = blockIdx.x / (nbx * nby);
+  const int x0 = bx * kTX, y0 = by * kTY, z0 = bz * zc;
+  const int z1 = min(z0 + zc, g.nzl);
+  if (z0 >= z1) return;
+
+  auto load_plane = [&](int p) { // unwrapped owned-plane number p in [-2, nzl + 1]
+    const int slot = (p - z0 + 2) % kZW;
+    const long zoff = (long)g.wz(p) * g.plane;
+    float* dst = tile + slot * kPlaneF;
+    for (int i = threadIdx.x; i < kPlaneF; i += kB) {
+      const int comp = i / (kPY * kPX), rem = i % (kPY * kPX), yy = rem / kPX, xx = rem % kPX;
+      int gx = (x0 - kH + xx) % g.nx, gy = (y0 - kH + yy) % g.ny;
+      gx += gx < 0 ? g.nx : 0;
+      gy += gy < 0 ? g.ny : 0;
+      const long src = comp * g.cstride + zoff + (long)gy * g.nx + gx;
+      dst[i] = FIRST ? (float)r64[src] : zin[src];
+    }
+  };
+
+  for (int p = z0 - 2; p < z0 + 2; ++p) load_plane(p);
+  const int x = x0 + 2 * lane, y = y0 + wy;
+  const bool row_ok = y < g.ny;
+  for (int z = z0; z < z1; ++z) {
+    load_plane(z + 2);
+    __syncthreads();
+    if (row_ok) { // (rows beyond ny only help loading the window)
+      float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+      int sbase[kZW]; // float offset of the window plane of z + dz
+#pragma unroll
+      for (int dz = -2; dz <= 2; ++dz) sbase[dz + 2] = ((z + dz - z0 + 2) % kZW) * kPlaneF;
+      const int lbase = (wy + kH) * kPX + 2 * lane;
+      // the 369 coefficients are re-read through the scalar cache for every plane: hoisted out of the march they would
+      // need 369 SGPRs (the compiler then parks them in VGPR lanes and pays a v_readlane per use)
+      asm volatile("" : "+s"(coef));
+      bar_apply(std::make_integer_sequence<int, 75>{}, acc, tile2, sbase, lbase, coef);
+      // pin the sums here: their only users sit behind the x < nx tests below, and the optimizer otherwise sinks all 738
+      // FMAs there while the 135 LDS reads stay in front (270 live VGPRs: spills)
+      asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]));
+      const long zoff = (long)g.wz(z) * g.plane + (long)y * g.nx;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (x + e >= g.nx) continue;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const long oc = c * g.cstride + zoff + x + e;
+          const double rv = FIRST ? r64[oc] : (double)r32[oc];
+          const double zc0 = (double)tile[sbase[2] + c * kPY * kPX + lbase + kH + e]; // the window's centre value
+          const double zv = FIRST ? rv * itheta : zc0;
+          const double m = FIRST ? (double)acc[e][c] * itheta : (double)acc[e][c];
+          const double dn = cd * (FIRST ? zv : (double)d[oc]) + cr * (rv - m);
+          if (FIRST && !LAST) r32[oc] = (float)rv;
+          if (LAST) out64[oc] = zv + dn;
+          else {
+            d[oc] = (float)dn;
+            zout[oc] = (float)(zv + dn);
+          }
+        }
+      }
+    }
+    __syncthreads(); // the next load overwrites the slot of plane z - 2
+  }
+}
+
+}  // namespace
+
+int halo_fill_f32(xpic_ctx* c, float* f, int width);
+
+// (re)build Abar = matM + <matL>: called once per assembly, before the predict solve
+int abar_update(xpic_ctx* c)
+{
+  const GridDev& g = c->g;
+  Timed t(c, "precond_setup");
+  const int sy = g.ny >= 16 ? 4 : 1, sz = g.nzl >= 16 ? 4 : 1;
+  const int nys = (g.ny + sy - 1) / sy, nzs = (g.nzl + sz - 1) / sz;
+  const int nrows = nys * nzs;
+  if (!c->abar32) {
+    XPIC_HIP(hipMalloc(&c->abar32, sizeof(float) * 3 * kLPad));
+    XPIC_HIP(hipMalloc(&c->abar_work, sizeof(double) * (3 * kLPad * 3 + (size_t)nrows * 3 * kLBlock)));
+    double mco[3 * kLPad];
+    matM_stencil(g, mco);
+    XPIC_HIP(hipMemcpy(c->abar_work + 3 * kLPad, mco, sizeof(mco), hipMemcpyHostToDevice));
+  }
+  double* sums = c->abar_work;                  // [3][kLPad]
+  double* mco = c->abar_work + 3 * kLPad;       // matM's coefficients
+  double* abar64 = c->abar_work + 6 * kLPad;
+  double* partial = c->abar_work + 9 * kLPad;
+  hipLaunchKernelGGL(k_lbar_rows, dim3(nrows, 3), dim3(512), 0, c->stream, g, c->matL, sy, sz, nys, partial);
+  hipLaunchKernelGGL(k_lbar_final, dim3(3), dim3(512), 0, c->stream, partial, nrows, sums);
+  XPIC_HIP(hipGetLastError());
+  XPIC_CALL(comm_allreduce_sum(c, sums, 3 * kLPad)); // the same surrogate on every slab
+  const double count = (double)nrows * g.nx * c->comm.nranks;
+  hipLaunchKernelGGL(k_abar, dim3(2), dim3(256), 0, c->stream, sums, mco, 1.0 / count, c->abar32, abar64);
+  XPIC_HIP(hipGetLastError());
+  // spectral interval of Abar for the Chebyshev polynomial: matM's exact interval [2, 2 + 2 dt^2 sum 1/h^2], widened
+  // at the top by the largest absolute row sum of Lbar (Lbar is positive semi-definite up to its small rotation part)
+  double h[3 * kLPad], hm[3 * kLPad];
+  XPIC_HIP(hipMemcpyAsync(h, abar64, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  XPIC_HIP(hipMemcpyAsync(hm, mco, sizeof(hm), hipMemcpyDeviceToHost, c->stream));
+  XPIC_HIP(hipStreamSynchronize(c->stream));
+  double rs = 0.0;
+  for (int c1 = 0; c1 < 3; ++c1) {
+    double s = 0.0;
+    for (int k = 0; k < kLStencil; ++k) s += std::fabs(h[c1 * kLPad + k] - hm[c1 * kLPad + k]);
+    rs = std::max(rs, s);
+  }
+  c->abar_lo = 2.0;
+  c->abar_hi = 2.0 + 2.0 * g.dt * g.dt * (1.0 / (g.dx * g.dx) + 1.0 / (g.dy * g.dy) + 1.0 / (g.dz * g.dz)) + rs;
+  c->abar_valid = true;
+  return 0;
+}
+
+// out ~ Abar^-1 r: `degree` steps of the Chebyshev iteration on [abar_lo, abar_hi]
+int cheb_abar_inverse(xpic_ctx* c, const double* r, double* out)
+{
+  Timed t(c, "precond");
+  const GridDev& g = c->g;
+  XPIC_CHECK(c->abar_valid, "the matL surrogate of the preconditioner was not built (abar_update)");
+  const double a = c->abar_lo, b = c->abar_hi;
+  const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma1 = theta / delta;
+  // error bound 2 rho^k / (1 + rho^2k) <= 2.5 % (what is left for GMRES is the 2 % noise of matL around its average)
+  const double kappa = b / a, rh = (std::sqrt(kappa) - 1.0) / (std::sqrt(kappa) + 1.0);
+  int degree = c->cheb_degree_user > 0 ? c->cheb_degree_user : (int)std::ceil(std::log(0.0125) / std::log(rh));
+  degree = degree < 2 ? 2 : (degree > 64 ? 64 : degree);
+  float* d = (float*)c->kry_p[0];
+  float* z0 = (float*)c->kry_p[1];
+  float* z1 = (float*)c->kry_p[2];
+  float* r32 = (float*)c->kry_t;
+  const int nbx = (g.nx + kTX - 1) / kTX, nby = (g.ny + kTY - 1) / kTY;
+  // z-chunks: enough workgroups for two per CU, chunks of at least 8 planes (4 halo planes are loaded per chunk)
+  int nzc = (int)((2 * 256 + (long)nbx * nby - 1) / ((long)nbx * nby));
+  int zc = (g.nzl + nzc - 1) / nzc;
+  if (zc < 8) zc = g.nzl < 8 ? g.nzl : 8;
+  nzc = (g.nzl + zc - 1) / zc;
+  const dim3 grid((unsigned)(nbx * nby * nzc)), block(kB);
+  double rho = 1.0 / sigma1;
+  for (int i = 1; i < degree; ++i) {
+    const double rho_new = 1.0 / (2.0 * sigma1 - rho);
+    const double cd = rho_new * rho, cr = 2.0 * rho_new / delta, it = 1.0 / theta;
+    const bool first = i == 1, last = i == degree - 1;
+    if (first) XPIC_CALL(halo_fill(c, const_cast<double*>(r), 2));
+    else XPIC_CALL(halo_fill_f32(c, z0, 2));
+#define LAUNCH(F, L) hipLaunchKernelGGL((k_cheb_bar<F, L>), grid, block, 0, c->stream, g, c->abar32, r, r32, z0, d, z1, out, cd, cr, it, nbx, nby, zc)
+    if (first && last) LAUNCH(true, true);
+    else if (first) LAUNCH(true, false);
+    else if (last) LAUNCH(false, true);
+    else LAUNCH(false, false);
+#undef LAUNCH
+    XPIC_HIP(hipGetLastError());
+    rho = rho_new;
+    std::swap(z0, z1);
+  }
+  return 0;
+}
+
+}  // namespace xpic
