@@ -446,9 +446,12 @@ def main():
                            + (" [gloo rehearsal: all ranks share one GPU]" if rehearsal else ""),
         },
         "ksp_iters_per_s": its_total / world / (ms_solve * 1e-3) if ms_solve else None,  # iterations are global
-        "ksp_method": None if args.scheme == "basic" else
-                      ("flexible GMRES(30), right-preconditioned by a Chebyshev polynomial in matM on fp32 work vectors (outer iterations; each = 1 matA "
-                       "apply + the polynomial's matM applies)" if not args.plain_gmres else "GMRES(30), no preconditioner"),
+        "ksp_method": None if args.scheme == "basic" else (
+            "GMRES(30), no preconditioner" if args.plain_gmres or args.precond == 0 else
+            "flexible GMRES(30), right-preconditioned by a Chebyshev polynomial in " +
+            ("matM + <matL> (the translation average of the assembled mass matrix: one constant 123-point stencil, fp32)"
+             if args.precond in (None, 3) else "matM (fp32 work vectors)" if args.precond == 1 else "matM (fp64)") +
+            "; outer iterations, each = 1 matA apply + the polynomial's stencil applies"),
         "ksp_iterations_per_step": its_total / world / args.steps,
         "phase_ms_per_step": {k: v[1] / args.steps for k, v in prof.items() if k != "allreduce"},
         "allreduces_per_step": prof["allreduce"][0] / args.steps,  # reductions that are all-reduces on slabs (counted on 1 GPU too)

@@ -153,7 +153,7 @@ int xpic_set_tolerances(xpic_ctx* ctx, double rtol, double atol, int maxit);
 /* PCSetType for the "predict" and "correct" KSPs.  The reference runs PETSc's default ILU(0) (not part of its tree, not a GPU
  * algorithm); here: kind 0 = none, kind 1 / 2 = a fixed Chebyshev polynomial in matM applied from the right
  * (matM = 2 I + 0.5 dt^2 rotB rotE dominates matA and its spectral interval is known in closed form), its work vectors
- * kept in fp32 (kind 1) or fp64 (kind 2); kind 3 = the polynomial in matM + <matL>, the translation average of the assembled
+ * kept in fp32 (kind 1) or fp64 (kind 2); kind 3 (default) = the polynomial in matM + <matL>, the translation average of the assembled
  * mass matrix as one constant-coefficient 123-point stencil (fp32), for the predict solve (the correct solve on matM keeps
  * kind 1).  The GMRES around it is the flexible variant (x = x0 + sum y_j P v_j with the
  * P v_j stored): the result does not depend on how exactly P is applied, only the iteration count could.

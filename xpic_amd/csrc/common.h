@@ -155,7 +155,7 @@ struct xpic_ctx {
   double* kry_t = nullptr; // preconditioner scratch (fp32 copy of its input)
   double* kry_Z = nullptr; // flexible GMRES: the preconditioned basis z_j = P v_j (allocated by the first preconditioned solve)
   double* kry_p[3] = {nullptr, nullptr, nullptr}; // Chebyshev preconditioner work vectors
-  int precond = 1;     // 0 none; Chebyshev polynomial (right preconditioning) in matM on fp32 (1) / fp64 (2) work vectors,
+  int precond = 3;     // 0 none; Chebyshev polynomial (right preconditioning) in matM on fp32 (1) / fp64 (2) work vectors,
                        // 3: in matM + the translation average of matL (precond.hip) for the predict solve
   int cheb_degree = 0; // steps of the Chebyshev iteration on matM (set at create from the spectral interval)
   int cheb_degree_user = 0; // explicit degree from xpic_set_preconditioner (0: automatic)

@@ -355,6 +355,8 @@ __global__ void __launch_bounds__(kBlock) k_cheb32(GridDev g, const double* __re
 // four coefficients k..k+3 of a block are one 128-byte line, consumed by four consecutive loads of the wave.  The
 // operand vector comes out of L1/L2 (every element is used by 123 rows).  The stencil (c2, dx, dy, dz) of every k is a compile-time constant: the term list is expanded with
 // an integer_sequence so that all address arithmetic folds into immediates and wave-uniform row bases.
+// (Two neighbouring rows per lane -- 16-byte coefficient loads, the operand taps of a stencil line as three 16-byte loads,
+// 2.2 x fewer vector-memory instructions per row -- was built and measured SLOWER: 11.6 against 10.5 ms per apply.)
 struct RowCtx {
   const char* Lb;    // wave-uniform: first coefficient of the row block (c1, z, y), x = 0
   const char* Xb;    // operand vector

@@ -27,7 +27,7 @@ namespace {
 
 constexpr int kB = 256;
 #ifndef BAR_SCHED_GROUP
-#define BAR_SCHED_GROUP 1 // scheduling regions of k_cheb_bar: 1 = one per (c2, dz) group of lines, 5 = one per c2, 0 = none
+#define BAR_SCHED_GROUP 0 // scheduling regions of k_cheb_bar: 1 = one per (c2, dz) group of lines, 5 = one per c2, 0 = none (measured equal)
 #endif
 
 // ---- matM as a 123-pattern stencil (host): probe 2 I + 0.5 dt^2 rot- rot+ with unit impulses on a 5^3 periodic box,
@@ -86,36 +86,45 @@ __global__ void __launch_bounds__(512) k_lbar_rows(GridDev g, const double* __re
   partial[((long)row * 3 + c1) * kLBlock + t] = s;
 }
 
-// stage 2: fixed-order sum over the sampled rows, then over x % 4: sums[c1][k] (deterministic)
-__global__ void __launch_bounds__(512) k_lbar_final(const double* __restrict__ partial, int nrows, double* __restrict__ sums)
+// stage 2: fixed-order sums over segments of the sampled rows; stage 3: over the segments, then over x % 4 (deterministic)
+constexpr int kSegs = 64;
+__global__ void __launch_bounds__(512) k_lbar_segments(const double* __restrict__ partial, int nrows, double* __restrict__ segsum)
+{
+  const int t = threadIdx.x, c1 = blockIdx.x, sg = blockIdx.y;
+  if (t >= kLBlock) return;
+  const int per = (nrows + kSegs - 1) / kSegs, r0 = sg * per, r1 = min(r0 + per, nrows);
+  double s = 0.0;
+  for (int r = r0; r < r1; ++r) s += partial[((long)r * 3 + c1) * kLBlock + t];
+  segsum[((long)sg * 3 + c1) * kLBlock + t] = s;
+}
+
+__global__ void __launch_bounds__(512) k_lbar_final(const double* __restrict__ segsum, double* __restrict__ sums)
 {
   __shared__ double sm[kLBlock];
   const int t = threadIdx.x, c1 = blockIdx.x;
   if (t < kLBlock) {
     double s = 0.0;
-    for (int r = 0; r < nrows; ++r) s += partial[((long)r * 3 + c1) * kLBlock + t];
+    for (int sg = 0; sg < kSegs; ++sg) s += segsum[((long)sg * 3 + c1) * kLBlock + t];
     sm[t] = s;
   }
   __syncthreads();
   if (t < kLPad) sums[c1 * kLPad + t] = (sm[4 * t] + sm[4 * t + 1]) + (sm[4 * t + 2] + sm[4 * t + 3]);
 }
 
-__global__ void k_abar(const double* __restrict__ sums, const double* __restrict__ mco, double inv_count, float* abar32,
-  double* abar64)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 3 * kLPad) return;
-  const double v = mco[i] + sums[i] * inv_count;
-  abar64[i] = v;
-  abar32[i] = (float)v;
-}
+// Abar = matM + <matL>: fp64 copy in the 123-pattern (host: spectral bound) and the fp32 table k_cheb_bar reads, packed
+// per stencil line (line_slot / tap_pos; defined below)
+__host__ __device__ constexpr bool line_used(int c2, int dy, int dz);
+__host__ __device__ constexpr int line_slot(int L);
+__host__ __device__ constexpr int tap_pos(int c2, int dz, int dy, int I);
+__global__ void k_abar(const double* __restrict__ sums, const double* __restrict__ mco, double inv_count, float* packed,
+  double* abar64);
 
 // ---- one Chebyshev step on Abar:  res = r - Abar z ; d = cd d + cr res ; z_out = z + d  (fp32 vectors) -------------
 // A workgroup owns a (128 x, 4 y) column of nodes and marches along z with a sliding window of 5 planes of the three
 // components in LDS (radius 2 in every direction); a lane computes two neighbouring x nodes of one row: every line
 // (c2, dy, dz) of the stencil is three 8-byte LDS reads for 2 x 5 taps.  The coefficients are wave-uniform (scalar
 // loads).  ~370 fp32 FMAs per node against ~70 LDS reads: bound by FMA issue, and by the 5 V / 2 of vector traffic.
-constexpr int kTX = 128, kTY = 4, kH = 2, kPX = kTX + 2 * kH, kPY = kTY + 2 * kH, kZW = 5;
+constexpr int kTX = 128, kTY = 4, kH = 2, kPX = kTX + 2 * kH, kPY = kTY + 2 * kH, kZW = 6;
 constexpr int kPlaneF = 3 * kPY * kPX; // floats of one window plane
 
 __host__ __device__ constexpr bool line_used(int c2, int dy, int dz)
@@ -126,18 +135,52 @@ __host__ __device__ constexpr bool line_used(int c2, int dy, int dz)
   return false;
 }
 
-using UniformFloats = const __attribute__((address_space(4))) float*;
 typedef float fpair __attribute__((ext_vector_type(2)));
+typedef float fquad __attribute__((ext_vector_type(4)));
+typedef double dpairv __attribute__((ext_vector_type(2)));
+
+// The coefficients travel through LDS, packed per stencil line: line L = (c2 * 5 + dz + 2) * 5 + dy + 2 owns kCoefPitch
+// floats at slot line_slot(L); its taps I = (dx + 2) * 3 + c1 that exist sit at tap_pos(.., I) in that order.  Read as
+// wave-uniform 16-byte LDS reads they return in order with the window reads (counted waits); as 369 scalar loads per
+// plane they shared the LDS counter, had to be waited for with lgkmcnt(0), and the kernel spent 4/5 of its time there.
+constexpr int kCoefPitch = 12; // a line has at most 3 + 4 + 4 taps
+__host__ __device__ constexpr int line_slot(int L)
+{
+  int n = 0;
+  for (int l = 0; l < L; ++l) n += line_used(l / 25, l % 5 - 2, (l / 5) % 5 - 2) ? 1 : 0;
+  return n;
+}
+constexpr int kLinesUsed = line_slot(75);
+__host__ __device__ constexpr int tap_pos(int c2, int dz, int dy, int I)
+{
+  int n = 0;
+  for (int i = 0; i < I; ++i) n += lencode(i % 3, c2, i / 3 - 2, dy, dz) >= 0 ? 1 : 0;
+  return n;
+}
 
 // The stencil is expanded at compile time (integer sequences, as k_matA's term list): tap I = (dx + 2) * 3 + c1 of the
 // line (C2, DZ, DY) exists iff lencode() >= 0 -- a constant expression here, not a run-time test.
+__global__ void k_abar(const double* __restrict__ sums, const double* __restrict__ mco, double inv_count, float* packed,
+  double* abar64)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * kLPad) return;
+  const int c1 = i / kLPad, k = i % kLPad;
+  const double v = mco[i] + sums[i] * inv_count;
+  abar64[i] = v;
+  if (k >= kLStencil) return;
+  const LEntry e = ldecode(c1, k);
+  const int L = (e.c2 * 5 + e.d[2] + 2) * 5 + e.d[1] + 2;
+  packed[line_slot(L) * kCoefPitch + tap_pos(e.c2, e.d[2], e.d[1], (e.d[0] + 2) * 3 + c1)] = (float)v;
+}
+
 template <int C2, int DZ, int DY, int I>
-__device__ __forceinline__ void bar_tap(float (&acc)[2][3], const float (&v)[6], UniformFloats coef)
+__device__ __forceinline__ void bar_tap(float (&acc)[2][3], const float (&v)[6], const float (&cf)[kCoefPitch])
 {
   constexpr int dx = I / 3 - 2, c1 = I % 3;
-  constexpr int k = lencode(c1, C2, dx, DY, DZ);
-  if constexpr (k >= 0) {
-    const float a = coef[c1 * kLPad + k]; // wave-uniform: a scalar load
+  if constexpr (lencode(c1, C2, dx, DY, DZ) >= 0) {
+    constexpr int pos = tap_pos(C2, DZ, DY, I);
+    const float a = cf[pos];
     acc[0][c1] += a * v[dx + 2];
     acc[1][c1] += a * v[dx + 3];
   }
@@ -145,96 +188,162 @@ __device__ __forceinline__ void bar_tap(float (&acc)[2][3], const float (&v)[6],
 
 template <int C2, int DZ, int DY, int... Is>
 __device__ __forceinline__ void bar_line(std::integer_sequence<int, Is...>, float (&acc)[2][3], const fpair* tile,
-  const int (&sbase)[kZW], int lbase, UniformFloats coef)
+  const int (&sbase)[5], int lbase, const fquad* ctab)
 {
   if constexpr (line_used(C2, DY, DZ)) {
     // float-pair units: every offset here is even, and saying so (a pair-typed array) makes the reads ds_read_b64
     const fpair* src = tile + (sbase[DZ + 2] + (C2 * kPY + DY) * kPX + lbase) / 2;
     const fpair v01 = src[0], v23 = src[1], v45 = src[2];
     const float v[6] = {v01.x, v01.y, v23.x, v23.y, v45.x, v45.y}; // x - 2 .. x + 3
-    (bar_tap<C2, DZ, DY, Is>(acc, v, coef), ...);
+    constexpr int L = (C2 * 5 + DZ + 2) * 5 + DY + 2, ntap = tap_pos(C2, DZ, DY, 15);
+    constexpr int slot = line_slot(L);
+    const fquad* cq = ctab + slot * (kCoefPitch / 4);
+    float cf[kCoefPitch] = {};
+    { const fquad q = cq[0]; cf[0] = q.x; cf[1] = q.y; cf[2] = q.z; cf[3] = q.w; }
+    if constexpr (ntap > 4) { const fquad q = cq[1]; cf[4] = q.x; cf[5] = q.y; cf[6] = q.z; cf[7] = q.w; }
+    if constexpr (ntap > 8) { const fquad q = cq[2]; cf[8] = q.x; cf[9] = q.y; cf[10] = q.z; cf[11] = q.w; }
+    (bar_tap<C2, DZ, DY, Is>(acc, v, cf), ...);
   }
-  // one scheduling region per (c2, dz) group of lines: left alone the scheduler hoists all 135 reads of a plane to the
-  // top (270 VGPRs: spills); a group is <= 15 reads in flight over ~150 FMAs, and the other wave of the SIMD covers the rest
+  // one scheduling region per (c2, dz) group of lines: left alone the scheduler hoists all reads of a plane to the
+  // top (spills); a group is <= 15 window reads in flight over ~150 FMAs, and the other wave of the SIMD covers the rest
   if constexpr (DY == 2 && (BAR_SCHED_GROUP == 1 || (BAR_SCHED_GROUP == 5 && DZ == 2))) __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int... Ls> // L = (c2 * 5 + dz + 2) * 5 + dy + 2
 __device__ __forceinline__ void bar_apply(std::integer_sequence<int, Ls...>, float (&acc)[2][3], const fpair* tile,
-  const int (&sbase)[kZW], int lbase, UniformFloats coef)
+  const int (&sbase)[5], int lbase, const fquad* ctab)
 {
-  (bar_line<Ls / 25, (Ls / 5) % 5 - 2, Ls % 5 - 2>(std::make_integer_sequence<int, 15>{}, acc, tile, sbase, lbase, coef), ...);
+  (bar_line<Ls / 25, (Ls / 5) % 5 - 2, Ls % 5 - 2>(std::make_integer_sequence<int, 15>{}, acc, tile, sbase, lbase, ctab), ...);
 }
 
-template <bool FIRST, bool LAST>
+// PAIR: nx is even -- every lane's two nodes (x, x + 1; x even) and every window pair are one aligned 8-byte (fp32) or
+// 16-byte (fp64) access; odd nx takes the scalar accesses
+template <bool FIRST, bool LAST, bool PAIR>
 __global__ void __launch_bounds__(kB, 2) k_cheb_bar(GridDev g, const float* __restrict__ coef_, const double* __restrict__ r64,
   float* __restrict__ r32, const float* __restrict__ zin, float* __restrict__ d, float* __restrict__ zout,
   double* __restrict__ out64, double cd, double cr, double itheta, int nbx, int nby, int zc)
 {
   __shared__ __attribute__((aligned(16))) fpair tile2[kZW * kPlaneF / 2];
-  float* tile = (float*)tile2;
-  UniformFloats coef = (UniformFloats)coef_;
+  __shared__ __attribute__((aligned(16))) fquad ctab[kLinesUsed * kCoefPitch / 4];
+  for (int i = threadIdx.x; i < kLinesUsed * kCoefPitch; i += kB) ((float*)ctab)[i] = coef_[i]; // packed by k_abar
   const int lane = threadIdx.x & 63, wy = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bx = blockIdx.x % nbx, by = (blockIdx.x / nbx) % nby, bz = blockIdx.x / (nbx * nby);
   const int x0 = bx * kTX, y0 = by * kTY, z0 = bz * zc;
   const int z1 = min(z0 + zc, g.nzl);
   if (z0 >= z1) return;
 
-  auto load_plane = [&](int p) { // unwrapped owned-plane number p in [-2, nzl + 1]
-    const int slot = (p - z0 + 2) % kZW;
-    const long zoff = (long)g.wz(p) * g.plane;
-    float* dst = tile + slot * kPlaneF;
-    for (int i = threadIdx.x; i < kPlaneF; i += kB) {
-      const int comp = i / (kPY * kPX), rem = i % (kPY * kPX), yy = rem / kPX, xx = rem % kPX;
+  // this thread's share of a window plane: pairs e = thread + k * 256 of [3][kPY][kPX / 2]; their offsets inside a
+  // z-plane of the vector (periodic in x and y) are fixed for the whole march
+  constexpr int kPairs = kPlaneF / 2, kPerP = (kPairs + kB - 1) / kB;
+  int goff[kPerP];
+#pragma unroll
+  for (int k = 0; k < kPerP; ++k) {
+    const int i = threadIdx.x + k * kB;
+    goff[k] = -1;
+    if (i < kPairs) {
+      const int comp = i / (kPY * kPX / 2), rem = i % (kPY * kPX / 2), yy = rem / (kPX / 2), xx = 2 * (rem % (kPX / 2));
       int gx = (x0 - kH + xx) % g.nx, gy = (y0 - kH + yy) % g.ny;
       gx += gx < 0 ? g.nx : 0;
       gy += gy < 0 ? g.ny : 0;
-      const long src = comp * g.cstride + zoff + (long)gy * g.nx + gx;
-      dst[i] = FIRST ? (float)r64[src] : zin[src];
+      goff[k] = (int)(comp * g.cstride + (long)gy * g.nx + gx); // a component-major vector has < 2^31 elements
+    }
+  }
+  const int nxm = g.nx; // (odd nx: the pair's second node is the wrapped x + 1)
+  auto fetch = [&](int p, fpair (&v)[kPerP]) { // unwrapped owned-plane number p in [-2, nzl + 1] (clamped reads beyond)
+    const long zoff = (long)g.wz(min(p, g.nzl + 1)) * g.plane;
+#pragma unroll
+    for (int k = 0; k < kPerP; ++k) {
+      v[k] = fpair{0.f, 0.f};
+      if (goff[k] < 0) continue;
+      const long o = zoff + goff[k];
+      if (PAIR) {
+        if (FIRST) { const dpairv t = *reinterpret_cast<const dpairv*>(r64 + o); v[k] = fpair{(float)t.x, (float)t.y}; }
+        else v[k] = *reinterpret_cast<const fpair*>(zin + o);
+      }
+      else {
+        // second node: x + 1 wrapped inside its row
+        const int gx = (int)((o - zoff) % nxm);
+        const long o1 = gx + 1 < nxm ? o + 1 : o + 1 - nxm;
+        v[k] = FIRST ? fpair{(float)r64[o], (float)r64[o1]} : fpair{zin[o], zin[o1]};
+      }
     }
   };
+  auto store = [&](int p, const fpair (&v)[kPerP]) {
+    fpair* dst = tile2 + ((p - z0 + 2) % kZW) * kPairs + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < kPerP; ++k)
+      if (goff[k] >= 0) dst[k * kB] = v[k];
+  };
 
-  for (int p = z0 - 2; p < z0 + 2; ++p) load_plane(p);
+  // The window holds 6 planes: compute(z) reads z - 2 .. z + 2 while plane z + 3 (requested an iteration earlier, kept in
+  // registers meanwhile) is written into the slot plane z - 3 left -- ONE barrier per plane, in front of that write, and
+  // the global latency of a plane runs under the FMAs of the previous one.
+  fpair nxt[kPerP];
+  for (int p = z0 - 2; p <= z0 + 2; ++p) { fetch(p, nxt); store(p, nxt); }
+  fetch(z0 + 3, nxt);
   const int x = x0 + 2 * lane, y = y0 + wy;
-  const bool row_ok = y < g.ny;
+  const bool row_ok = y < g.ny && x < g.nx;
+  const bool two = x + 1 < g.nx;
   for (int z = z0; z < z1; ++z) {
-    load_plane(z + 2);
-    __syncthreads();
-    if (row_ok) { // (rows beyond ny only help loading the window)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // every wave is done with plane z - 3 (and sees z + 2)
+    store(z + 3, nxt);
+    if (z + 1 < z1) fetch(z + 4, nxt);
+    if (row_ok) { // (rows beyond ny, lanes beyond nx only help loading the window)
+      // the right-hand side and the direction of this lane's two nodes are requested BEFORE the stencil sums: their HBM
+      // latency runs under the 738 FMAs instead of behind them
+      const long oc0 = (long)g.wz(z) * g.plane + (long)y * g.nx + x;
+      fpair rv2[3], dv2[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const long oc = c * g.cstride + oc0;
+        if (PAIR) {
+          if (FIRST) { const dpairv t = *reinterpret_cast<const dpairv*>(r64 + oc); rv2[c] = fpair{(float)t.x, (float)t.y}; }
+          else { rv2[c] = *reinterpret_cast<const fpair*>(r32 + oc); dv2[c] = *reinterpret_cast<const fpair*>(d + oc); }
+        }
+        else {
+          if (FIRST) rv2[c] = fpair{(float)r64[oc], two ? (float)r64[oc + 1] : 0.f};
+          else { rv2[c] = fpair{r32[oc], two ? r32[oc + 1] : 0.f}; dv2[c] = fpair{d[oc], two ? d[oc + 1] : 0.f}; }
+        }
+      }
       float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-      int sbase[kZW]; // float offset of the window plane of z + dz
+      int sbase[5]; // float offset of the window plane of z + dz
 #pragma unroll
       for (int dz = -2; dz <= 2; ++dz) sbase[dz + 2] = ((z + dz - z0 + 2) % kZW) * kPlaneF;
       const int lbase = (wy + kH) * kPX + 2 * lane;
-      // the 369 coefficients are re-read through the scalar cache for every plane: hoisted out of the march they would
-      // need 369 SGPRs (the compiler then parks them in VGPR lanes and pays a v_readlane per use)
-      asm volatile("" : "+s"(coef));
-      bar_apply(std::make_integer_sequence<int, 75>{}, acc, tile2, sbase, lbase, coef);
-      // pin the sums here: their only users sit behind the x < nx tests below, and the optimizer otherwise sinks all 738
-      // FMAs there while the 135 LDS reads stay in front (270 live VGPRs: spills)
+      bar_apply(std::make_integer_sequence<int, 75>{}, acc, tile2, sbase, lbase, ctab);
+      // pin the sums here: their only users sit behind the stores below, and the optimizer otherwise sinks all 738 FMAs
+      // there while the 135 LDS reads stay in front (270 live VGPRs: spills)
       asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]));
-      const long zoff = (long)g.wz(z) * g.plane + (long)y * g.nx;
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        if (x + e >= g.nx) continue;
+      for (int c = 0; c < 3; ++c) {
+        const long oc = c * g.cstride + oc0;
+        const fpair zc2 = tile2[(sbase[2] + c * kPY * kPX + lbase + kH) / 2]; // the window's centre values
+        float dn[2], zn[2];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const long oc = c * g.cstride + zoff + x + e;
-          const double rv = FIRST ? r64[oc] : (double)r32[oc];
-          const double zc0 = (double)tile[sbase[2] + c * kPY * kPX + lbase + kH + e]; // the window's centre value
-          const double zv = FIRST ? rv * itheta : zc0;
-          const double m = FIRST ? (double)acc[e][c] * itheta : (double)acc[e][c];
-          const double dn = cd * (FIRST ? zv : (double)d[oc]) + cr * (rv - m);
-          if (FIRST && !LAST) r32[oc] = (float)rv;
-          if (LAST) out64[oc] = zv + dn;
-          else {
-            d[oc] = (float)dn;
-            zout[oc] = (float)(zv + dn);
+        for (int e = 0; e < 2; ++e) {
+          const float rv = e ? rv2[c].y : rv2[c].x;
+          // FIRST: z0 = r / theta and Abar z0 = (Abar r) / theta
+          const float zv = FIRST ? rv * (float)itheta : (e ? zc2.y : zc2.x);
+          const float m = FIRST ? acc[e][c] * (float)itheta : acc[e][c];
+          dn[e] = (float)cd * (FIRST ? zv : (e ? dv2[c].y : dv2[c].x)) + (float)cr * (rv - m);
+          zn[e] = zv + dn[e];
+        }
+        if (PAIR) {
+          if (FIRST && !LAST) *reinterpret_cast<fpair*>(r32 + oc) = rv2[c];
+          if (LAST) *reinterpret_cast<dpairv*>(out64 + oc) = dpairv{(double)zn[0], (double)zn[1]};
+          else { *reinterpret_cast<fpair*>(d + oc) = fpair{dn[0], dn[1]}; *reinterpret_cast<fpair*>(zout + oc) = fpair{zn[0], zn[1]}; }
+        }
+        else {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            if (e && !two) continue;
+            if (FIRST && !LAST) r32[oc + e] = e ? rv2[c].y : rv2[c].x;
+            if (LAST) out64[oc + e] = (double)zn[e];
+            else { d[oc + e] = dn[e]; zout[oc + e] = zn[e]; }
           }
         }
       }
     }
-    __syncthreads(); // the next load overwrites the slot of plane z - 2
   }
 }
 
@@ -251,8 +360,9 @@ int abar_update(xpic_ctx* c)
   const int nys = (g.ny + sy - 1) / sy, nzs = (g.nzl + sz - 1) / sz;
   const int nrows = nys * nzs;
   if (!c->abar32) {
-    XPIC_HIP(hipMalloc(&c->abar32, sizeof(float) * 3 * kLPad));
-    XPIC_HIP(hipMalloc(&c->abar_work, sizeof(double) * (3 * kLPad * 3 + (size_t)nrows * 3 * kLBlock)));
+    XPIC_HIP(hipMalloc(&c->abar32, sizeof(float) * kLinesUsed * kCoefPitch));
+    XPIC_HIP(hipMemsetAsync(c->abar32, 0, sizeof(float) * kLinesUsed * kCoefPitch, c->stream));
+    XPIC_HIP(hipMalloc(&c->abar_work, sizeof(double) * (3 * kLPad * 3 + ((size_t)nrows + kSegs) * 3 * kLBlock)));
     double mco[3 * kLPad];
     matM_stencil(g, mco);
     XPIC_HIP(hipMemcpy(c->abar_work + 3 * kLPad, mco, sizeof(mco), hipMemcpyHostToDevice));
@@ -262,7 +372,9 @@ int abar_update(xpic_ctx* c)
   double* abar64 = c->abar_work + 6 * kLPad;
   double* partial = c->abar_work + 9 * kLPad;
   hipLaunchKernelGGL(k_lbar_rows, dim3(nrows, 3), dim3(512), 0, c->stream, g, c->matL, sy, sz, nys, partial);
-  hipLaunchKernelGGL(k_lbar_final, dim3(3), dim3(512), 0, c->stream, partial, nrows, sums);
+  double* segsum = partial + (size_t)nrows * 3 * kLBlock;
+  hipLaunchKernelGGL(k_lbar_segments, dim3(3, kSegs), dim3(512), 0, c->stream, partial, nrows, segsum);
+  hipLaunchKernelGGL(k_lbar_final, dim3(3), dim3(512), 0, c->stream, segsum, sums);
   XPIC_HIP(hipGetLastError());
   XPIC_CALL(comm_allreduce_sum(c, sums, 3 * kLPad)); // the same surrogate on every slab
   const double count = (double)nrows * g.nx * c->comm.nranks;
@@ -316,7 +428,13 @@ int cheb_abar_inverse(xpic_ctx* c, const double* r, double* out)
     const bool first = i == 1, last = i == degree - 1;
     if (first) XPIC_CALL(halo_fill(c, const_cast<double*>(r), 2));
     else XPIC_CALL(halo_fill_f32(c, z0, 2));
-#define LAUNCH(F, L) hipLaunchKernelGGL((k_cheb_bar<F, L>), grid, block, 0, c->stream, g, c->abar32, r, r32, z0, d, z1, out, cd, cr, it, nbx, nby, zc)
+#define LAUNCH(F, L)                                                                                                        \
+  do {                                                                                                                      \
+    if (g.nx % 2 == 0) hipLaunchKernelGGL((k_cheb_bar<F, L, true>), grid, block, 0, c->stream, g, c->abar32, r, r32, z0, d,  \
+      z1, out, cd, cr, it, nbx, nby, zc);                                                                                   \
+    else hipLaunchKernelGGL((k_cheb_bar<F, L, false>), grid, block, 0, c->stream, g, c->abar32, r, r32, z0, d, z1, out, cd,  \
+      cr, it, nbx, nby, zc);                                                                                                \
+  } while (0)
     if (first && last) LAUNCH(true, true);
     else if (first) LAUNCH(true, false);
     else if (last) LAUNCH(false, true);
