@@ -90,9 +90,12 @@ constexpr int kOffAB = 24; // [24, 33): A_p*matB row-major, [33, 36): I_p
 constexpr int kStage = kCP * kPitch;
 constexpr int kAcc = 36;          // accumulators per lane: 30 matL (component pair x octant bits of the pair) + 6 currI
 typedef double mfma_acc __attribute__((ext_vector_type(4)));
+typedef double dpair __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) double GlobalDouble; // matL / currI are global memory: a pointer rebuilt from an
+// integer is 'flat' to the compiler, and flat loads also count in lgkmcnt -- the LDS-only barriers then wait for HBM
+typedef __attribute__((address_space(1))) dpair GlobalPair;
 typedef __attribute__((address_space(3))) const char* LdsBytes; // LDS addresses are 32 bits: say so where address arithmetic is hot
 typedef __attribute__((address_space(3))) double LdsDouble;
-typedef double dpair __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) dpair LdsDouble2;
 constexpr int kMatLines = 816;    // distinct (c1, row dy, row dz, k) streams one pencil can touch
 constexpr int kCurLines = 16;     // (c, dy, dz) streams of currI
@@ -263,7 +266,8 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
       pf.cnt = __builtin_amdgcn_readfirstlane(cstart[cx + 1]) - pf.start;
     }
     else {
-      // wave-uniform index: a scalar load (cell_start does not change while this kernel runs)
+      // wave-uniform index: a scalar load (cell_start does not change while this kernel runs; requesting it a chunk
+      // ahead of the particle loads it addresses was measured: no change)
       using UniformInts = const __attribute__((address_space(4))) int*;
       UniformInts cs = (UniformInts)(s.cell_start + pencil0);
       const int cxu = __builtin_amdgcn_readfirstlane(cx);
@@ -498,7 +502,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     const bool alias = !FX && alias_rows != 0;
     const bool vecL = FX || (ndone == kW && !alias), vecI = FX || (vecL && (g.nx & 1) == 0);
     double old[kOwn][kW];
-    double* ptr[kOwn];
+    GlobalDouble* ptr[kOwn];
     bool fst[kOwn];
 #pragma unroll
     for (int mm = 0; mm < kOwn; ++mm) {
@@ -506,14 +510,14 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
       const uintptr_t lb = lbase[mm];
       fst[mm] = lb & 1;
       const bool vec = line < kMatLines ? vecL : vecI;
-      ptr[mm] = lb ? (double*)(lb & ~(uintptr_t)1) + (long)j * (line < kMatLines ? kLBlock : kW) : nullptr;
+      ptr[mm] = lb ? (GlobalDouble*)(lb & ~(uintptr_t)1) + (long)j * (line < kMatLines ? kLBlock : kW) : nullptr;
 #pragma unroll
       for (int c = 0; c < kW; ++c) old[mm][c] = 0.0;
       if (ptr[mm] && !fst[mm] && FILL_EXP != 8) {
         if (vec) {
 #pragma unroll
           for (int c = 0; c < kW; c += 2) {
-            const double2 v = *(const double2*)(ptr[mm] + c);
+            const dpair v = *(const GlobalPair*)(ptr[mm] + c);
             old[mm][c] = v.x; old[mm][c + 1] = v.y;
           }
         }
@@ -598,12 +602,12 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
           if (vec) {
 #pragma unroll
             for (int c = 0; c < kW; c += 2)
-              *(double2*)(ptr[mm] + c) = double2{old[mm][c] + w[c], old[mm][c + 1] + w[c + 1]};
+              *(GlobalPair*)(ptr[mm] + c) = dpair{old[mm][c] + w[c], old[mm][c + 1] + w[c + 1]};
           }
           else if (alias) {
 #pragma unroll
             for (int c = 0; c < kW; ++c)
-              if (c < ndone && w[c] != 0.0) unsafeAtomicAdd(ptr[mm] + c, w[c]);
+              if (c < ndone && w[c] != 0.0) unsafeAtomicAdd((double*)(ptr[mm] + c), w[c]);
           }
           else {
 #pragma unroll

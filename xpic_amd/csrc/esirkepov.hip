@@ -60,7 +60,11 @@ constexpr int kSeg = 8;               // cells (segments) per round
 #ifndef ESK_COLS1
 #define ESK_COLS1 160
 #endif
+#ifndef ESK_SEG0
+#define ESK_SEG0 16
+#endif
 template <int MODE> struct StageDim {
+  static constexpr int kSegM = MODE == 0 ? ESK_SEG0 : 8; // cells (segments) per round
   static constexpr int kCols = MODE == 1 ? ESK_COLS1 : 240;
   static constexpr int kPitch = kCols + 4; // row pitch: 4 rows x 4 columns of a phase-2 read fall in 16 distinct bank pairs (pitch = 4 mod 8)
   static_assert(kCols % 4 == 0 && kCols <= kThreadsB && kPitch % 8 == 4, "stage geometry");
@@ -120,14 +124,15 @@ __device__ inline double lane_value(double v, int src)
 
 // One round of a pencil: up to kSeg segments, each the (rest of the) particles of one cell.  A cell with more particles
 // than a round holds is continued in the next round (then alone in its round's first segment).
+constexpr int kSegMax = 16;
 struct RoundTab {
   int base;            // first cell of the round: the J window's column 0 is node base - 1
   int nseg, ncols, tcount;
   int adv;             // cells completed by the round: the window moves on by this many columns
-  int cell[kSeg];      // cell - base
-  int start[kSeg];     // first particle
-  int col0[kSeg + 1];  // first stage column (multiple of 4)
-  int toff[kSeg + 1];  // first thread
+  int cell[kSegMax];      // cell - base
+  int start[kSegMax];     // first particle
+  int col0[kSegMax + 1];  // first stage column (multiple of 4)
+  int toff[kSegMax + 1];  // first thread
 };
 
 // what a thread requests one round ahead: its particle of the next round (and, MODE 2, its share of the cells' CIC
@@ -149,6 +154,14 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
 {
   // workgroup -> the x-pencil (cy, cz), marched in rounds
   constexpr int kCols = StageDim<MODE>::kCols, kPitch = StageDim<MODE>::kPitch;
+  // cells per round.  MODE 0 takes up to 16: BASELINE configs[1] is two species of 16 ppc, and a round of 8 such cells
+  // fills half of the 256 lanes (the instruction stream of a round costs the same); the names below shadow the
+  // namespace-scope values that MODE 1 and 2 keep.
+  constexpr int kSeg = StageDim<MODE>::kSegM;
+  constexpr int kJX = kSeg + kD - 1, kJN = kJX * kD * kD, kJPer = (3 * kJN + kThreadsB - 1) / kThreadsB;
+  constexpr int kTX = kSeg + kT - 1, kTileN = kTX * kT * kT, kFtPer = (6 * kTileN + kThreadsB - 1) / kThreadsB;
+  static_assert(kSeg <= kCellStartPad && kSeg <= kSegMax, "compose reads kSeg entries ahead");
+  static_assert(MODE != 0 || 6 * kTileN <= kSRows * kPitch, "the gather tile shares the stage's LDS");
   const int cy = blockIdx.x % g.ny;
   const int cz = blockIdx.x / g.ny;
   // the wave index is wave-uniform: said explicitly, the K-step ranges and segment walks of phase 2 become scalar code
@@ -256,7 +269,7 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
     P += __builtin_amdgcn_update_dpp(0, P, 0x111, 0xf, 0xf, true); Q += __builtin_amdgcn_update_dpp(0, Q, 0x111, 0xf, 0xf, true);
     P += __builtin_amdgcn_update_dpp(0, P, 0x112, 0xf, 0xf, true); Q += __builtin_amdgcn_update_dpp(0, Q, 0x112, 0xf, 0xf, true);
     P += __builtin_amdgcn_update_dpp(0, P, 0x114, 0xf, 0xf, true); Q += __builtin_amdgcn_update_dpp(0, Q, 0x114, 0xf, 0xf, true);
-    static_assert(kSeg == 8, "three row shifts cover eight lanes");
+    static_assert(MODE != 1 || kSeg == 8, "three row shifts cover eight lanes");
     const unsigned some = (unsigned)__ballot(cnt > 0) & ((1u << kSeg) - 1u);
     const int first = some ? __ffs(some) - 1 : kSeg;
     int nseg, ncols, tcount;
@@ -287,7 +300,7 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
     }
   };
   auto compose = [&](RoundTab& T) {
-    if (MODE == 1) compose_lanes(T);
+    if constexpr (MODE == 1) compose_lanes(T);
     else compose_scalar(T);
   };
 
