@@ -70,19 +70,13 @@ template <int MODE> struct StageDim {
   static_assert(kCols % 4 == 0 && kCols <= kThreadsB && kPitch % 8 == 4, "stage geometry");
 };
 constexpr int kD = 4;                 // deposit box per axis: nodes c-1 .. c+2
-constexpr int kJX = kSeg + kD - 1;    // J window nodes along x
-constexpr int kJN = kJX * kD * kD;
-constexpr int kJPer = (3 * kJN + kThreadsB - 1) / kThreadsB; // window elements per thread
+// (J window: kSeg + kD - 1 nodes along x; gather tile: kSeg + kT - 1; both sized per MODE inside the kernel)
 constexpr int kSRows = 36;            // So[3][4], Sn[3][4], P[3][4]
 constexpr int kT = 6;                 // gather tile per axis (MODE 0): nodes c-2 .. c+3
-constexpr int kTX = kSeg + kT - 1;
-constexpr int kTileN = kTX * kT * kT;
-constexpr int kFtPer = (6 * kTileN + kThreadsB - 1) / kThreadsB; // gather-tile values per thread
 constexpr int kLinesB = 3 * kD * kD;  // 48 lines of 4 nodes
 constexpr int kNb = 36 + 54;          // CIC neighbourhood of a cell (MODE 2): 3 x 12 E nodes, 54 B nodes
 constexpr int kNbPer = (kSeg * kNb + kThreadsB - 1) / kThreadsB;
 static_assert(kSeg <= kCellStartPad, "compose reads kSeg entries ahead");
-static_assert(6 * kTileN <= kSRows * StageDim<0>::kPitch, "the gather tile shares the stage's LDS");
 
 // raw workgroup barrier that only drains LDS traffic: the particle stores, the J atomics and the requests of the next
 // round stay in flight across it (__syncthreads() would wait for every one of them: a round trip to HBM per round)
