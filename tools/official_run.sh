@@ -1,5 +1,5 @@
 # official artifacts of a build: GPU tests, bench lines, rocprofv3 kernel stats, PMC traffic (separate passes)
-# usage: tools/official_run.sh <tag> [part]   part: all | tests | ecsim | side | sq | rehearsal
+# usage: tools/official_run.sh <tag> [part]   part: all | tests | ecsim | side | cfg4 | sq | rehearsal
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r02}
@@ -22,6 +22,15 @@ fi
 if [ $PART = all ] || [ $PART = side ]; then
   bash tools/profile_scheme.sh basic 128 32 $TAG 0.1 || exit 1
   bash tools/profile_scheme.sh ecsimcorr 128 32 $TAG 1.0 || exit 1
+fi
+if [ $PART = all ] || [ $PART = cfg4 ]; then
+  # one GPU's real share of BASELINE configs[4]: ecsimcorr, 512 x 512 x 64 cells x 32 ppc (537 M particles) as one periodic box
+  A="--scheme ecsimcorr --grid-xyz 512 512 64 --ppc 32 --steps 5 --warmup 2"
+  timeout -k 10 600 python bench.py $A > gpurun_out/bench_cfg4_$TAG.json 2> gpurun_out/bench_cfg4_$TAG.err || { tail gpurun_out/bench_cfg4_$TAG.err; exit 1; }
+  cut -c1-300 gpurun_out/bench_cfg4_$TAG.json
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $R/gpurun_out/prof_cfg4_$TAG && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cfg4_$TAG -- python3 $R/bench.py $A --no-cpu-baseline > $R/gpurun_out/prof_cfg4_$TAG.log 2>&1 || exit 1
+  cd $R
 fi
 if [ $PART = all ] || [ $PART = sq ]; then
   bash tools/pmc_sq.sh $TAG > /dev/null || exit 1
