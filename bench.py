@@ -304,10 +304,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         rdv = os.environ.get("XPIC_BENCH_RDV")  # set by launch_ranks: file rendezvous; under torch.distributed.run: env://
         kw = dict(init_method="file://" + rdv) if rdv else {}
-        if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world, **kw)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), **kw)
+        # stdout carries exactly ONE line (rank 0's JSON): the transports' own connection chatter goes to stderr
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if rehearsal:
+                dist.init_process_group("gloo", rank=rank, world_size=world, **kw)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), **kw)
+            dist.barrier()
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
 
     import numpy as np
     import xpic_amd as X
