@@ -102,6 +102,15 @@ constexpr int kCurLines = 16;     // (c, dy, dz) streams of currI
 constexpr int kLines = kMatLines + kCurLines;
 constexpr int kThreads = kW * 64;
 constexpr int kSlots = kW + 2;    // window columns: kW finished + 2 carried
+#ifndef FILL_WPITCH
+#define FILL_WPITCH 7
+#endif
+// doubles between two window lines (>= kSlots).  The merge's 36 ds_add_f64 per lane hit lines that lie multiples of 8 apart:
+// with the natural pitch of 6 doubles those share their banks (line * 12 dwords mod 32 has period 8), an odd pitch cycles
+// through all 16 bank pairs.  Per assembly: pitch 6 106.6 ms, 7 101.5, 9 102.8, 8 138.3 (the seed and the flush give up
+// their 16-byte window accesses for it).
+constexpr int kWP = FILL_WPITCH;
+static_assert(kWP >= kSlots, "window pitch");
 constexpr int kOwn = (kLines + kThreads - 1) / kThreads; // window lines owned by a thread (init, flush, carry)
 #ifndef FILL_LEAN_LDS
 #define FILL_LEAN_LDS 1 // 1: the per-lane window offsets and the cell_start row are read from global memory (five 16-byte
@@ -131,7 +140,7 @@ __host__ __device__ constexpr int row_of(int c, int g, int i)
   return 24 + (g * 2 + (i >> 1)) * 2 + (i & 1);                  // i = j * 2 + ix
 }
 
-static_assert(kLines * kSlots <= kW * kStage, "the merge window must fit in the (dead) staging area");
+static_assert(kLines * kWP <= kW * kStage, "the merge window must fit in the (dead) staging area");
 
 __device__ inline void wave_sync()
 {
@@ -559,10 +568,18 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     for (int mm = 0; mm < kOwn; ++mm) {
       const int line = threadIdx.x + mm * kThreads;
       if (line < kLines) {
-        double2* w = (double2*)(win + line * kSlots);
-        w[0] = double2{carry[mm][0], carry[mm][1]};
+        if (kWP % 2 == 0) {
+          double2* w = (double2*)(win + line * kWP);
+          w[0] = double2{carry[mm][0], carry[mm][1]};
 #pragma unroll
-        for (int c = 1; c < kSlots / 2; ++c) w[c] = double2{0.0, 0.0};
+          for (int c = 1; c < kSlots / 2; ++c) w[c] = double2{0.0, 0.0};
+        }
+        else {
+          double* w = win + line * kWP;
+          w[0] = carry[mm][0]; w[1] = carry[mm][1];
+#pragma unroll
+          for (int c = 2; c < kSlots; ++c) w[c] = 0.0;
+        }
       }
     }
     lds_barrier();
@@ -586,9 +603,15 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
       const int line = threadIdx.x + mm * kThreads;
       if (line < kLines) {
         double w[kSlots];
-        const double2* wp = (const double2*)(win + line * kSlots);
+        if (kWP % 2 == 0) {
+          const double2* wp = (const double2*)(win + line * kWP);
 #pragma unroll
-        for (int c = 0; c < kSlots / 2; ++c) { const double2 v = wp[c]; w[2 * c] = v.x; w[2 * c + 1] = v.y; }
+          for (int c = 0; c < kSlots / 2; ++c) { const double2 v = wp[c]; w[2 * c] = v.x; w[2 * c + 1] = v.y; }
+        }
+        else {
+#pragma unroll
+          for (int c = 0; c < kSlots; ++c) w[c] = win[line * kWP + c];
+        }
         const bool vec = line < kMatLines ? vecL : vecI;
         // lines without a contribution from this chunk are left alone (vacuum stays exactly zero and costs no write);
         // the full-chunk instantiation skips the test: in a plasma every line has one
@@ -726,8 +749,8 @@ int build_ltab(xpic_ctx* c)
   // own cell's column); elements without a target point at a per-lane dummy double behind the window
   std::vector<unsigned short> dtab(kAcc * 64);
   for (int e = 0; e < kAcc; ++e)
-    for (int lane = 0; lane < 64; ++lane) dtab[e * 64 + lane] = (unsigned short)(kLines * kSlots + lane);
-  auto wbyte = [](int d) { return (unsigned short)((d >> 2) * kSlots + (d & 3)); };
+    for (int lane = 0; lane < 64; ++lane) dtab[e * 64 + lane] = (unsigned short)(kLines * kWP + lane);
+  auto wbyte = [](int d) { return (unsigned short)((d >> 2) * kWP + (d & 3)); };
   std::vector<int> seen(kAcc, 0);
   for (int o = 0; o < 8; ++o) {
     const int ob[3] = {o & 1, (o >> 1) & 1, (o >> 2) & 1};
@@ -751,9 +774,9 @@ int build_ltab(xpic_ctx* c)
     for (int c1 = 0; c1 < 3; ++c1)
       for (int c2 = 0; c2 < 3; ++c2) seen[acc_main(c1, c2, o)] = 1;
   }
-  static_assert((kLines * kSlots + 64) <= kW * kStage, "the dummy doubles must lie inside the stage area");
+  static_assert((kLines * kWP + 64) <= kW * kStage, "the dummy doubles must lie inside the stage area");
   if (FILL_LEAN_LDS) { // [lane][kDtabPitch] instead of [e][64], and BYTE offsets (one add per atomic in the kernel)
-    static_assert((kLines * kSlots + 64 + kW) * 8 <= 0xffff, "window byte offsets must fit 16 bits");
+    static_assert((kLines * kWP + 64 + kW) * 8 <= 0xffff, "window byte offsets must fit 16 bits");
     std::vector<unsigned short> t(64 * kDtabPitch, 0);
     for (int e = 0; e < kAcc; ++e)
       for (int lane = 0; lane < 64; ++lane) t[lane * kDtabPitch + e] = (unsigned short)(8 * dtab[e * 64 + lane]);
