@@ -167,14 +167,17 @@ struct Prefetch {
 //   Bx at (xn in cx..cx+1, ys in cy-1..cy+1, zs in cz-1..cz+1)   -> [ 0,18): (kl*3 + jl)*2 + i
 //   By at (xs in cx-1..cx+1, yn in cy..cy+1, zs in cz-1..cz+1)   -> [18,36): (kl*2 + j)*3 + il
 //   Bz at (xs in cx-1..cx+1, ys in cy-1..cy+1, zn in cz..cz+1)   -> [36,54): (k*3 + jl)*3 + il
-__device__ inline double load_bnb(const GridDev& g, const double* __restrict__ B, int lane, int cx, int cy, int cz)
+// lane's entry of the table: the row of B it lies in (fixed for a pencil) and its x offset from the cell
+__device__ inline const double* bnb_row(const GridDev& g, const double* __restrict__ B, int lane, int cy, int cz, int* ox_out)
 {
-  if (lane >= 54) return 0.0;
+  *ox_out = 0;
+  if (lane >= 54) return nullptr;
   int c, ox, oy, oz;
   if (lane < 18) { c = 0; ox = lane % 2; oy = (lane / 2) % 3 - 1; oz = lane / 6 - 1; }
   else if (lane < 36) { const int l = lane - 18; c = 1; ox = l % 3 - 1; oy = (l / 3) % 2; oz = l / 6 - 1; }
   else { const int l = lane - 36; c = 2; ox = l % 3 - 1; oy = (l / 3) % 3 - 1; oz = l / 9; }
-  return B[c * g.cstride + g.nodew(cx + ox, cy + oy, cz + oz)];
+  *ox_out = ox;
+  return B + c * g.cstride + g.node(0, g.wy(cy + oy), g.wz(cz + oz));
 }
 
 // P2: power-of-two spacings (exact reciprocals, device_common.h); FX: nx is a multiple of the chunk width, so every
@@ -266,6 +269,8 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
 
   // cells are visited in the order 1, 2, ..., nx-1, 0 so that finished columns start 64-byte aligned
   auto cell_x = [&](int i) { return (i + 1 == g.nx) ? 0 : i + 1; };
+  int box;
+  const double* const brow = bnb_row(g, B, lane, cy, cz, &box); // this lane's value of a cell's B neighbourhood: row, x offset
   auto prefetch_cell = [&](int i, Prefetch& pf) {
     pf.start = 0; pf.cnt = 0; pf.b = 0.0;
     if (i >= g.nx) return;
@@ -283,7 +288,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
       pf.start = cs[cxu];
       pf.cnt = cs[cxu + 1] - pf.start;
     }
-    pf.b = load_bnb(g, B, lane, cx, cy, cz);
+    pf.b = brow ? brow[g.wx(cx + box)] : 0.0;
     if (lane < min(kCP, pf.cnt)) {
       const long p = (long)pf.start + lane;
 #pragma unroll
@@ -360,6 +365,8 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
           }
         }
         if (real) {
+          // (shifting the odd-ranked particles of an octant by 16 bytes inside their slot, so that the two particles whose
+          // operand reads share an LDS cycle in phase 2 sit 16 instead of 12 banks apart, was measured: 98.9 against 98.1 ms)
           double2* dst = (double2*)(st + slot * kPitch);
           // The 24 values of the cell's B neighbourhood this particle's octant touches are requested FIRST (their
           // addresses depend on the octant alone) and consumed last: the LDS latency runs under the 36 weight products
@@ -591,6 +598,8 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
       char* wv = (char*)(win + wave);
 #pragma unroll
       for (int e = 0; e < kAcc; ++e) {
+        // (masking out the lanes of the six currI accumulators that have no target, instead of letting them add into their
+        // dummy doubles, was measured: no difference)
         unsafeAtomicAdd((double*)(wv + (FILL_LEAN_LDS ? wdst[e] : 8 * wdst[e])), acc[e]);
         acc[e] = 0.0;
       }
