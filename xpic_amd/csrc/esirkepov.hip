@@ -175,6 +175,7 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
   // this thread's entries e = thread + i * kThreadsB of the kSeg x 90 neighbourhood table (MODE 2): segment, field
   // component and node offset, numbered as in k_second_push; packed seg | comp << 4 | isB << 6 | (d + 1) << 8, 10, 12
   int nbd[MODE == 2 ? kNbPer : 1];
+  const double* nbrow[MODE == 2 ? kNbPer : 1];
   if (MODE == 2) {
 #pragma unroll
     for (int i = 0; i < kNbPer; ++i) {
@@ -197,6 +198,8 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
         else { const int l = kb - 36; comp = 2; d0 = l % 3 - 1; d1 = (l / 3) % 3 - 1; d2 = l / 9; }
       }
       nbd[i] = e < kSeg * kNb ? (sg | comp << 4 | isB << 6 | (d0 + 1) << 8 | (d1 + 1) << 10 | (d2 + 1) << 12) : -1;
+      // the row of E / B the entry lies in is fixed for the pencil: only its x position moves with the round
+      nbrow[i] = e < kSeg * kNb ? (isB ? B : E) + comp * g.cstride + g.node(0, g.wy(cy + d1), g.wz(cz + d2)) : nullptr;
     }
   }
 
@@ -323,8 +326,7 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
         const int d = nbd[i];
         if (d >= 0 && (d & 15) < nseg) {
           const int cx = base + T.cell[d & 15];
-          const double* F = ((d >> 6) & 1 ? B : E) + ((d >> 4) & 3) * g.cstride;
-          pf.nb[i] = F[g.nodew(cx + ((d >> 8) & 3) - 1, cy + ((d >> 10) & 3) - 1, cz + ((d >> 12) & 3) - 1)];
+          pf.nb[i] = nbrow[i][g.wx(cx + ((d >> 8) & 3) - 1)];
         }
       }
     }
