@@ -154,10 +154,14 @@ __global__ void __launch_bounds__(kBlock) k_scatter(GridDev g, SortDev s, int64_
   if (blk >= nblk) return;
   const int64_t p = blk * kBlock + threadIdx.x;
   if (p >= n) return;
+  // everything that does not depend on another load is requested together: the key, the arrival rank and the record
+  // (the compiler otherwise serialises key -> record -> cell_start -> rank: four dependent round trips per thread)
   const int c = s.cell[p];
-  if (c < 0) return;
+  const int rk = s.rank[p];
   double x = s.r[0][p], y = s.r[1][p], z = s.r[2][p];
   const double vx = s.v[0][p], vy = s.v[1][p], vz = s.v[2][p];
+  if (c < 0) return;
+  const int64_t d = (int64_t)s.cell_start[c] + rk;
   if (MOVE) {
     x += vx * step;
     y += vy * step;
@@ -168,7 +172,6 @@ __global__ void __launch_bounds__(kBlock) k_scatter(GridDev g, SortDev s, int64_
     y = bound_periodic(y, g.Ly);
     z = bound_periodic(z, g.Lz);
   }
-  const int64_t d = (int64_t)s.cell_start[c] + s.rank[p];
   s.r2[0][d] = x; s.r2[1][d] = y; s.r2[2][d] = z;
   s.v2[0][d] = vx; s.v2[1][d] = vy; s.v2[2][d] = vz;
 }
