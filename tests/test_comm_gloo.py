@@ -9,9 +9,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world", [2, 3])
+# 8 = the rank count of BASELINE configs[3] / [4]: the ring's neighbour arithmetic, tags and the all-reduce at the real size
+# (the GPU side of an 8-slab run is tests/test_gpu_slabs.py::test_eight_slabs_in_one_process: 8 contexts, 8 threads, one card)
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_gloo_ring_semantics(world):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(29611 + world), os.path.join(ROOT, "tests", "mp_ring_worker.py")]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)

@@ -106,3 +106,109 @@ def test_migration_overflow_fails_on_every_rank():
     for r, o in enumerate(outs):
         assert f"rank {r} error" in o and "migration buffer overflow" in o, o
     assert "of the z-slabs" in outs[1]
+
+
+class ThreadRing:
+    """The xpic_comm_callbacks transport between THREADS of one process: every rank's context lives in its own thread of
+    this process and the ring exchange / all-reduce are rendezvous on barriers.  One process on the GPU whatever the
+    number of ranks -- the way to run the 8 slabs of BASELINE configs[3] / [4] under the pool's limit of 6 processes per
+    card."""
+
+    def __init__(self, n):
+        import threading
+
+        self.n = n
+        self.bar = threading.Barrier(n, timeout=240)
+        self.down = [b""] * n
+        self.up = [b""] * n
+        self.red = [None] * n
+
+    def attach(self, ctx, rank):
+        import numpy as np
+
+        n = self.n
+        lo, hi = (rank - 1 + n) % n, (rank + 1) % n
+
+        def sendrecv(down, up, n_from_up, n_from_down):
+            self.down[rank], self.up[rank] = bytes(down), bytes(up)
+            self.bar.wait()
+            fu, fd = self.down[hi], self.up[lo]  # the upper neighbour's "down" message, the lower neighbour's "up" message
+            assert len(fu) == n_from_up and len(fd) == n_from_down, (rank, len(fu), n_from_up, len(fd), n_from_down)
+            self.bar.wait()
+            return fu, fd
+
+        def allreduce_sum(arr):
+            self.red[rank] = np.array(arr, copy=True)
+            self.bar.wait()
+            tot = self.red[0].copy()
+            for r in range(1, n):  # the same order on every rank: bitwise the same sum everywhere
+                tot += self.red[r]
+            self.bar.wait()
+            arr[:] = tot
+
+        ctx.comm_init_callbacks(sendrecv, allreduce_sum)
+
+
+@pytest.mark.parametrize("scheme", ["ecsim", "ecsimcorr"])
+def test_eight_slabs_in_one_process(scheme, oracle):
+    """BASELINE configs[3] / [4] are 8 z-slabs.  Eight contexts (rank r of 8, slabs of the minimum 6 planes) driven by
+    eight threads of THIS process through the callback transport must reproduce the single-slab run and the CPU oracle's
+    whole-box run: fields to 1e-8, particle totals and per-cell occupancy exactly -- colour schedule, ghost-row
+    exchange, migration, split operator applies and the reductions at the real rank count."""
+    import threading
+
+    import numpy as np
+    import xpic_amd as X
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import mp_slab_worker as W
+
+    nr, nzl = 8, 6
+    n, d = (12, 10, nzl * nr), (0.5, 0.4, 0.25)
+    dt = 0.2 if scheme != "ecsim" else 0.8
+    ring = ThreadRing(nr)
+    res, errs = [None] * nr, []
+
+    def rank_main(r):
+        try:
+            ctx = W.build(scheme, n, d, dt, r, nr, seed=42)
+            ring.attach(ctx, r)
+            c0 = [ctx.count(s) for s in range(2)]
+            its = [ctx.step() for _ in range(3)]
+            occ = [np.bincount(ctx.particles(s)[1].astype(np.int64) + ctx.z0 * n[0] * n[1], minlength=n[0] * n[1] * n[2])
+                   for s in range(2)]
+            res[r] = dict(E=ctx.get_field(X.E), B=ctx.get_field(X.B), c0=c0, c1=[ctx.count(s) for s in range(2)], its=its,
+                          occ=occ, en=ctx.energy())
+            ctx.close()
+        except BaseException as e:  # noqa: BLE001 -- release the other ranks, report below
+            errs.append((r, repr(e)))
+            ring.bar.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(nr)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=400)
+    assert not errs and all(x is not None for x in res), errs
+    E = np.concatenate([x["E"] for x in res], axis=0)
+    B = np.concatenate([x["B"] for x in res], axis=0)
+    tot1 = [sum(x["c1"][s] for x in res) for s in range(2)]
+    assert any(x["c1"] != x["c0"] for x in res)  # particles did migrate between the slabs
+    ref = W.build(scheme, n, d, dt, 0, 1, seed=42)
+    rits = [ref.step() for _ in range(3)]
+    assert tot1 == [ref.count(s) for s in range(2)]
+    for F, fid in ((E, X.E), (B, X.B)):
+        a = ref.get_field(fid)
+        assert np.abs(a - F).max() <= 1e-8 * np.abs(a).max()
+    assert np.allclose(res[0]["en"], ref.energy(), rtol=1e-9, atol=1e-15)
+    assert all(abs(a - b) <= 2 for a, b in zip(res[0]["its"], rits))
+    o = W.build_oracle(scheme, n, d, dt, seed=42)
+    for _ in range(3):
+        assert o.step() >= 0
+    for F, name in ((E, "E"), (B, "B")):
+        a = o.get_field(name)
+        assert np.abs(a - F).max() <= 1e-8 * np.abs(a).max()
+    for s in range(2):
+        assert o.count(s) == tot1[s]
+        oo = np.bincount(o.particles(s)[1].astype(np.int64), minlength=n[0] * n[1] * n[2])
+        assert np.array_equal(oo, sum(x["occ"][s] for x in res))

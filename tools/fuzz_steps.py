@@ -30,7 +30,7 @@ def _case(case, rng, worst, verbose, nxmax):
     o = oracle_lib.OracleSim(scheme, n, d, dt)
     g = X.Context(scheme, n, d, dt)
     if scheme != "basic":
-        g.set_preconditioner(int(rng.integers(0, 3)))
+        g.set_preconditioner(int(rng.integers(0, 4)))  # none, polynomial in matM (fp32 / fp64 vectors), in matM + <matL>
     # Poisson background + a few heavy cells + empty stretches
     ppc = float(rng.choice([0.3, 3.0, 20.0, 70.0]))
     cnt = rng.poisson(ppc, n[::-1])

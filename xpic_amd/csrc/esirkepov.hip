@@ -60,6 +60,9 @@ constexpr int kSeg = 8;               // cells (segments) per round
 #ifndef ESK_COLS1
 #define ESK_COLS1 160
 #endif
+#ifndef ESK_EXP
+#define ESK_EXP 0
+#endif
 #ifndef ESK_SEG0
 #define ESK_SEG0 16
 #endif
@@ -529,11 +532,13 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
         // pred_w += qn_Np * 0.5 * (old_v + point.p).dot(E_p)   (:77-78)
         pw += qn_Np * 0.5 * ((old_v[0] + v[0]) * Ep[0] + (old_v[1] + v[1]) * Ep[1] + (old_v[2] + v[2]) * Ep[2]);
       }
+#if ESK_EXP != 2
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         s.r[a][p] = r[a];
         if (MODE != 1) s.v[a][p] = v[a];
       }
+#endif
 
       // Shape::setup(old_r, new_r) (shape.cpp:43-54): the box [sst, send) of the pair per axis
       bool ok = true;
@@ -687,7 +692,9 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
           if (j < adv || last) {
             const double val = jtile[t];
             if (val != 0.0) {
+#if ESK_EXP != 1 // (experiment builds: 1 drops the J atomics, 2 the particle stores -- what each costs, results garbage)
               unsafeAtomicAdd(&J[c * g.cstride + g.nodew(base - 1 + j, cy - 1 + ty, cz - 1 + tz)], val);
+#endif
               jtile[t] = 0.0;
             }
           }
