@@ -98,6 +98,15 @@ def count_gpus():
     return n
 
 
+def slabs_fit(args):
+    n, nz = args.gpus, args.n3[2]
+    if nz % n or nz // n < 6:
+        print(f"bench.py --gpus {n}: the {args.n3[0]} x {args.n3[1]} x {nz} box cannot be cut into {n} z-slabs of >= 6 planes",
+              file=sys.stderr, flush=True)
+        return False
+    return True
+
+
 def launch_ranks(args, argv):
     import signal
     import tempfile
@@ -110,10 +119,7 @@ def launch_ranks(args, argv):
         print(f"bench.py --gpus {n}: needs {need} MI355X device(s), found {ndev}; the xpic HIP path has no CPU "
               f"fallback and will not run fewer ranks than asked", file=sys.stderr, flush=True)
         return 3
-    nz = args.n3[2]
-    if nz % n or nz // n < 6:
-        print(f"bench.py --gpus {n}: the {args.n3[0]} x {args.n3[1]} x {nz} box cannot be cut into {n} z-slabs of >= 6 planes",
-              file=sys.stderr, flush=True)
+    if not slabs_fit(args):
         return 3
     # rendezvous through a file in a private directory: no port to pick, free and hand over (bind/close/reuse is a race)
     rdv = tempfile.mkdtemp(prefix="xpic_bench_")
@@ -276,12 +282,99 @@ def pmc_traffic(scheme, n3, kernel):
     return val if stamp == csrc_hash() else None
 
 
+class Job:
+    """How the ranks of one run meet outside the data path (timing barrier, MAX / SUM of a scalar) and which transport
+    a context gets: "single"; "rccl" (production: one process per GPU); "gloo" (rehearsal: one process per rank, all
+    on GPU 0, host-staged exchange); "threads" (rehearsal: one THREAD per rank in this process, all on GPU 0 -- the
+    only way to 8 slabs on a pool box, which admits 6 processes to its card)."""
+
+    def __init__(self, kind, rank, world, ring=None):
+        self.kind, self.rank, self.world, self.ring = kind, rank, world, ring
+        self.note = {"gloo": " [gloo rehearsal: all ranks share one GPU]",
+                     "threads": " [rehearsal: one thread per rank, all ranks share one GPU]"}.get(kind, "")
+
+    def attach(self, ctx):
+        if self.kind == "rccl":
+            from xpic_amd.parallel import init_rccl
+
+            init_rccl(ctx)
+        elif self.kind == "gloo":
+            from xpic_amd.parallel import GlooRing
+
+            GlooRing().attach(ctx)
+        elif self.kind == "threads":
+            self.ring.attach(ctx, self.rank)
+
+    def barrier(self):
+        if self.kind in ("rccl", "gloo"):
+            import torch.distributed as dist
+
+            dist.barrier()
+        elif self.kind == "threads":
+            self.ring.bar.wait()
+
+    def reduce(self, x, op):
+        """MAX or SUM of one float over the ranks"""
+        if self.kind in ("rccl", "gloo"):
+            import torch
+            import torch.distributed as dist
+
+            t = torch.tensor([x], dtype=torch.float64, device="cpu" if self.kind == "gloo" else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+            return float(t.item())
+        if self.kind == "threads":
+            self.ring.red[self.rank] = float(x)
+            self.ring.bar.wait()
+            vals = list(self.ring.red)
+            self.ring.bar.wait()
+            return max(vals) if op == "max" else sum(vals)
+        return float(x)
+
+
+def run_threads(args):
+    """XPIC_BENCH_COMM=threads: the N ranks of `--gpus N` as N threads of THIS process (ctypes releases the GIL inside
+    the library), each with its own context, stream and slab on GPU 0."""
+    import threading
+
+    import torch
+    from xpic_amd.parallel import ThreadRing
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the xpic HIP path has no CPU fallback")
+    if not slabs_fit(args):
+        raise SystemExit(3)
+    torch.cuda.set_device(0)
+    ring = ThreadRing(args.gpus)
+    errs = []
+
+    def body(rank):
+        try:
+            rank_body(args, rank, args.gpus, 0, Job("threads", rank, args.gpus, ring))
+        except BaseException as e:  # noqa: BLE001 -- a rank that dies must not leave the others at a barrier
+            errs.append((rank, e))
+            ring.bar.abort()
+
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(args.gpus)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        first = [e for e in errs if not isinstance(e[1], threading.BrokenBarrierError)] or errs
+        raise SystemExit(f"rank {first[0][0]} failed: {first[0][1]!r}")
+
+
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    mode = os.environ.get("XPIC_BENCH_COMM", "rccl")
+    if mode not in ("rccl", "gloo", "threads"):
+        raise SystemExit(f"XPIC_BENCH_COMM={mode}: rccl, gloo or threads")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        if mode == "threads":
+            return run_threads(args)
         sys.exit(launch_ranks(args, argv))
 
     import torch
@@ -296,7 +389,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the xpic HIP path has no CPU fallback")
     # XPIC_BENCH_COMM=gloo: rehearse the N > 1 path on a one-GPU box (all ranks share GPU 0, host-staged exchange)
-    rehearsal = os.environ.get("XPIC_BENCH_COMM", "rccl") == "gloo"
+    rehearsal = mode == "gloo"
+    if mode == "threads" and world > 1:
+        raise SystemExit("XPIC_BENCH_COMM=threads runs its ranks inside one process: start it without a launcher")
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -317,7 +412,13 @@ def main():
         finally:
             os.dup2(saved, 1)
             os.close(saved)
+    rank_body(args, rank, world, local_rank, Job("single" if world == 1 else mode, rank, world))
+    if world > 1:
+        dist.destroy_process_group()
 
+
+def rank_body(args, rank, world, local_rank, job):
+    import torch
     import numpy as np
     import xpic_amd as X
 
@@ -327,13 +428,7 @@ def main():
     gname = f"{n}^3" if cubic else f"{n3[0]} x {n3[1]} x {n3[2]}"
     # N > 1: the SAME global grid, cut into z-slabs (BASELINE.json configs[3]); one slab, one process, one GPU
     ctx = X.Context(args.scheme, n3, (args.dx,) * 3, args.dt, device=local_rank, rank=rank, nranks=world)
-    if world > 1:
-        from xpic_amd.parallel import GlooRing, init_rccl
-
-        if rehearsal:
-            GlooRing().attach(ctx)
-        else:
-            init_rccl(ctx)
+    job.attach(ctx)
     comm_ranks = ctx.comm_size()  # read back from the communicator itself (ncclCommCount)
     if comm_ranks != world:
         raise SystemExit(f"the communicator holds {comm_ranks} ranks, expected {world}")
@@ -355,8 +450,7 @@ def main():
     def barrier():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        job.barrier()
 
     if args.plain_gmres and args.scheme != "basic":
         ctx.set_preconditioner(0)
@@ -374,16 +468,8 @@ def main():
         its += ctx.step()
     barrier()
     elapsed = time.perf_counter() - t0
-    red_dev = "cpu" if rehearsal else "cuda"
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        it_t = torch.tensor([its], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(it_t, op=dist.ReduceOp.SUM)
-        its_total = float(it_t.item())
-    else:
-        its_total = float(its)
+    elapsed = job.reduce(elapsed, "max")
+    its_total = job.reduce(its, "sum")
 
     cg_line = None
     if args.scheme == "basic" and world == 1:
@@ -412,11 +498,7 @@ def main():
                                             "corr_second_push", "solve_matM", "precond", "matL_apply", "rebin",
                                             "allreduce")}
     count_local = sum(ctx.count(s) for s in sorts)
-    count = count_local
-    if world > 1:
-        ct = torch.tensor([count], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(ct)
-        count = int(ct.item())
+    count = int(job.reduce(count_local, "sum"))
     assert count == world * npart, "particles were lost in a periodic box"
 
     headline = {"ecsim": "particles pushed/sec (ECSIM full step) + KSP iters/sec, 256^3 grid 64ppc",
@@ -452,7 +534,7 @@ def main():
                       else "exactly ppc particles in every cell",
             "parallelism": "1 GPU" if world == 1 else
                            f"{world} z-slabs of {n3[2] // world} planes, RCCL halo / migration / dot all-reduce over xGMI"
-                           + (" [gloo rehearsal: all ranks share one GPU]" if rehearsal else ""),
+                           + job.note,
         },
         "ksp_iters_per_s": its_total / world / (ms_solve * 1e-3) if ms_solve else None,  # iterations are global
         "ksp_method": None if args.scheme == "basic" else (
@@ -554,8 +636,6 @@ def main():
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -97,6 +97,30 @@ def test_two_rank_rehearsal_reports_two_ranks():
 
 
 @pytest.mark.gpu
+def test_eight_rank_rehearsal_in_one_process():
+    """BASELINE configs[3]'s rank count through bench.py itself: `--gpus 8 --grid 128` with XPIC_BENCH_COMM=threads runs
+    the eight slabs (16 planes each) as eight threads of one process on GPU 0 (a pool box admits 6 processes to its card);
+    the line reports the 8 ranks of the communicator, every particle is still there, the solve converges in the same
+    number of iterations on every rank, and the all-reduces stay at one per Krylov iteration + the step's fixed ones."""
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--grid", "128", "--ppc", "8", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], env=_env(XPIC_BENCH_COMM="threads"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["steps"] == 2 and line["scaling"] == "strong"
+    assert line["config"]["particles_per_gpu"] == 8 * 128 * 128 * 16
+    assert "8 z-slabs of 16 planes" in line["config"]["parallelism"]
+    its = line["ksp_iterations_per_step"]
+    assert its > 0 and its == int(its)  # the same count on all 8 ranks (the sum over ranks / 8 is whole)
+    assert line["phase_ms_per_step"]["halo"] > 0 and line["phase_ms_per_step"]["migrate"] > 0
+    # one per Krylov iteration + the fixed ones of a step (norm of the right-hand side, initial residual, the surrogate's
+    # sums, the migration's flags) + the explicit norms of the last iterations (residual below 1e-6 of the right-hand side:
+    # krylov.hip's rule); classical Gram-Schmidt with a separate norm would be 2 per iteration + the fixed ones
+    assert line["allreduces_per_step"] <= its + 6
+
+
+@pytest.mark.gpu
 def test_single_rank_line_has_the_contract_fields():
     out = subprocess.run([sys.executable, BENCH, "--grid", "32", "--ppc", "16", "--steps", "2", "--warmup", "1",
                           "--cpu-grid", "16", "--cpu-steps", "1"], env=_env(), capture_output=True, text=True, timeout=500)

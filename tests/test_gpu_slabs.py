@@ -108,47 +108,6 @@ def test_migration_overflow_fails_on_every_rank():
     assert "of the z-slabs" in outs[1]
 
 
-class ThreadRing:
-    """The xpic_comm_callbacks transport between THREADS of one process: every rank's context lives in its own thread of
-    this process and the ring exchange / all-reduce are rendezvous on barriers.  One process on the GPU whatever the
-    number of ranks -- the way to run the 8 slabs of BASELINE configs[3] / [4] under the pool's limit of 6 processes per
-    card."""
-
-    def __init__(self, n):
-        import threading
-
-        self.n = n
-        self.bar = threading.Barrier(n, timeout=240)
-        self.down = [b""] * n
-        self.up = [b""] * n
-        self.red = [None] * n
-
-    def attach(self, ctx, rank):
-        import numpy as np
-
-        n = self.n
-        lo, hi = (rank - 1 + n) % n, (rank + 1) % n
-
-        def sendrecv(down, up, n_from_up, n_from_down):
-            self.down[rank], self.up[rank] = bytes(down), bytes(up)
-            self.bar.wait()
-            fu, fd = self.down[hi], self.up[lo]  # the upper neighbour's "down" message, the lower neighbour's "up" message
-            assert len(fu) == n_from_up and len(fd) == n_from_down, (rank, len(fu), n_from_up, len(fd), n_from_down)
-            self.bar.wait()
-            return fu, fd
-
-        def allreduce_sum(arr):
-            self.red[rank] = np.array(arr, copy=True)
-            self.bar.wait()
-            tot = self.red[0].copy()
-            for r in range(1, n):  # the same order on every rank: bitwise the same sum everywhere
-                tot += self.red[r]
-            self.bar.wait()
-            arr[:] = tot
-
-        ctx.comm_init_callbacks(sendrecv, allreduce_sum)
-
-
 @pytest.mark.parametrize("scheme", ["ecsim", "ecsimcorr"])
 def test_eight_slabs_in_one_process(scheme, oracle):
     """BASELINE configs[3] / [4] are 8 z-slabs.  Eight contexts (rank r of 8, slabs of the minimum 6 planes) driven by
@@ -162,11 +121,12 @@ def test_eight_slabs_in_one_process(scheme, oracle):
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import mp_slab_worker as W
+    from xpic_amd.parallel import ThreadRing
 
     nr, nzl = 8, 6
     n, d = (12, 10, nzl * nr), (0.5, 0.4, 0.25)
     dt = 0.2 if scheme != "ecsim" else 0.8
-    ring = ThreadRing(nr)
+    ring = ThreadRing(nr)  # xpic_amd.parallel: rendezvous of threads on barriers
     res, errs = [None] * nr, []
 
     def rank_main(r):

@@ -39,4 +39,7 @@ fi
 if [ $PART = all ] || [ $PART = rehearsal ]; then
   XPIC_BENCH_COMM=gloo timeout -k 10 600 python bench.py --gpus 2 --grid 128 --ppc 32 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_n2_rehearsal_$TAG.json 2> gpurun_out/bench_n2_rehearsal_$TAG.err || { tail gpurun_out/bench_n2_rehearsal_$TAG.err; exit 1; }
   cut -c1-300 gpurun_out/bench_n2_rehearsal_$TAG.json
+  # BASELINE configs[3] as it is cut: 8 z-slabs of 32 planes of the 256^3 x 64 box, one thread per rank in one process
+  XPIC_BENCH_COMM=threads timeout -k 10 600 python bench.py --gpus 8 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_n8_threads_$TAG.json 2> gpurun_out/bench_n8_threads_$TAG.err || { tail gpurun_out/bench_n8_threads_$TAG.err; exit 1; }
+  cut -c1-300 gpurun_out/bench_n8_threads_$TAG.json
 fi

@@ -2,10 +2,14 @@
 
 * `init_rccl(ctx)`  -- production: RCCL over xGMI.  torch.distributed is only the bootstrap channel that carries
   rank 0's 128-byte ncclUniqueId to the other ranks; all data-path traffic is issued by libxpic_hip.so itself.
+* `ThreadRing`      -- tests / rehearsals: the same callbacks between THREADS of one process (one context per thread, all
+  on one GPU): N slabs under the GPU pool's limit of 6 processes per card.
 * `GlooRing`        -- tests: a host-staged ring send/receive + all-reduce over torch.distributed (gloo), plugged in
   through xpic_comm_init_callbacks.  Lets two ranks that share one GPU (or none, for the transport's own tests)
   exercise the slab code path.
 """
+import threading
+
 import numpy as np
 
 
@@ -84,3 +88,40 @@ class GlooRing:
 
     def attach(self, ctx):
         ctx.comm_init_callbacks(self.sendrecv, self.allreduce_sum)
+
+
+class ThreadRing:
+    """The xpic_comm_callbacks transport between THREADS of one process: every rank's context lives in its own thread of
+    this process and the ring exchange / all-reduce are rendezvous on barriers.  One process on the GPU whatever the
+    number of ranks -- the way to run the 8 slabs of BASELINE configs[3] / [4] under the pool's limit of 6 processes per
+    card."""
+
+    def __init__(self, n):
+        self.n = n
+        self.bar = threading.Barrier(n, timeout=240)
+        self.down = [b""] * n
+        self.up = [b""] * n
+        self.red = [None] * n
+
+    def attach(self, ctx, rank):
+        n = self.n
+        lo, hi = (rank - 1 + n) % n, (rank + 1) % n
+
+        def sendrecv(down, up, n_from_up, n_from_down):
+            self.down[rank], self.up[rank] = bytes(down), bytes(up)
+            self.bar.wait()
+            fu, fd = self.down[hi], self.up[lo]  # the upper neighbour's "down" message, the lower neighbour's "up" message
+            assert len(fu) == n_from_up and len(fd) == n_from_down, (rank, len(fu), n_from_up, len(fd), n_from_down)
+            self.bar.wait()
+            return fu, fd
+
+        def allreduce_sum(arr):
+            self.red[rank] = np.array(arr, copy=True)
+            self.bar.wait()
+            tot = self.red[0].copy()
+            for r in range(1, n):  # the same order on every rank: bitwise the same sum everywhere
+                tot += self.red[r]
+            self.bar.wait()
+            arr[:] = tot
+
+        ctx.comm_init_callbacks(sendrecv, allreduce_sum)
