@@ -66,6 +66,21 @@ constexpr int kSeg = 8;               // cells (segments) per round
 #ifndef ESK_SEG0
 #define ESK_SEG0 16
 #endif
+#ifndef ESK_LANES
+#define ESK_LANES 2 // bit MODE: the round is composed on 8 / 16 lanes (row shifts, ballots) instead of by the scalar loop
+#endif
+#ifndef ESK_OCC1
+#define ESK_OCC1 2 // workgroups per CU the register allocation of MODE 1 must allow
+#endif
+#ifndef ESK_DRAIN0
+#define ESK_DRAIN0 1
+#endif
+#ifndef ESK_TILE_LATE
+#define ESK_TILE_LATE 1
+#endif
+#ifndef ESK_PIPE
+#define ESK_PIPE 6 // bit MODE: phase 2 requests the operands of the next K step before this step's products (MODE 1, 2: -2 %; MODE 0 spills with it)
+#endif
 #ifndef ESK_BOX_GENERIC
 #define ESK_BOX_GENERIC 0 // 1: the staged box values by four calls of the generic spline per axis and position (round 2)
 #endif
@@ -148,7 +163,7 @@ using UniformInts = const __attribute__((address_space(4))) int*; // wave-unifor
 
 // P2: power-of-two spacings (exact reciprocals instead of divisions, device_common.h: scaled_position)
 template <int MODE, bool P2>
-__global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, SortDev s, const double* __restrict__ E,
+__global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkepov_push(GridDev g, SortDev s, const double* __restrict__ E,
   const double* __restrict__ B, double* __restrict__ J, double qm, double alpha, double qn_Np, double* pred_w,
   int* bad_count)
 {
@@ -258,7 +273,9 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
   // segments.  A fifth of the scalar loop's instructions; pays where registers are not the limit (MODE 1: first_push
   // 6.75 -> 6.1 ms; MODE 0 and 2, at their register limit, lose 3 % with it and keep the scalar loop).
   auto compose_lanes = [&](RoundTab& T) {
-    const int base = cur;
+    // (said to be uniform: the cell_start reads below are then scalar loads; as vector loads they brought a
+    // s_waitcnt vmcnt(0) -- a wait for the previous round's particle stores and J atomics -- to the top of every round)
+    const int base = __builtin_amdgcn_readfirstlane(cur);
     int cv[kSeg + 1];
 #pragma unroll
     for (int i = 0; i <= kSeg; ++i) cv[i] = cs[base + i];
@@ -272,7 +289,10 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
     P += __builtin_amdgcn_update_dpp(0, P, 0x111, 0xf, 0xf, true); Q += __builtin_amdgcn_update_dpp(0, Q, 0x111, 0xf, 0xf, true);
     P += __builtin_amdgcn_update_dpp(0, P, 0x112, 0xf, 0xf, true); Q += __builtin_amdgcn_update_dpp(0, Q, 0x112, 0xf, 0xf, true);
     P += __builtin_amdgcn_update_dpp(0, P, 0x114, 0xf, 0xf, true); Q += __builtin_amdgcn_update_dpp(0, Q, 0x114, 0xf, 0xf, true);
-    static_assert(MODE != 1 || kSeg == 8, "three row shifts cover eight lanes");
+    if constexpr (kSeg > 8) { // sixteen lanes: one more shift (a DPP row is 16 lanes)
+      P += __builtin_amdgcn_update_dpp(0, P, 0x118, 0xf, 0xf, true); Q += __builtin_amdgcn_update_dpp(0, Q, 0x118, 0xf, 0xf, true);
+    }
+    static_assert(kSeg == 8 || kSeg == 16, "three / four row shifts cover eight / sixteen lanes");
     const unsigned some = (unsigned)__ballot(cnt > 0) & ((1u << kSeg) - 1u);
     const int first = some ? __ffs(some) - 1 : kSeg;
     int nseg, ncols, tcount;
@@ -303,7 +323,7 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
     }
   };
   auto compose = [&](RoundTab& T) {
-    if constexpr (MODE == 1) compose_lanes(T);
+    if constexpr ((ESK_LANES >> MODE) & 1) compose_lanes(T);
     else compose_scalar(T);
   };
 
@@ -356,6 +376,13 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
   __syncthreads();
   Ahead<MODE> pf;
   request(tab[0], pf);
+#if ESK_DRAIN0
+  // The first round's particles are waited for HERE.  Left pending into the loop they make the compiler place the waits
+  // of the first iteration (vmcnt(4), (2), (0) at the first uses) into every iteration, where -- the request of the
+  // next round being conditional, hence not counted -- they wait for the loads issued a moment ago: the prefetch of a
+  // round ahead was a full memory round trip at the start of every phase 1.
+  __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0), lgkmcnt / expcnt untouched
+#endif
 #ifdef ESK_STAMPS
   unsigned long long stamp_t_ = __builtin_readcyclecounter();
   unsigned long long stamp_acc_[10] = {};
@@ -368,10 +395,11 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
     const int nseg = __builtin_amdgcn_readfirstlane(T.nseg), ncols = __builtin_amdgcn_readfirstlane(T.ncols);
     const int adv = __builtin_amdgcn_readfirstlane(T.adv);
     // ---- this round's neighbourhoods / tile go to LDS; the next round is composed and requested
+    double ft[MODE == 0 ? kFtPer : 1];
     if (MODE == 0) {
       // DMGlobalToLocal(E), (B) (basic/simulation.cpp:56-57) for just the nodes the round's particles can gather from
-      // (requesting the tile a round ahead was measured: no gain, the other workgroup of the CU covers the latency)
-      double ft[kFtPer];
+      // (requesting the tile a round ahead was measured: no gain, the other workgroup of the CU covers the latency);
+      // the values go to LDS after the next round is composed: the scalar loop runs under the loads' latency
 #pragma unroll
       for (int k = 0; k < kFtPer; ++k) {
         const int t = threadIdx.x + k * kThreadsB;
@@ -385,11 +413,6 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
           if (base - 2 + tx <= g.nx + 2) ft[k] = F[g.nodew(base - 2 + tx, cy - 2 + ty, cz - 2 + tz)];
         }
       }
-#pragma unroll
-      for (int k = 0; k < kFtPer; ++k) {
-        const int t = threadIdx.x + k * kThreadsB;
-        if (t < 6 * kTileN) ftile[t] = ft[k];
-      }
     }
     if (MODE == 2) {
 #pragma unroll
@@ -400,8 +423,24 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
     }
     const int p = pf.p, col = pf.col, crel = pf.crel, seg = pf.seg;
     double r[3] = {pf.r[0], pf.r[1], pf.r[2]}, v[3] = {pf.v[0], pf.v[1], pf.v[2]};
+    if (MODE == 0 && p >= 0) {
+      // (MODE 0 cannot hold a particle a round ahead -- the 2nd-order gather takes every register -- but it can ask for
+      // it here: the composition of the next round and the barrier pass under the latency)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { r[a] = s.r[a][p]; v[a] = s.v[a][p]; }
+    }
     STAMP(1);
     compose(tab[(rd + 1) & 1]);
+    if (MODE == 0) {
+#if ESK_TILE_LATE
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+      for (int k = 0; k < kFtPer; ++k) {
+        const int t = threadIdx.x + k * kThreadsB;
+        if (t < 6 * kTileN) ftile[t] = ft[k];
+      }
+    }
     STAMP(2);
     lds_barrier_b();
     STAMP(3);
@@ -415,10 +454,6 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
     double po[3] = {0, 0, 0}, pn[3] = {0, 0, 0};
     int sst[3] = {0, 0, 0}, ssz[3] = {0, 0, 0};
     if (p >= 0) {
-      if (MODE == 0) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { r[a] = s.r[a][p]; v[a] = s.v[a][p]; }
-      }
       const double old_r[3] = {r[0], r[1], r[2]};
       double Ep[3] = {0, 0, 0}, Bp[3] = {0, 0, 0};
 
@@ -683,21 +718,72 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
             if (acc[c] != 0.0) unsafeAtomicAdd(&jtile[c * kJN + (tZ[c] * kD + tY[c]) * kJX + tX[c]], acc[c]);
           }
         };
-        for (int k = k0; k < k1; ++k) {
-          if (4 * k >= nextcol) {
+        if constexpr ((ESK_PIPE >> MODE) & 1) {
+          // the same K steps with the operands of step k + 1 requested before the products of step k (two operand sets,
+          // steps taken in pairs inside a cell so that no set is ever copied)
+          struct Ops { double a[2][2], b[2][2], pr[3]; }; // [x | y at row qq][old | new], [z | x at row qb][old | new], P_c at qq
+          auto load = [&](int k, Ops& o) {
+            const double* cp = stage + 4 * k + kk;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              o.a[0][h] = cp[(12 * h + 0 * kD + qq) * kPitch];
+              o.a[1][h] = cp[(12 * h + 1 * kD + qq) * kPitch];
+              o.b[0][h] = cp[(12 * h + 2 * kD + qb) * kPitch];
+              o.b[1][h] = cp[(12 * h + 0 * kD + qb) * kPitch];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o.pr[c] = cp[(24 + c * kD + qq) * kPitch];
+          };
+          auto compute = [&](const Ops& o) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const double (&A)[2] = c == 1 ? o.a[0] : o.a[1]; // X: A = y, B = z;  Y: A = x, B = z;  Z: A = y, B = x
+              const double (&Bv)[2] = c == 2 ? o.b[1] : o.b[0];
+              const double Tc = -qdc[c] * (A[1] * (2.0 * Bv[1] + Bv[0]) + A[0] * (2.0 * Bv[0] + Bv[1]));
+              acc[c] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.pr[c], Tc, acc[c], 0, 0, 0);
+            }
+          };
+          Ops oa, ob;
+          int k = k0;
+          load(k, oa);
+          while (true) {
+            const int kend = min(k1, nextcol >> 2); // the steps of this cell that are this wave's
+            for (; k + 1 < kend; k += 2) {
+              load(k + 1, ob);
+              compute(oa);
+              if (k + 2 < k1) load(k + 2, oa);
+              compute(ob);
+            }
+            if (k < kend) {
+              if (k + 1 < k1) load(k + 1, ob);
+              compute(oa);
+              oa = ob;
+              ++k;
+            }
+            if (k >= k1) break;
             merge(__builtin_amdgcn_readfirstlane(T.cell[sg]));
             acc[0] = acc[1] = acc[2] = 0.0;
             ++sg;
             nextcol = __builtin_amdgcn_readfirstlane(T.col0[sg + 1]);
           }
-          const double* cp = stage + 4 * k + kk;
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const int aA = c == 1 ? 0 : 1, aB = c == 2 ? 0 : 2; // X: A = y, B = z;  Y: A = x, B = z;  Z: A = y, B = x
-            const double sA_o = cp[(aA * kD + qq) * kPitch], sA_n = cp[(12 + aA * kD + qq) * kPitch];
-            const double sB_o = cp[(aB * kD + qb) * kPitch], sB_n = cp[(12 + aB * kD + qb) * kPitch];
-            const double Tc = -qdc[c] * (sA_n * (2.0 * sB_n + sB_o) + sA_o * (2.0 * sB_o + sB_n));
-            acc[c] = __builtin_amdgcn_mfma_f64_4x4x4f64(cp[(24 + c * kD + qq) * kPitch], Tc, acc[c], 0, 0, 0);
+        }
+        else {
+        for (int k = k0; k < k1; ++k) {
+            if (4 * k >= nextcol) {
+              merge(__builtin_amdgcn_readfirstlane(T.cell[sg]));
+              acc[0] = acc[1] = acc[2] = 0.0;
+              ++sg;
+              nextcol = __builtin_amdgcn_readfirstlane(T.col0[sg + 1]);
+            }
+            const double* cp = stage + 4 * k + kk;
+  #pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const int aA = c == 1 ? 0 : 1, aB = c == 2 ? 0 : 2; // X: A = y, B = z;  Y: A = x, B = z;  Z: A = y, B = x
+              const double sA_o = cp[(aA * kD + qq) * kPitch], sA_n = cp[(12 + aA * kD + qq) * kPitch];
+              const double sB_o = cp[(aB * kD + qb) * kPitch], sB_n = cp[(12 + aB * kD + qb) * kPitch];
+              const double Tc = -qdc[c] * (sA_n * (2.0 * sB_n + sB_o) + sA_o * (2.0 * sB_o + sB_n));
+              acc[c] = __builtin_amdgcn_mfma_f64_4x4x4f64(cp[(24 + c * kD + qq) * kPitch], Tc, acc[c], 0, 0, 0);
+            }
           }
         }
         merge(__builtin_amdgcn_readfirstlane(T.cell[sg]));
@@ -705,6 +791,12 @@ __global__ void __launch_bounds__(kThreadsB, 2) k_esirkepov_push(GridDev g, Sort
     }
     STAMP(8);
     lds_barrier_b();
+#if ESK_DRAIN0
+    // the next round's particles (requested before phase 1) and this round's stores are waited for HERE, ahead of the
+    // flush's atomics: in order behind those, the wait would be for the atomics' acknowledgements (the compiler puts it at
+    // the loop's end, where it copies the requested values into this round's registers)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
     // ---- the next round starts at cell base + adv: the window's nodes base - 1 .. base + adv - 2 are final and leave
     // with one fp64 atomic per node (other pencils add to the same nodes); their columns, zeroed, become the nodes
     // kJX further on (the window is circular, nothing moves).  The last round flushes everything (its tail wraps
