@@ -64,6 +64,9 @@ extern "C" int xpic_debug_fill_stamps(double* out, int reset)
 #define STAMP(k)
 #endif
 
+#ifndef FILL_DRAIN
+#define FILL_DRAIN 0
+#endif
 namespace xpic {
 
 namespace {
@@ -298,6 +301,9 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
 
   Prefetch pf;
   prefetch_cell(wave, pf);
+#if FILL_DRAIN
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
   double carry[kOwn][2];
 #pragma unroll
   for (int mm = 0; mm < kOwn; ++mm) carry[mm][0] = carry[mm][1] = 0.0;
@@ -606,11 +612,15 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     }
     lds_barrier();
     STAMP(6);
+#if FILL_DRAIN
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
     // (The next chunk's first use of the prefetched registers is guarded by s_waitcnt vmcnt(0): the stores of the flush
     // below sit in divergent branches, so the compiler cannot count them, and every chunk begins by waiting for its
     // predecessor's stores.  Telling the compiler that all reads are complete here -- __builtin_amdgcn_s_waitcnt before
     // the flush and before the loop -- removes that wait and was measured SLOWER, 108.0 against 97.8 ms: the stall then
-    // moves into the pass loop's particle loads, which queue behind the same stores.)
+    // moves into the pass loop's particle loads, which queue behind the same stores.  Re-measured at the end of round 3,
+    // FILL_DRAIN=1: 108.5 against 97.7 ms.)
     // ---- stream out the finished columns (plain RMW, kW consecutive doubles per line), keep 2 in registers
 #pragma unroll
     for (int mm = 0; mm < kOwn; ++mm) {
