@@ -158,6 +158,7 @@ struct xpic_ctx {
   int precond = 3;     // 0 none; Chebyshev polynomial (right preconditioning) in matM on fp32 (1) / fp64 (2) work vectors,
                        // 3: in matM + the translation average of matL (precond.hip) for the predict solve
   int cheb_degree = 0; // steps of the Chebyshev iteration on matM (set at create from the spectral interval)
+  int cheb_degree_M = 0; // the same iteration as the preconditioner of a solve ON matM (ecsimcorr's "correct"): a tighter bound pays there
   int cheb_degree_user = 0; // explicit degree from xpic_set_preconditioner (0: automatic)
   float* abar32 = nullptr;    // kind 3: the 3 x 124 coefficients of Abar = matM + <matL>
   double* abar_work = nullptr; // sums, matM's coefficients, fp64 Abar, per-row partials
@@ -218,7 +219,7 @@ int matM_apply(xpic_ctx* c, const double* x, double* y, bool add);
 int matL_apply(xpic_ctx* c, const double* x, double* y, bool add);
 int matA_apply(xpic_ctx* c, const double* x, double* y);
 int op_apply_overlapped(xpic_ctx* c, bool with_L, double* x, double* y); // halo exchange of x beside the interior rows
-int cheb_matM_inverse(xpic_ctx* c, const double* r, double* out);
+int cheb_matM_inverse(xpic_ctx* c, const double* r, double* out, int degree);
 int halo_fill_f32(xpic_ctx* c, float* f, int width);
 // precond.hip
 int abar_update(xpic_ctx* c);                                     // Abar = matM + <matL> from the assembled matL

@@ -738,13 +738,12 @@ int halo_fill_f32(xpic_ctx* c, float* f, int width);
 // operator, no inner products (no all-reduce), one 1-plane halo per step.  `z` ends in out; uses c->kry_p[0..2] and
 // c->kry_t.  precond kind 1 keeps the iteration's vectors in fp32 (half the traffic; the flexible GMRES around it does
 // not care how exact its preconditioner is, krylov.hip), kind 2 in fp64.
-int cheb_matM_inverse(xpic_ctx* c, const double* r, double* out)
+int cheb_matM_inverse(xpic_ctx* c, const double* r, double* out, int degree)
 {
   Timed t(c, "precond");
   const GridDev& g = c->g;
   const double a = 2.0, b = 2.0 + 2.0 * g.dt * g.dt * (1.0 / (g.dx * g.dx) + 1.0 / (g.dy * g.dy) + 1.0 / (g.dz * g.dz));
   const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma1 = theta / delta;
-  const int degree = c->cheb_degree;
   if (degree <= 1) return launch_ew(c, FScaleTo{out, 1.0 / theta, r});
   double rho = 1.0 / sigma1;
   long blocks = (g.nown + kBlock - 1) / kBlock;

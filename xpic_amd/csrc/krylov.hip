@@ -74,7 +74,7 @@ int gmres(xpic_ctx* c, int op, const double* b, double* x, double rtol, double a
       if (pc) {
         double* Zj = Z + (long)j * c->nvec;
         if (pc_abar) XPIC_CALL(cheb_abar_inverse(c, Vj, Zj));
-        else XPIC_CALL(cheb_matM_inverse(c, Vj, Zj));
+        else XPIC_CALL(cheb_matM_inverse(c, Vj, Zj, op == XPIC_OP_MATM_GMRES ? c->cheb_degree_M : c->cheb_degree));
         XPIC_CALL(apply_op(c, op, Zj, w));
       }
       else XPIC_CALL(apply_op(c, op, Vj, w));
