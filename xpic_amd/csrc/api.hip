@@ -282,6 +282,10 @@ int xpic_create(const xpic_geometry* geom, int scheme, xpic_ctx** out)
   xpic_ctx* c = new xpic_ctx;
   c->geom = *geom;
   c->scheme = scheme;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, geom->device) == hipSuccess && cus > 0) c->num_cus = cus;
+  }
   GridDev& g = c->g;
   g.nx = geom->n[0]; g.ny = geom->n[1]; g.nzg = geom->n[2];
   g.nzl = g.nzg / geom->nranks;

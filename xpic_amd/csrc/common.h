@@ -157,6 +157,7 @@ struct xpic_ctx {
   double* kry_p[3] = {nullptr, nullptr, nullptr}; // Chebyshev preconditioner work vectors
   int precond = 3;     // 0 none; Chebyshev polynomial (right preconditioning) in matM on fp32 (1) / fp64 (2) work vectors,
                        // 3: in matM + the translation average of matL (precond.hip) for the predict solve
+  int num_cus = 256; // hipDeviceAttributeMultiprocessorCount (the colour schedule of the assembly counts workgroup rounds)
   int cheb_degree = 0; // steps of the Chebyshev iteration on matM (set at create from the spectral interval)
   int cheb_degree_M = 0; // the same iteration as the preconditioner of a solve ON matM (ecsimcorr's "correct"): a tighter bound pays there
   int cheb_degree_user = 0; // explicit degree from xpic_set_preconditioner (0: automatic)

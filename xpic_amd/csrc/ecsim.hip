@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
         if (g.G == 0) pz = pz < 0 ? pz + g.nzl : (pz >= g.nzl ? pz - g.nzl : pz);
         else if (pz < 0 || pz >= g.nzl) continue; // no such local pencil: the neighbour rank's rows are its own
         const int ca = py < bodyy ? py % per_y : per_y + (py - bodyy);
-        const int cb = g.G == 0 ? (pz < bodyz ? pz % per_z : per_z + (pz - bodyz)) : pz % 3;
+        const int cb = g.G == 0 ? (pz < bodyz ? pz % per_z : per_z + (pz - bodyz)) : pz % per_z;
         if (cb * ncol_y + ca < my_order) first = false;
       }
     }
@@ -817,11 +817,43 @@ int build_ltab(xpic_ctx* c)
 // Colour classes of one periodic axis of n indices.  Same-colour indices must be >= 3 apart (periodically).
 // If 3, 4 or 5 divides n the colours are the residues mod that period (all classes equal: no thin launches);
 // otherwise residues mod 3 over the first 3*floor(n/3) indices plus one class per trailing index.
+#ifndef XPIC_MAX_PER_Z
+#define XPIC_MAX_PER_Z 5 // (3: the round-2 schedule of a slab, plain residues mod 3)
+#endif
 static int colour_period(int n)
 {
   for (int p = 3; p <= 5; ++p)
     if (n % p == 0) return p;
   return 3;
+}
+
+// Colour periods (p along y, q along z).  Pencils of one launch must be >= 3 apart along y or z; any p, q >= 3 will do,
+// and what they cost is the number of workgroup ROUNDS: a launch of n pencils on S workgroup slots (2 per CU) takes
+// ceil(n / S) rounds of one pencil's duration each, whatever n is.  A 256 x 32 slab (BASELINE configs[3] on 8 GPUs) with
+// (4, 3) is 12 launches of 704 / 704 / 640 pencils = 24 rounds of 512; with (4, 4) 16 launches of exactly 512 = 16 rounds.
+// Periodic extents (y always, z on a single slab) take a period that divides them where one exists (no remainder
+// classes: each of those is a launch of a few pencils); a slab's z is not periodic inside the slab (its ghost rows are
+// its own), any q >= 3 partitions it.
+static void colour_periods(const GridDev& g, int slots, int* per_y, int* per_z)
+{
+  const int py = colour_period(g.ny);
+  if (g.G == 0) { *per_y = py; *per_z = colour_period(g.nzl); return; }
+  long best = -1;
+  int bq = 3;
+  const int ncol_y = py + g.ny % py;
+  for (int q = 3; q <= XPIC_MAX_PER_Z; ++q) {
+    long rounds = 0;
+    for (int b = 0; b < q; ++b) {
+      const int ncz = (g.nzl - b + q - 1) / q;
+      if (ncz <= 0) continue;
+      for (int a = 0; a < ncol_y; ++a) {
+        const int ncy = a < py ? (g.ny - g.ny % py) / py : 1;
+        rounds += ((long)ncy * ncz + slots - 1) / slots;
+      }
+    }
+    if (best < 0 || rounds < best) { best = rounds; bq = q; }
+  }
+  *per_y = py; *per_z = bq;
 }
 
 static void colour_class(int n, int period, int colour, int* first, int* step, int* count)
@@ -836,15 +868,16 @@ int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, d
   if (s.n == 0) return 0;
   const GridDev& g = c->g;
   // y is periodic inside the slab; z is periodic only when the slab is the whole box: with z-neighbours the rows
-  // below plane 0 / above plane nzl-1 are ghost rows of this rank alone, so plain residues mod 3 suffice
-  const int per_y = colour_period(g.ny), per_z = g.G == 0 ? colour_period(g.nzl) : 3;
-  const int ncol_y = per_y + g.ny % per_y, ncol_z = g.G == 0 ? per_z + g.nzl % per_z : 3;
+  // below plane 0 / above plane nzl-1 are ghost rows of this rank alone, so plain residues mod per_z suffice
+  int per_y, per_z;
+  colour_periods(g, 2 * c->num_cus, &per_y, &per_z);
+  const int ncol_y = per_y + g.ny % per_y, ncol_z = g.G == 0 ? per_z + g.nzl % per_z : per_z;
   for (int b = 0; b < ncol_z; ++b)
     for (int a = 0; a < ncol_y; ++a) {
       int cy0, cys, ncy, cz0, czs, ncz;
       colour_class(g.ny, per_y, a, &cy0, &cys, &ncy);
       if (g.G == 0) colour_class(g.nzl, per_z, b, &cz0, &czs, &ncz);
-      else { cz0 = b; czs = 3; ncz = (g.nzl - b + 2) / 3; }
+      else { cz0 = b; czs = per_z; ncz = (g.nzl - b + per_z - 1) / per_z; }
       if (ncy == 0 || ncz == 0) continue;
       Timed t(c, "fill_current"); // one entry per colour launch: the average is the kernel's own launch duration
       const bool alias = g.ny < 3 || (g.G == 0 && g.nzl < 3);
