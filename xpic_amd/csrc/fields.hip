@@ -428,7 +428,7 @@ constexpr int kBandY = 4; // y-chunks per band: 16 rows
 
 template <bool WITH_L, bool WITH_M>
 __global__ void __launch_bounds__(kRowX* kRowY, 4) k_matA(GridDev g, const double* __restrict__ L,
-  const double* __restrict__ X, double* __restrict__ Y, int add, int z0r, int nzr)
+  const double* __restrict__ X, double* __restrict__ Y, int add, int z0r, int nzr, int zsplit)
 {
   // rows of the owned planes [z0r, z0r + nzr): the whole slab, or its interior / boundary planes (matA_apply_overlapped)
   // 1-D grid.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  XCD r sweeps its own
@@ -437,13 +437,18 @@ __global__ void __launch_bounds__(kRowX* kRowY, 4) k_matA(GridDev g, const doubl
   // Order inside a band position: component fastest (the three rows of a node share their operand footprint), x, y.
   const int nxc = (g.nx + kRowX - 1) / kRowX, nyc = (g.ny + kRowY - 1) / kRowY;
   const int nyt = (nyc + kBandY - 1) / kBandY;         // y-bands
-  const int P = (nzr + 7) / 8;                         // planes per XCD run
-  const int per_z = kBandY * nxc * 3, per_band = P * per_z;
+  // the 8 XCDs split the planes zsplit ways and the y-bands 8 / zsplit ways (row_split: whatever leaves the least idle;
+  // 8 x 1 for a whole box, 4 x 2 for the 28 interior planes of a 32-plane slab, where 8 runs of 4 planes left one XCD idle)
+  const int ysplit = 8 / zsplit;
+  const int Pz = (nzr + zsplit - 1) / zsplit;          // planes per XCD run
+  const int Pb = (nyt + ysplit - 1) / ysplit;          // y-bands per XCD
+  const int per_z = kBandY * nxc * 3, per_band = Pz * per_z;
   const int xcd = blockIdx.x % 8;
   const long q = blockIdx.x / 8;
-  const int yt = (int)(q / per_band);
+  const int ytl = (int)(q / per_band);
+  const int yt = (xcd / zsplit) * Pb + ytl;
   const int rem = (int)(q % per_band);
-  const int zr = xcd * P + rem / per_z;
+  const int zr = (xcd % zsplit) * Pz + rem / per_z;
   const int z = z0r + zr;
   const int rem2 = rem % per_z;
   const int c1 = rem2 % 3;
@@ -451,7 +456,7 @@ __global__ void __launch_bounds__(kRowX* kRowY, 4) k_matA(GridDev g, const doubl
   // y is the same for the 64 lanes of a wave (blockDim.x == 64): tell the compiler, so that every row base
   // below is scalar arithmetic
   const int y = (yt * kBandY + rem2 / (3 * nxc)) * kRowY + __builtin_amdgcn_readfirstlane(threadIdx.y);
-  if (yt >= nyt || zr >= nzr) return;
+  if (ytl >= Pb || yt >= nyt || zr >= nzr) return;
   if (x >= g.nx || y >= g.ny) return;
   using Seq = std::make_integer_sequence<int, kLStencil>;
   double r = 0.0;
@@ -677,18 +682,34 @@ int matM_apply(xpic_ctx* c, const double* x, double* y, bool add)
   return matM_planes(c, x, y, add, 0, c->g.nzl);
 }
 
-static dim3 row_grid(const GridDev& g, int nzr)
+// how the 8 XCDs share the rows of nzr planes: zsplit runs of planes x (8 / zsplit) groups of y-bands, the split with
+// the smallest largest share (ties: more z runs -- a run marches along z with its operand footprint in L2)
+static int row_split(const GridDev& g, int nzr)
+{
+  const long nyc = (g.ny + kRowY - 1) / kRowY, nyt = (nyc + kBandY - 1) / kBandY;
+  int best = 8;
+  long cost = -1;
+  for (int zs = 8; zs >= 1; zs >>= 1) {
+    const long load = ((nzr + zs - 1) / zs) * ((nyt + 8 / zs - 1) / (8 / zs));
+    if (cost < 0 || load < cost) { cost = load; best = zs; }
+  }
+  return best;
+}
+
+static dim3 row_grid(const GridDev& g, int nzr, int zsplit)
 {
   const long nxc = (g.nx + kRowX - 1) / kRowX, nyc = (g.ny + kRowY - 1) / kRowY;
-  const long nyt = (nyc + kBandY - 1) / kBandY, P = (nzr + 7) / 8;
-  return dim3((unsigned)(8 * nyt * P * kBandY * nxc * 3));
+  const long nyt = (nyc + kBandY - 1) / kBandY;
+  const long Pz = (nzr + zsplit - 1) / zsplit, Pb = (nyt + 8 / zsplit - 1) / (8 / zsplit);
+  return dim3((unsigned)(8 * Pb * Pz * kBandY * nxc * 3));
 }
 
 int matL_apply(xpic_ctx* c, const double* x, double* y, bool add)
 {
   Timed t(c, "matL_apply");
-  hipLaunchKernelGGL((k_matA<true, false>), row_grid(c->g, c->g.nzl), dim3(kRowX, kRowY), 0, c->stream, c->g, c->matL, x, y,
-    add ? 1 : 0, 0, c->g.nzl);
+  const int zs = row_split(c->g, c->g.nzl);
+  hipLaunchKernelGGL((k_matA<true, false>), row_grid(c->g, c->g.nzl, zs), dim3(kRowX, kRowY), 0, c->stream, c->g, c->matL, x, y,
+    add ? 1 : 0, 0, c->g.nzl, zs);
   XPIC_HIP(hipGetLastError());
   return 0;
 }
@@ -696,7 +717,9 @@ int matL_apply(xpic_ctx* c, const double* x, double* y, bool add)
 static int matA_planes(xpic_ctx* c, const double* x, double* y, int z0r, int nzr)
 {
   if (nzr <= 0) return 0;
-  hipLaunchKernelGGL((k_matA<true, true>), row_grid(c->g, nzr), dim3(kRowX, kRowY), 0, c->stream, c->g, c->matL, x, y, 0, z0r, nzr);
+  const int zs = row_split(c->g, nzr);
+  hipLaunchKernelGGL((k_matA<true, true>), row_grid(c->g, nzr, zs), dim3(kRowX, kRowY), 0, c->stream, c->g, c->matL, x, y, 0, z0r,
+    nzr, zs);
   XPIC_HIP(hipGetLastError());
   return 0;
 }
