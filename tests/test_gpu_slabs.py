@@ -80,6 +80,52 @@ print("self-ring ok")
     assert "self-ring ok" in out.stdout
 
 
+def test_slab_colour_schedule_at_the_size_that_takes_four_z_colours():
+    """The assembly's colour schedule on a slab picks its z period (3 .. 5) by the number of workgroup rounds: small test
+    slabs always get 3.  A 256 x 256 x 32 slab -- one rank's share of BASELINE configs[3] on 8 GPUs -- gets 4 (16 launches
+    of exactly 512 pencils).  Its assembled operator and one whole step must equal the ghost-free periodic run of the same
+    box: matA applied to a random vector to 1e-12, fields after a step to 1e-9, counts exactly."""
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import xpic_amd as X
+
+def build(force):
+    n, d = (256, 256, 32), (0.5, 0.5, 0.5)
+    ctx = X.Context("ecsim", n, d, 1.0, self_ring=force)
+    if force: ctx.comm_init_rccl(X.rccl_unique_id())
+    s = ctx.add_sort(8, 1.0, -1.0, 1.0, capacity=int(8 * n[0] * n[1] * n[2] * 1.1))
+    ctx.fill_synthetic(s, 8, 0.02, seed=77)
+    B = np.zeros(ctx.fshape()) + np.array([0.05, 0.1, 0.2])
+    ctx.set_field(X.B, B); ctx.set_field(X.B0, B)
+    rng = np.random.default_rng(5)
+    ctx.set_field(X.W0, rng.normal(0.0, 1.0, ctx.fshape()))
+    return ctx
+
+a, b = build(True), build(False)
+for c in (a, b):
+    c.profile_enable(True)
+    c.ecsim_fill_current()
+assert a.profile_get("fill_current")[0] == 16, a.profile_get("fill_current")  # 4 x 4 colours on the slab
+for c in (a, b):
+    c.matA_apply(X.W0, X.W1)
+ya, yb = a.get_field(X.W1), b.get_field(X.W1)
+assert np.abs(ya - yb).max() <= 1e-12 * np.abs(yb).max(), np.abs(ya - yb).max() / np.abs(yb).max()
+ia, ib = a.step(), b.step()
+assert abs(ia - ib) <= 1, (ia, ib)
+for f in (X.E, X.B):
+    fa, fb = a.get_field(f), b.get_field(f)
+    assert np.abs(fa - fb).max() <= 1e-9 * np.abs(fb).max(), f
+assert a.count(0) == b.count(0) == 8 * 256 * 256 * 32
+print("slab colours ok")
+''' % ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "slab colours ok" in out.stdout
+
+
 def test_migration_overflow_fails_on_every_rank():
     """Error state is collective: rank 0 overflows its migration send buffer, rank 1 has nothing wrong locally.  Both
     must return the error (no rank left waiting in ncclRecv / the ring exchange of the next phase)."""
