@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Random small configurations (grid extents, spacings, particles per cell from 0 to a few hundred, clustered cells),
-two steps of every scheme on the GPU against the CPU oracle.  usage: fuzz_steps.py [cases] [seed] [largest nx + 1]"""
+two steps of every scheme on the GPU against the CPU oracle.  usage: fuzz_steps.py [cases] [seed] [largest nx + 1] [slab]
+"slab": the device side is a single z-slab that keeps its ghost planes and is its own neighbour over RCCL
+(geometry.self_ring) -- the slab code paths (ghost exchanges, migration, colour schedule, cleared boundary planes of the
+assembly) on the same random configurations, empty stretches and heavy cells included."""
 import os
 import sys
 
@@ -13,22 +16,24 @@ import xpic_amd as X
 
 
 
-def run(cases=12, seed=7, verbose=True, nxmax=41):
+def run(cases=12, seed=7, verbose=True, nxmax=41, slab=False):
     rng = np.random.default_rng(seed)
     oracle_lib.lib()
     worst = {}
     for case in range(cases):
-        _case(case, rng, worst, verbose, nxmax)
+        _case(case, rng, worst, verbose, nxmax, slab)
     return worst
 
 
-def _case(case, rng, worst, verbose, nxmax):
+def _case(case, rng, worst, verbose, nxmax, slab=False):
     scheme = ("basic", "ecsim", "ecsimcorr")[case % 3]
     n = tuple(int(v) for v in rng.integers(6, [nxmax, 13, 12]))
     d = tuple(float(v) for v in rng.choice([0.25, 0.4, 0.5, 0.7], 3))
     dt = float(rng.choice([0.05, 0.1]) if scheme == "basic" else rng.choice([0.2, 0.5]))
     o = oracle_lib.OracleSim(scheme, n, d, dt)
-    g = X.Context(scheme, n, d, dt)
+    g = X.Context(scheme, n, d, dt, self_ring=slab)
+    if slab:
+        g.comm_init_rccl(X.rccl_unique_id())
     if scheme != "basic":
         g.set_preconditioner(int(rng.integers(0, 4)))  # none, polynomial in matM (fp32 / fp64 vectors), in matM + <matL>
     # Poisson background + a few heavy cells + empty stretches
@@ -88,5 +93,5 @@ def _case(case, rng, worst, verbose, nxmax):
 
 if __name__ == "__main__":
     w = run(int(sys.argv[1]) if len(sys.argv) > 1 else 12, int(sys.argv[2]) if len(sys.argv) > 2 else 7,
-            nxmax=int(sys.argv[3]) if len(sys.argv) > 3 else 41)
+            nxmax=int(sys.argv[3]) if len(sys.argv) > 3 else 41, slab=len(sys.argv) > 4 and sys.argv[4] == "slab")
     print("worst relative field error per scheme:", w)
