@@ -504,6 +504,13 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
         }
 #endif
         STAMP(2);
+#if FILL_DRAIN >= 3
+        // the next pass's particles are waited for HERE (they had this pass's phase 2 to arrive; on every path out of the
+        // pass body, or the compiler keeps its own): left to the compiler the wait sits at the head of EVERY pass, the
+        // first one of a chunk included, where -- the memory counter being in order -- it is a wait for the previous
+        // chunk's flush stores
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
         if (lastpass) break;
         real = real_next;
       }
@@ -511,6 +518,11 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
 
     STAMP(2);
     // next chunk's cell: particle data and B neighbourhood travel while this chunk is merged and flushed
+#if FILL_DRAIN >= 2
+    // (nothing is outstanding here but the previous chunk's stores: said explicitly, so that the compiler does not guard its
+    // re-use of the pass loop's load registers with waits BEHIND the requests below)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
     prefetch_cell(i + kW, pf);
 
     // ---- the finished columns of this chunk leave by read-modify-write: request their current values NOW, so
@@ -617,10 +629,13 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
 #endif
     // (The next chunk's first use of the prefetched registers is guarded by s_waitcnt vmcnt(0): the stores of the flush
     // below sit in divergent branches, so the compiler cannot count them, and every chunk begins by waiting for its
-    // predecessor's stores.  Telling the compiler that all reads are complete here -- __builtin_amdgcn_s_waitcnt before
-    // the flush and before the loop -- removes that wait and was measured SLOWER, 108.0 against 97.8 ms: the stall then
-    // moves into the pass loop's particle loads, which queue behind the same stores.  Re-measured at the end of round 3,
-    // FILL_DRAIN=1: 108.5 against 97.7 ms.)
+    // predecessor's stores.  FILL_DRAIN removes that wait step by step.  1 -- all reads declared complete here and before
+    // the loop: 108.5 against 97.7 ms, NOT because of the stores: the compiler then guards its re-use of the pass loop's
+    // load registers with vmcnt(3) .. (0) BEHIND the next chunk's requests, a full memory round trip.  2 -- also before
+    // those requests: 97.9.  3 -- also at the end of every pass (the head of the pass loop otherwise keeps counted waits
+    // that, the counter being in order, drain the stores after all): no vmcnt wait is left between the flush and the end
+    // of the next chunk's first pass, and the assembly takes 97.4 ms.  The acknowledgements of the flush stores were never
+    // what a chunk waits for; the default stays 0.)
     // ---- stream out the finished columns (plain RMW, kW consecutive doubles per line), keep 2 in registers
 #pragma unroll
     for (int mm = 0; mm < kOwn; ++mm) {
