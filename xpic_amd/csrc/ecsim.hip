@@ -65,7 +65,7 @@ extern "C" int xpic_debug_fill_stamps(double* out, int reset)
 #endif
 
 #ifndef FILL_DRAIN
-#define FILL_DRAIN 0
+#define FILL_DRAIN 3 // explicit waits for global reads where they cost nothing (see the comment in front of the flush)
 #endif
 namespace xpic {
 
@@ -634,8 +634,8 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     // load registers with vmcnt(3) .. (0) BEHIND the next chunk's requests, a full memory round trip.  2 -- also before
     // those requests: 97.9.  3 -- also at the end of every pass (the head of the pass loop otherwise keeps counted waits
     // that, the counter being in order, drain the stores after all): no vmcnt wait is left between the flush and the end
-    // of the next chunk's first pass, and the assembly takes 97.4 ms.  The acknowledgements of the flush stores were never
-    // what a chunk waits for; the default stays 0.)
+    // of the next chunk's first pass, and the assembly takes 97.4 ms (A/B/A/B in one call: 98.12, 97.47, 98.15, 97.39).
+    // The acknowledgements of the flush stores were never most of what a chunk waits for; 3 is the default.)
     // ---- stream out the finished columns (plain RMW, kW consecutive doubles per line), keep 2 in registers
 #pragma unroll
     for (int mm = 0; mm < kOwn; ++mm) {
