@@ -64,6 +64,18 @@ extern "C" int xpic_debug_fill_stamps(double* out, int reset)
 #define STAMP(k)
 #endif
 
+// wave priority (s_setprio) of phase 2, phase 1 and the chunk's tail.  Raising phase 2 alone -- the wave that has matrix
+// instructions to issue goes first against the other workgroup's wave on its SIMD -- is worth 1.3 % (97.5 -> 96.0 / 96.3 ms;
+// phase 2 = 2 / 3: 96.3-96.6; also the tail = 1 or 2: 97.2-97.8; phase 1 alone: 97.2; the tail alone: 97.7)
+#ifndef FILL_PRIO
+#define FILL_PRIO 1
+#endif
+#ifndef FILL_PRIO1
+#define FILL_PRIO1 0
+#endif
+#ifndef FILL_PRIOT
+#define FILL_PRIOT 0
+#endif
 #ifndef FILL_DRAIN
 #define FILL_DRAIN 3 // explicit waits for global reads where they cost nothing (see the comment in front of the flush)
 #endif
@@ -320,6 +332,9 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
   const int nch = (g.nx + kW - 1) / kW;
   for (int j = 0; j < nch; ++j) {
     STAMP(0);
+#if FILL_PRIO || FILL_PRIO1 || FILL_PRIOT
+    __builtin_amdgcn_s_setprio(FILL_PRIO1);
+#endif
     const int i = j * kW + wave;
     const bool active = FX || i < g.nx; // full chunks: every wave has a cell
 
@@ -456,6 +471,9 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
         // operand set, the next step's ten reads issued between this step's products and its matrix instructions, also
         // across octants -- compiled as intended, 6 register moves per step, and was SLOWER: 115.1 against 108.6 ms per
         // assembly.  The other wave of the SIMD already covers the read latency; what a step costs is issue slots.)
+#if FILL_PRIO
+        __builtin_amdgcn_s_setprio(FILL_PRIO);
+#endif
 #if FILL_EXP != 1 && !(FILL_EXP >= 6 && FILL_EXP <= 8)
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
@@ -503,6 +521,9 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
           }
         }
 #endif
+#if FILL_PRIO || FILL_PRIO1
+        __builtin_amdgcn_s_setprio(FILL_PRIO1);
+#endif
         STAMP(2);
 #if FILL_DRAIN >= 3
         // the next pass's particles are waited for HERE (they had this pass's phase 2 to arrive; on every path out of the
@@ -517,6 +538,9 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     }
 
     STAMP(2);
+#if FILL_PRIO || FILL_PRIO1 || FILL_PRIOT
+    __builtin_amdgcn_s_setprio(FILL_PRIOT);
+#endif
     // next chunk's cell: particle data and B neighbourhood travel while this chunk is merged and flushed
 #if FILL_DRAIN >= 2
     // (nothing is outstanding here but the previous chunk's stores: said explicitly, so that the compiler does not guard its
