@@ -136,3 +136,23 @@ def test_single_rank_line_has_the_contract_fields():
     assert line["roofline_spmv"]["bound"] == "hbm"
     c = line["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["ksp_iters_per_s_at_sample_grid"] > 0
+
+
+def test_pmc_traffic_is_quoted_only_for_the_sources_it_was_taken_on(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic comes from the newest committed PMC summary, and only while xpic_amd/csrc still hashes to
+    the value stamped in that file; another grid, an unknown kernel or a stale stamp give null (never a stale number)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import xpic_amd
+
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    good = "# csrc-hash %s   (stamp)\nkernel calls read write total ms\nk_ecsim_fill<true, true>  32  9.2  7.2  16.4  6.2\n"
+    (prof / "r03_pmc_traffic_256.txt").write_text(good % xpic_amd.csrc_hash())
+    assert bench.pmc_traffic("ecsim", (256, 256, 256), "k_ecsim_fill") == pytest.approx(16.4e9)
+    assert bench.pmc_traffic("ecsim", (128, 128, 128), "k_ecsim_fill") is None      # not the grid it was taken on
+    assert bench.pmc_traffic("ecsim", (256, 256, 256), "k_no_such_kernel") is None
+    assert bench.pmc_traffic("basic", (128, 128, 128), "k_esirkepov_push<0") is None  # no file for that scheme
+    (prof / "r04_pmc_traffic_256.txt").write_text(good % ("0" * 40))                 # a newer file, other sources
+    assert bench.pmc_traffic("ecsim", (256, 256, 256), "k_ecsim_fill") is None
