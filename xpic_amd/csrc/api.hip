@@ -7,13 +7,14 @@
 #include "common.h"
 #include "lstencil.h"
 
+// first-touch assembly on a z-slab with neighbours (ecsim_fill_current): 0 clears all of matL every step (round 2)
+#ifndef XPIC_SLAB_FIRST_TOUCH
+#define XPIC_SLAB_FIRST_TOUCH 1
+#endif
 // Chebyshev degree of the preconditioner of a solve ON matM (ecsimcorr's "correct"): there the polynomial approximates
 // the inverse of the operator itself, and a tighter bound (0.25 % instead of 8 %) trades stencil passes on fp32 vectors for
 // outer iterations with their Gram-Schmidt passes and all-reduces: at dt = 1, dx = 0.5 degree 12 instead of 6, 3 instead
 // of 6 iterations per solve (128^3: 2.41 -> 1.72 ms; degrees 8 / 16 / 20 / 30: 2.32 / 2.14 / 1.69 / 2.32)
-#ifndef XPIC_SLAB_FIRST_TOUCH
-#define XPIC_SLAB_FIRST_TOUCH 1
-#endif
 #ifndef XPIC_CHEB_M_BOUND
 #define XPIC_CHEB_M_BOUND 0.00125
 #endif
@@ -115,8 +116,9 @@ static int ecsim_fill_current(xpic_ctx* c)
 {
   const GridDev& g = c->g;
   // MatZeroEntries (:164).  On a single slab every matL entry has a local writer, so the first species' assembly
-  // stores instead of adding (first touch) and no clearing pass is needed.  With z-neighbours some rows of the
-  // top / bottom planes are written only by the neighbour's ghost-row exchange: clear everything, add everywhere.
+  // stores instead of adding (first touch) and no clearing pass is needed.  With z-neighbours some lines of the ghost
+  // planes and of the first / last owned plane are written only by the neighbour's ghost-row exchange: those four
+  // planes are cleared (below), the rest is first touch too.
   bool any = false;
   for (auto& s : c->sorts) any = any || s.n > 0;
   // (and a y or z extent of 2 folds two row offsets of a pencil onto one stream: ecsim.hip adds those with atomics)
