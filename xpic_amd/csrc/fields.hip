@@ -872,9 +872,13 @@ int field_export(xpic_ctx* c, const double* src, double* dst_host)
 namespace {
 
 // buf[c][w][plane] <-> f[c][zs0 + w][plane]
+// blockIdx.y = 0 / 1: the lower / upper side of an exchange in ONE launch (a 32-plane slab runs 32 exchanges per step:
+// four launches of a few microseconds each around every one of them were two too many)
 template <int OP, class T = double> // 0: pack f -> buf, 1: unpack buf -> f, 2: add buf into f
-__global__ void __launch_bounds__(kBlock) k_planes(GridDev g, T* f, T* buf, int zs0, int width)
+__global__ void __launch_bounds__(kBlock) k_planes(GridDev g, T* f, T* buf0, int zs00, T* buf1, int zs01, int width)
 {
+  T* buf = blockIdx.y == 0 ? buf0 : buf1;
+  const int zs0 = blockIdx.y == 0 ? zs00 : zs01;
   const long per = (long)width * g.plane;
   const long n = 3 * per;
   const long stride = (long)gridDim.x * kBlock;
@@ -928,13 +932,11 @@ int halo_fill_t(xpic_ctx* c, T* f, int width)
   const unsigned nb = plane_grid(n);
   T* hb[4] = {(T*)c->halo_buf[0], (T*)c->halo_buf[1], (T*)c->halo_buf[2], (T*)c->halo_buf[3]};
   // my bottom owned planes go down, my top owned planes go up
-  hipLaunchKernelGGL((k_planes<0, T>), dim3(nb), dim3(kBlock), 0, c->stream, g, f, hb[0], g.G, width);
-  hipLaunchKernelGGL((k_planes<0, T>), dim3(nb), dim3(kBlock), 0, c->stream, g, f, hb[1], g.G + g.nzl - width, width);
+  hipLaunchKernelGGL((k_planes<0, T>), dim3(nb, 2), dim3(kBlock), 0, c->stream, g, f, hb[0], g.G, hb[1], g.G + g.nzl - width, width);
   XPIC_HIP(hipGetLastError());
   XPIC_CALL(comm_ring(c, c->halo_buf[0], bytes, c->halo_buf[1], bytes, c->halo_buf[2], bytes, c->halo_buf[3], bytes));
   // from the upper neighbour: its bottom planes = my upper ghost; from the lower: its top planes = my lower ghost
-  hipLaunchKernelGGL((k_planes<1, T>), dim3(nb), dim3(kBlock), 0, c->stream, g, f, hb[2], g.G + g.nzl, width);
-  hipLaunchKernelGGL((k_planes<1, T>), dim3(nb), dim3(kBlock), 0, c->stream, g, f, hb[3], g.G - width, width);
+  hipLaunchKernelGGL((k_planes<1, T>), dim3(nb, 2), dim3(kBlock), 0, c->stream, g, f, hb[2], g.G + g.nzl, hb[3], g.G - width, width);
   XPIC_HIP(hipGetLastError());
   return 0;
 }
@@ -956,8 +958,7 @@ int halo_post(xpic_ctx* c, double* f, int width)
   XPIC_CALL(ensure_halo_buf(c, bytes));
   const unsigned nb = plane_grid(n);
   double* hb[4] = {c->halo_buf[0], c->halo_buf[1], c->halo_buf[2], c->halo_buf[3]};
-  hipLaunchKernelGGL((k_planes<0, double>), dim3(nb), dim3(kBlock), 0, c->stream, g, f, hb[0], g.G, width);
-  hipLaunchKernelGGL((k_planes<0, double>), dim3(nb), dim3(kBlock), 0, c->stream, g, f, hb[1], g.G + g.nzl - width, width);
+  hipLaunchKernelGGL((k_planes<0, double>), dim3(nb, 2), dim3(kBlock), 0, c->stream, g, f, hb[0], g.G, hb[1], g.G + g.nzl - width, width);
   XPIC_HIP(hipGetLastError());
   XPIC_HIP(hipEventRecord(c->comm_ev[0], c->stream));
   XPIC_HIP(hipStreamWaitEvent(c->comm_stream, c->comm_ev[0], 0));
@@ -965,8 +966,7 @@ int halo_post(xpic_ctx* c, double* f, int width)
   c->stream = c->comm_stream; // comm_ring and the unpack below are enqueued on the communication stream
   int rc = comm_ring(c, hb[0], bytes, hb[1], bytes, hb[2], bytes, hb[3], bytes);
   if (rc == 0) {
-    hipLaunchKernelGGL((k_planes<1, double>), dim3(nb), dim3(kBlock), 0, c->stream, g, f, hb[2], g.G + g.nzl, width);
-    hipLaunchKernelGGL((k_planes<1, double>), dim3(nb), dim3(kBlock), 0, c->stream, g, f, hb[3], g.G - width, width);
+    hipLaunchKernelGGL((k_planes<1, double>), dim3(nb, 2), dim3(kBlock), 0, c->stream, g, f, hb[2], g.G + g.nzl, hb[3], g.G - width, width);
   }
   c->stream = compute;
   XPIC_CALL(rc);
@@ -996,12 +996,10 @@ int halo_add(xpic_ctx* c, double* f, int width)
   XPIC_CALL(ensure_halo_buf(c, bytes));
   const unsigned nb = plane_grid(n);
   // what I deposited below my slab belongs to the lower neighbour's top planes, above -> upper neighbour's bottom
-  hipLaunchKernelGGL(k_planes<0>, dim3(nb), dim3(kBlock), 0, c->stream, g, f, c->halo_buf[0], g.G - width, width);
-  hipLaunchKernelGGL(k_planes<0>, dim3(nb), dim3(kBlock), 0, c->stream, g, f, c->halo_buf[1], g.G + g.nzl, width);
+  hipLaunchKernelGGL(k_planes<0>, dim3(nb, 2), dim3(kBlock), 0, c->stream, g, f, c->halo_buf[0], g.G - width, c->halo_buf[1], g.G + g.nzl, width);
   XPIC_HIP(hipGetLastError());
   XPIC_CALL(comm_ring(c, c->halo_buf[0], bytes, c->halo_buf[1], bytes, c->halo_buf[2], bytes, c->halo_buf[3], bytes));
-  hipLaunchKernelGGL(k_planes<2>, dim3(nb), dim3(kBlock), 0, c->stream, g, f, c->halo_buf[2], g.G + g.nzl - width, width);
-  hipLaunchKernelGGL(k_planes<2>, dim3(nb), dim3(kBlock), 0, c->stream, g, f, c->halo_buf[3], g.G, width);
+  hipLaunchKernelGGL(k_planes<2>, dim3(nb, 2), dim3(kBlock), 0, c->stream, g, f, c->halo_buf[2], g.G + g.nzl - width, c->halo_buf[3], g.G, width);
   XPIC_HIP(hipGetLastError());
   return 0;
 }
