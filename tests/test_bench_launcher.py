@@ -156,3 +156,22 @@ def test_pmc_traffic_is_quoted_only_for_the_sources_it_was_taken_on(tmp_path, mo
     assert bench.pmc_traffic("basic", (128, 128, 128), "k_esirkepov_push<0") is None  # no file for that scheme
     (prof / "r04_pmc_traffic_256.txt").write_text(good % ("0" * 40))                 # a newer file, other sources
     assert bench.pmc_traffic("ecsim", (256, 256, 256), "k_ecsim_fill") is None
+
+
+def test_workload_helpers():
+    """The argument surface of bench.py that the driver and the side configurations rely on: default = BASELINE configs[2]
+    on one GPU, `--scheme basic` = two species of ppc / 2, `--grid-xyz` a non-cubic box, and the slab rule of --gpus N."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    a = bench.parse_args([])
+    assert a.gpus == 1 and a.n3 == (256, 256, 256) and a.ppc == 64 and a.scheme == "ecsim"
+    assert bench.species(a) == [(64, 1.0, -1.0, 1.0)]
+    b = bench.parse_args(["--scheme", "basic", "--grid", "128", "--ppc", "32"])
+    assert bench.species(b) == [(16, 0.5, -1.0, 1.0)] * 2
+    c = bench.parse_args(["--scheme", "ecsimcorr", "--grid-xyz", "512", "512", "64", "--ppc", "32", "--gpus", "8"])
+    assert c.n3 == (512, 512, 64) and bench.slabs_fit(c)          # 8 slabs of 8 planes
+    d = bench.parse_args(["--grid", "32", "--gpus", "8"])
+    assert not bench.slabs_fit(d)                                   # 4 planes per slab: below the 6 a slab needs
+    e = bench.parse_args(["--grid", "100", "--gpus", "8"])
+    assert not bench.slabs_fit(e)                                   # not divisible
