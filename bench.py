@@ -47,7 +47,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-grid", type=int, default=64)   # 64^3 x ppc, as SURVEY 8(d) asks: ~20 s of oracle work
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--probe", action="store_true", help="also run the device copy probes (PMC calibration)")
+    ap.add_argument("--no-probe", dest="probe", action="store_false",
+                    help="skip the device copy probe (1 GiB device-to-device copies: the achievable copy rate of THIS box, "
+                         "SURVEY 8(d); on by default, outside the timed region)")
     ap.add_argument("--plain-gmres", action="store_true", help="unpreconditioned GMRES(30), as the CPU oracle runs")
     ap.add_argument("--cheb-degree", type=int, default=0, help="override the Chebyshev preconditioner degree (experiments)")
     ap.add_argument("--precond", type=int, default=None, choices=[0, 1, 2, 3],
@@ -603,6 +605,21 @@ def rank_body(args, rank, world, local_rank, job):
     if args.scheme == "ecsim":
         line["roofline"] = fill
         line["roofline_spmv"] = spmv
+        # The whole step against the HBM roofline: SURVEY 8(d)'s algorithmic bytes of one ecsim step = 334 B per particle
+        # (first_push 72 + assembly 48 + second_push 72 + re-binning 96, + 2952 B of matL per cell) + the Krylov solve,
+        # GMRES iteration j of a cycle = one matA apply (3000 N) + (2 j + 9) vectors of 24 N bytes
+        its_step = its_total / world / args.steps
+        full, frac_it = int(its_step), its_step - int(its_step)
+        it_bytes = lambda j: 3000.0 * N + (2 * j + 9) * 24.0 * N
+        solve_bytes = sum(it_bytes(j % 30) for j in range(full)) + frac_it * it_bytes(full % 30)
+        step_bytes = (72 + 48 + 72 + 96 + 2952.0 / args.ppc) * count_local + solve_bytes
+        gbs_step = step_bytes / (elapsed / args.steps) / 1e9
+        line["roofline_step"] = {
+            "what": "SURVEY 8(d) algorithmic HBM bytes of one whole step (per GPU) / ms_per_step", "bound": "hbm",
+            "achieved": gbs_step, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_step / HBM_PEAK_GBS,
+            "bytes_per_step": step_bytes, "particle_bytes": step_bytes - solve_bytes, "solve_bytes": solve_bytes,
+            "frac_of_device_copy_rate": gbs_step / (copy_rate / 1e9) if copy_rate else None,
+        }
         # algorithmic HBM bytes per particle and step of the ecsim particle phases: first_push 72 +
         # assembly 48 (+ 2952 B of matL per cell) + second_push 72 + re-binning 96
         ms_part = sum(prof[k][1] for k in ("fill_current", "second_push", "move_bin", "scatter", "scan", "rebin")) / args.steps

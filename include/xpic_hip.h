@@ -68,6 +68,11 @@ enum xpic_solve_op {
 #define XPIC_LSTENCIL 123 /* couplings per matL row: 27 same-component + 48 + 48 */
 
 const char* xpic_last_error(void);
+/* XPIC_VERSION, with XPIC_VERSION_EXPERIMENT_BIT set when any object of the library was built with -DXPIC_EXPERIMENT
+ * (ablation switches and in-kernel timers of the kernels; some produce wrong physics by design): refuse such a library
+ * for production runs. */
+#define XPIC_VERSION 2
+#define XPIC_VERSION_EXPERIMENT_BIT 0x40000000
 int xpic_version(void);
 
 /* World::initialize + Simulation::initialize_implementation (world.cpp:11-48; ecsim/simulation.cpp:122-143,
@@ -142,8 +147,14 @@ int xpic_calculate_energy(xpic_ctx* ctx, int sort, double* energy);
 int xpic_ecsimcorr_scalars(xpic_ctx* ctx, int sort, double* out6);
 
 /* KSPSolve (src/impls/ecsim/simulation.cpp:266): x0 = 0, preconditioner as set by xpic_set_preconditioner (both GMRES
- * operators; CG is unpreconditioned), converged when the TRUE residual ||r|| <= max(rtol ||b||, atol) (the cheap
- * preconditioned XPIC_OP_MATM_GMRES is run to 1e-2 of that). *iterations >= 0; *reason > 0 converged, < 0 diverged (maxit).
+ * operators; CG is unpreconditioned), converged when the residual ||b - A x|| <= max(rtol ||b||, atol) (the cheap
+ * preconditioned XPIC_OP_MATM_GMRES is run to 1e-2 of that).  The norm tested (and returned in *rnorm) is GMRES's
+ * RECURRENCE value of the unpreconditioned residual -- right / flexible preconditioning keeps it the residual of A x = b
+ * itself, not of a preconditioned system -- as in PETSc's KSPGMRES; no explicit b - A x is formed at exit (one more apply
+ * per solve).  It equals the true residual up to the orthogonality of the basis: iterations whose entering residual is
+ * above 1e-6 ||b|| take |w - sum h_i v_i| from w.w - sum h_i^2 (one reduction per iteration), later ones and every solve
+ * with a tolerance below 1e-8 ||b|| take the norm explicitly (krylov.hip).  *iterations >= 0; *reason > 0 converged,
+ * < 0 diverged (maxit).
  * A non-converged solve RETURNS NON-ZERO, like KSPSetErrorIfNotConverged (:562). */
 int xpic_solve(xpic_ctx* ctx, int op, int rhs, int x, double rtol, double atol, int maxit, int* iterations,
   int* reason, double* rnorm);
@@ -157,11 +168,16 @@ int xpic_set_tolerances(xpic_ctx* ctx, double rtol, double atol, int maxit);
  * mass matrix as one constant-coefficient 123-point stencil (fp32), for the predict solve (the correct solve on matM keeps
  * kind 1).  The GMRES around it is the flexible variant (x = x0 + sum y_j P v_j with the
  * P v_j stored): the result does not depend on how exactly P is applied, only the iteration count could.
- * degree <= 0 keeps the automatic choice.  The stopping rule of xpic_solve is unchanged: true residual norm. */
+ * degree <= 0 returns to the automatic choice.  The stopping rule of xpic_solve is unchanged (the residual of A x = b).
+ * Kind 3 checks its surrogate per solve (2 + the Gershgorin lower bound of <matL> must be positive) and otherwise runs
+ * that solve with kind 1. */
 int xpic_set_preconditioner(xpic_ctx* ctx, int kind, int degree);
 /* MatMult on a z-slab with neighbours: on = 1 (default) posts the ghost exchange of the operand (VecScatterBegin), applies
  * the rows of the interior planes meanwhile and the rows of the boundary planes after it (VecScatterEnd), as PETSc's
- * MPIAIJ MatMult does (the reference's KSPSolve, src/impls/ecsim/simulation.cpp:266); on = 0 exchanges first. Same result. */
+ * MPIAIJ MatMult does (the reference's KSPSolve, src/impls/ecsim/simulation.cpp:266); on = 0 exchanges first. Same result.
+ * The same switch covers the assembly's ghost-row exchange of matL (posted beside the interior colour launches).
+ * Default: on, except over RCCL with more than one rank, where the second-stream path has not yet run on two distinct
+ * GPUs: there it is off unless this call (or XPIC_RCCL_OVERLAP=1) turns it on. */
 int xpic_set_overlap(xpic_ctx* ctx, int on);
 
 /* timestep_implementation of the context's scheme (basic/simulation.cpp:30-43, ecsim/simulation.cpp:145-155,

@@ -652,6 +652,13 @@ void matM_apply(const orc_sim* s, const double* x, double* y)
 void matL_apply(const orc_sim* s, const double* x, double* y, bool add)
 {
   const Grid& gr = s->gr;
+  /* matL before its first assembly is the zero matrix (MatZeroEntries, simulation.cpp:164): an apply or a solve on a
+   * simulation whose fill_ecsim_current never ran must not index the still empty value array -- every thread of the
+   * team below would fault at once */
+  if (s->matL.size() != (size_t)gr.N * 3 * ORC_LSTENCIL) {
+    if (!add) std::fill(y, y + gr.N * 3, 0.0);
+    return;
+  }
   static int dec[3][ORC_LSTENCIL][4];
   static bool built = false;
   if (!built) {

@@ -8,7 +8,8 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+# XPIC_ORACLE_SO: another build of the same sources (tests/test_oracle_sanitized.py loads the ASan/UBSan one)
+_SO = os.environ.get("XPIC_ORACLE_SO") or os.path.join(ROOT, "oracle", "liboracle.so")
 
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int)

@@ -33,6 +33,25 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
 
 
+def test_library_is_not_an_experiment_build():
+    """xpic_version() carries bit 30 when any object was compiled with -DXPIC_EXPERIMENT (FILL_EXP / ESK_EXP ablations
+    and in-kernel stamps, some of which compute garbage on purpose): such a library must not pass as the product."""
+    import xpic_amd
+
+    if not os.path.exists(xpic_amd.LIB_PATH):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    lib = ctypes.CDLL(xpic_amd.LIB_PATH)
+    v = lib.xpic_version()
+    assert v & 0x40000000 == 0, "libxpic_hip.so is an XPIC_EXPERIMENT build: make clean all"
+    hdr = open(os.path.join(ROOT, "include", "xpic_hip.h")).read()
+    assert v == int(re.search(r"#define XPIC_VERSION (\d+)", hdr).group(1))
+    # the ablation switches refuse to compile without the experiment switch
+    src = open(os.path.join(ROOT, "xpic_amd", "csrc", "common.h")).read()
+    assert "#error" in src and "XPIC_EXPERIMENT" in src
+
+
 def test_no_cpu_fallback_without_a_device():
     """Without a HIP device xpic_create must fail loudly (never route to a CPU path)."""
     import torch

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Section shares of the Esirkepov push kernels (build with EXTRA=-DESK_STAMPS): esk_stamps.py [grid] [ppc]"""
+"""Section shares of the Esirkepov push kernels (build with EXTRA="-DXPIC_EXPERIMENT -DESK_STAMPS", run with XPIC_ALLOW_EXPERIMENT=1): esk_stamps.py [grid] [ppc]"""
 import ctypes as C
 import os
 import sys

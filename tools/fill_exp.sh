@@ -5,8 +5,8 @@ R=$GRAFT_REPO_ROOT
 cd $R
 for e in $1; do
   rm -f xpic_amd/csrc/ecsim.o
-  F=-DFILL_EXP=$e; [ "$e" = s ] && F=-DFILL_STAMPS
-  make -s xpic_amd/libxpic_hip.so EXTRA=$F > gpurun_out/fill_exp_build_$e.log 2>&1 || { tail gpurun_out/fill_exp_build_$e.log; exit 1; }
+  F="-DXPIC_EXPERIMENT -DFILL_EXP=$e"; [ "$e" = s ] && F="-DXPIC_EXPERIMENT -DFILL_STAMPS"; export XPIC_ALLOW_EXPERIMENT=1
+  make -s xpic_amd/libxpic_hip.so EXTRA="$F" > gpurun_out/fill_exp_build_$e.log 2>&1 || { tail gpurun_out/fill_exp_build_$e.log; exit 1; }
   echo -n "FILL_EXP=$e: "
   timeout -k 10 300 python tools/fill_bench.py ${2:-256} ${3:-64} 3 2> gpurun_out/fill_exp_$e.err | tail -12 || { tail -3 gpurun_out/fill_exp_$e.err; }
 done

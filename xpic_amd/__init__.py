@@ -57,6 +57,9 @@ class Geometry(C.Structure):
                 ("rank", C.c_int32), ("nranks", C.c_int32), ("device", C.c_int32), ("self_ring", C.c_int32)]
 
 
+VERSION_EXPERIMENT_BIT = 0x40000000  # include/xpic_hip.h: XPIC_VERSION_EXPERIMENT_BIT
+
+
 class SortParams(C.Structure):
     _fields_ = [("Np", C.c_int32), ("n", C.c_double), ("q", C.c_double), ("m", C.c_double)]
 
@@ -75,6 +78,10 @@ def load_library():
                         "xpic_amd has no CPU fallback")
     L = C.CDLL(LIB_PATH)
     L.xpic_last_error.restype = C.c_char_p
+    if L.xpic_version() & VERSION_EXPERIMENT_BIT and os.environ.get("XPIC_ALLOW_EXPERIMENT") != "1":
+        raise XpicError(f"{LIB_PATH} was built with -DXPIC_EXPERIMENT (ablation switches / in-kernel timers: its results "
+                        "may be wrong by design); rebuild with `make clean all`, or set XPIC_ALLOW_EXPERIMENT=1 for a "
+                        "measurement script")
     _lib = L
     return L
 

@@ -80,6 +80,7 @@ static int ensure_flexible_workspace(xpic_ctx* c)
     if (c->kry_Z) { XPIC_HIP(hipStreamSynchronize(c->stream)); XPIC_HIP(hipFree(c->kry_Z)); c->kry_Z = nullptr; }
     return 0;
   }
+  if (c->precond == 3 && c->matL) XPIC_CALL(abar_alloc(c)); // kind 3's surrogate: buffers and matM's coefficients
   if (c->kry_Z) return 0;
   XPIC_HIP(hipMalloc(&c->kry_Z, sizeof(double) * c->nvec * 30));
   XPIC_HIP(hipMemsetAsync(c->kry_Z, 0, sizeof(double) * c->nvec * 30, c->stream));
@@ -277,7 +278,12 @@ using namespace xpic;
 extern "C" {
 
 const char* xpic_last_error(void) { return g_error.c_str(); }
-int xpic_version(void) { return 1; }
+int xpic_version(void)
+{
+  // bit 30: some object of this library was built with -DXPIC_EXPERIMENT (ablation switches, in-kernel timers)
+  const bool exp = XPIC_TU_EXPERIMENT || experiment_ecsim() || experiment_esirkepov();
+  return XPIC_VERSION | (exp ? XPIC_VERSION_EXPERIMENT_BIT : 0);
+}
 
 int xpic_create(const xpic_geometry* geom, int scheme, xpic_ctx** out)
 {
@@ -291,7 +297,8 @@ int xpic_create(const xpic_geometry* geom, int scheme, xpic_ctx** out)
     "basic and ecsimcorr need every grid extent >= 4 cells (>= 6 for their pushes)");
   XPIC_CHECK(geom->nranks >= 1 && geom->rank >= 0 && geom->rank < geom->nranks, "bad rank / nranks");
   XPIC_CHECK(geom->n[2] % geom->nranks == 0, "nz must be divisible by the number of z-slabs");
-  XPIC_CHECK(geom->nranks == 1 || geom->n[2] / geom->nranks >= 6, "a z-slab must hold at least 6 planes");
+  // (self_ring slabs too: halo_add's two sides are one launch and must not overlap, 2 x 3 planes)
+  XPIC_CHECK((geom->nranks == 1 && !geom->self_ring) || geom->n[2] / geom->nranks >= 6, "a z-slab must hold at least 6 planes");
   XPIC_CHECK(scheme == XPIC_BASIC || scheme == XPIC_ECSIM || scheme == XPIC_ECSIMCORR, "unknown scheme");
   int ndev = 0;
   XPIC_HIP(hipGetDeviceCount(&ndev));
@@ -355,9 +362,9 @@ int xpic_create(const xpic_geometry* geom, int scheme, xpic_ctx** out)
       const double kappa = 1.0 + g.dt * g.dt * (1.0 / (g.dx * g.dx) + 1.0 / (g.dy * g.dy) + 1.0 / (g.dz * g.dz));
       const double rho = (std::sqrt(kappa) - 1.0) / (std::sqrt(kappa) + 1.0);
       int k = rho > 0 ? (int)std::ceil(std::log(0.04) / std::log(rho)) : 2;
-      c->cheb_degree = k < 2 ? 2 : (k > 32 ? 32 : k);
+      c->cheb_degree = c->cheb_degree_auto = k < 2 ? 2 : (k > 32 ? 32 : k);
       int kM = rho > 0 ? (int)std::ceil(std::log(XPIC_CHEB_M_BOUND) / std::log(rho)) : 2;
-      c->cheb_degree_M = kM < 2 ? 2 : (kM > 48 ? 48 : kM);
+      c->cheb_degree_M = c->cheb_degree_M_auto = kM < 2 ? 2 : (kM > 48 ? 48 : kM);
     }
     XPIC_CALL(build_ltab(c));
     XPIC_CALL(ensure_flexible_workspace(c));
@@ -674,6 +681,7 @@ int xpic_set_preconditioner(xpic_ctx* ctx, int kind, int degree)
   ctx->precond = kind;
   ctx->cheb_degree_user = degree > 0 ? (degree > 64 ? 64 : degree) : 0;
   if (degree > 0) ctx->cheb_degree = ctx->cheb_degree_M = ctx->cheb_degree_user;
+  else { ctx->cheb_degree = ctx->cheb_degree_auto; ctx->cheb_degree_M = ctx->cheb_degree_M_auto; } // back to the automatic choice
   return ensure_flexible_workspace(ctx);
 }
 
@@ -681,6 +689,7 @@ int xpic_set_overlap(xpic_ctx* ctx, int on)
 {
   CTX_CHECK(ctx);
   ctx->overlap = on != 0;
+  ctx->overlap_explicit = true;
   return 0;
 }
 

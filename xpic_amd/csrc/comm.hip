@@ -8,6 +8,8 @@
 
 #include <cstring>
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace xpic {
@@ -143,6 +145,15 @@ int xpic_comm_init_rccl(xpic_ctx* ctx, const void* id128)
   ctx->comm.nccl = nc;
   ctx->comm.rank = ctx->geom.rank;
   ctx->comm.nranks = ctx->geom.nranks;
+  // The overlapped exchanges (fields.hip: op_apply_overlapped, the matL ghost rows beside the interior colours) put
+  // send/recv on comm_stream while all-reduces go on the compute stream, on ONE communicator.  Every rank issues them
+  // in the same program order, which is what RCCL asks for, but the only hardware that has run this branch is a
+  // one-GPU self-ring: until a run on two distinct GPUs exists, N > 1 over RCCL exchanges first (no second stream)
+  // unless the caller asked for the overlap (xpic_set_overlap(ctx, 1) or XPIC_RCCL_OVERLAP=1).
+  if (ctx->geom.nranks > 1 && !ctx->overlap_explicit) {
+    const char* e = getenv("XPIC_RCCL_OVERLAP");
+    ctx->overlap = e && e[0] == '1';
+  }
   return 0;
 }
 

@@ -10,9 +10,25 @@
 
 #include "../../include/xpic_hip.h"
 
+// Experiment builds.  The kernels carry ablation switches and in-kernel timers (FILL_EXP, FILL_STAMPS, ESK_EXP, ESK_STAMPS:
+// some of them produce wrong physics by design).  They are honoured ONLY under -DXPIC_EXPERIMENT, and an object built that
+// way says so through xpic_version() (bit 30 set), which tests/test_abi.py and xpic_amd/__init__.py refuse: a stray
+// EXTRA=-DFILL_EXP=1 no longer builds a library that loads and passes the ABI test.
+#if !defined(XPIC_EXPERIMENT) && ((defined(FILL_EXP) && FILL_EXP != 0) || defined(FILL_STAMPS) || (defined(ESK_EXP) && ESK_EXP != 0) || defined(ESK_STAMPS))
+#error "FILL_EXP / FILL_STAMPS / ESK_EXP / ESK_STAMPS are experiment switches: build with -DXPIC_EXPERIMENT as well"
+#endif
+#ifdef XPIC_EXPERIMENT
+#define XPIC_TU_EXPERIMENT 1
+#else
+#define XPIC_TU_EXPERIMENT 0
+#endif
+
 namespace xpic {
 
 void set_error(const std::string& msg);
+// 1 when the translation unit was built with -DXPIC_EXPERIMENT (one per kernel file that has experiment switches)
+int experiment_ecsim();
+int experiment_esirkepov();
 
 #define XPIC_HIP(call)                                                                         \
   do {                                                                                         \
@@ -161,9 +177,11 @@ struct xpic_ctx {
   int cheb_degree = 0; // steps of the Chebyshev iteration on matM (set at create from the spectral interval)
   int cheb_degree_M = 0; // the same iteration as the preconditioner of a solve ON matM (ecsimcorr's "correct"): a tighter bound pays there
   int cheb_degree_user = 0; // explicit degree from xpic_set_preconditioner (0: automatic)
+  int cheb_degree_auto = 0, cheb_degree_M_auto = 0; // the automatic degrees of xpic_create (restored by degree <= 0)
   float* abar32 = nullptr;    // kind 3: the 3 x 124 coefficients of Abar = matM + <matL>
   double* abar_work = nullptr; // sums, matM's coefficients, fp64 Abar, per-row partials
   double abar_lo = 0, abar_hi = 0; // spectral interval of Abar
+  double abar_gershgorin = 0;      // 2 + Gershgorin lower bound of Lbar: kind 3 is used only while this is positive
   bool abar_valid = false;
   double* red_partial = nullptr; // reduction partials
   double* red_out = nullptr;     // device results (pinned mirror below)
@@ -180,6 +198,7 @@ struct xpic_ctx {
   hipEvent_t comm_ev[2] = {nullptr, nullptr}; // packed (compute -> comm), ghosts in place (comm -> compute)
   bool halo_posted = false;
   bool overlap = true;
+  bool overlap_explicit = false; // set by xpic_set_overlap: xpic_comm_init_rccl then leaves the choice alone
   bool profiling = false;
   std::map<std::string, xpic::ProfileEntry> prof;
   std::vector<hipEvent_t> event_pool;
@@ -223,6 +242,7 @@ int op_apply_overlapped(xpic_ctx* c, bool with_L, double* x, double* y); // halo
 int cheb_matM_inverse(xpic_ctx* c, const double* r, double* out, int degree);
 int halo_fill_f32(xpic_ctx* c, float* f, int width);
 // precond.hip
+int abar_alloc(xpic_ctx* c);                                      // kind 3's buffers (with the context, not inside a solve)
 int abar_update(xpic_ctx* c);                                     // Abar = matM + <matL> from the assembled matL
 int cheb_abar_inverse(xpic_ctx* c, const double* r, double* out); // out ~ Abar^-1 r
 int cg_apply_dot_host(xpic_ctx* c, const double* p, double* Ap, double* pAp);                       // Ap = matM p, p . Ap

@@ -81,6 +81,8 @@ extern "C" int xpic_debug_fill_stamps(double* out, int reset)
 #endif
 namespace xpic {
 
+int experiment_ecsim() { return XPIC_TU_EXPERIMENT; }
+
 namespace {
 
 constexpr int kW = 4;             // waves per workgroup = cells per chunk

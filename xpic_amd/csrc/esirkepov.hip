@@ -36,6 +36,8 @@
 
 namespace xpic {
 
+int experiment_esirkepov() { return XPIC_TU_EXPERIMENT; }
+
 namespace {
 
 #ifdef ESK_STAMPS

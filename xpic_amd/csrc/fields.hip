@@ -990,6 +990,8 @@ int halo_add(xpic_ctx* c, double* f, int width)
   const GridDev& g = c->g;
   if (g.G == 0) return 0;
   XPIC_CHECK(width <= g.G && width <= g.nzl, "halo width exceeds the ghost layer");
+  // both sides are added by ONE launch (plain +=): the bottom and the top plane ranges must not share a plane
+  XPIC_CHECK(2 * width <= g.nzl, "halo_add: the slab is thinner than its two halo layers");
   Timed t(c, "halo");
   const long n = 3L * width * g.plane;
   const size_t bytes = sizeof(double) * n;

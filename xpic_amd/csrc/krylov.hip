@@ -38,8 +38,12 @@ int gmres(xpic_ctx* c, int op, const double* b, double* x, double rtol, double a
   // could fail on one slab alone and leave the others waiting in the solve's collectives
   XPIC_CHECK(!pc || c->kry_Z, "flexible GMRES workspace missing (xpic_set_preconditioner allocates it)");
   // kind 3: the predict solve's polynomial is in matM + <matL>, rebuilt from the matL this solve runs on
-  const bool pc_abar = pc && c->precond == 3 && op == XPIC_OP_MATA_GMRES;
-  if (pc_abar) XPIC_CALL(abar_update(c));
+  bool pc_abar = pc && c->precond == 3 && op == XPIC_OP_MATA_GMRES;
+  if (pc_abar) {
+    XPIC_CALL(abar_update(c));
+    // the surrogate's Gershgorin check failed (precond.hip): this solve falls back to the matM polynomial, on every slab
+    if (!c->abar_valid) { pc_abar = false; if (c->profiling) c->prof["precond_fallback"].launches += 1; }
+  }
   double* Z = c->kry_Z;
   double* V = c->kry_V;
   double* w = c->kry_w;

@@ -351,22 +351,64 @@ __global__ void __launch_bounds__(kB, 2) k_cheb_bar(GridDev g, const float* __re
 
 int halo_fill_f32(xpic_ctx* c, float* f, int width);
 
-// (re)build Abar = matM + <matL>: called once per assembly, before the predict solve
+namespace {
+
+// rows of the translation average: every 4th row in y and z of extents that have 16
+inline void lbar_rows(const GridDev& g, int* sy, int* sz, int* nys, int* nrows)
+{
+  *sy = g.ny >= 16 ? 4 : 1;
+  *sz = g.nzl >= 16 ? 4 : 1;
+  *nys = (g.ny + *sy - 1) / *sy;
+  *nrows = *nys * ((g.nzl + *sz - 1) / *sz);
+}
+
+// bounds of Lbar = Abar - matM per row component c1 (one wave each): out[c1] = sum_k |Lbar[c1][k]| (widens the top of the
+// spectral interval), out[3 + c1] = Lbar's diagonal minus the absolute sum of its other entries (Gershgorin: a lower
+// bound of the real parts of Lbar's eigenvalues, rotation part included)
+__global__ void __launch_bounds__(64) k_abar_bounds(const double* __restrict__ abar64, const double* __restrict__ mco, double* out)
+{
+  const int c1 = blockIdx.x, lane = threadIdx.x;
+  const int kdiag = lencode(c1, c1, 0, 0, 0);
+  double sa = 0.0, diag = 0.0;
+  for (int k = lane; k < kLStencil; k += 64) {
+    const double v = abar64[c1 * kLPad + k] - mco[c1 * kLPad + k];
+    sa += fabs(v);
+    if (k == kdiag) diag = v;
+  }
+  for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o); diag += __shfl_xor(diag, o); }
+  if (lane == 0) { out[c1] = sa; out[3 + c1] = diag - (sa - fabs(diag)); }
+}
+
+}  // namespace
+
+// kind 3's buffers and matM's probed coefficients: sized and uploaded with the context (api.hip:
+// ensure_flexible_workspace, at xpic_create / xpic_set_preconditioner time), like kry_Z -- an allocation inside the first
+// solve of a step could fail on one slab alone and leave the others waiting in the solve's collectives
+int abar_alloc(xpic_ctx* c)
+{
+  if (c->abar32) return 0;
+  const GridDev& g = c->g;
+  int sy, sz, nys, nrows;
+  lbar_rows(g, &sy, &sz, &nys, &nrows);
+  XPIC_HIP(hipMalloc(&c->abar32, sizeof(float) * kLinesUsed * kCoefPitch));
+  XPIC_HIP(hipMemsetAsync(c->abar32, 0, sizeof(float) * kLinesUsed * kCoefPitch, c->stream));
+  XPIC_HIP(hipMalloc(&c->abar_work, sizeof(double) * (3 * kLPad * 3 + ((size_t)nrows + kSegs) * 3 * kLBlock)));
+  double mco[3 * kLPad];
+  matM_stencil(g, mco);
+  XPIC_HIP(hipMemcpyAsync(c->abar_work + 3 * kLPad, mco, sizeof(mco), hipMemcpyHostToDevice, c->stream));
+  XPIC_HIP(hipStreamSynchronize(c->stream)); // mco is a stack array
+  return 0;
+}
+
+// (re)build Abar = matM + <matL>: called once per assembly, before the predict solve.  No allocation, no pageable copy:
+// the two bounds the host needs come back through the pinned reduction mirror.
 int abar_update(xpic_ctx* c)
 {
   const GridDev& g = c->g;
   Timed t(c, "precond_setup");
-  const int sy = g.ny >= 16 ? 4 : 1, sz = g.nzl >= 16 ? 4 : 1;
-  const int nys = (g.ny + sy - 1) / sy, nzs = (g.nzl + sz - 1) / sz;
-  const int nrows = nys * nzs;
-  if (!c->abar32) {
-    XPIC_HIP(hipMalloc(&c->abar32, sizeof(float) * kLinesUsed * kCoefPitch));
-    XPIC_HIP(hipMemsetAsync(c->abar32, 0, sizeof(float) * kLinesUsed * kCoefPitch, c->stream));
-    XPIC_HIP(hipMalloc(&c->abar_work, sizeof(double) * (3 * kLPad * 3 + ((size_t)nrows + kSegs) * 3 * kLBlock)));
-    double mco[3 * kLPad];
-    matM_stencil(g, mco);
-    XPIC_HIP(hipMemcpy(c->abar_work + 3 * kLPad, mco, sizeof(mco), hipMemcpyHostToDevice));
-  }
+  XPIC_CHECK(c->abar32 && c->abar_work, "kind-3 preconditioner workspace missing (xpic_set_preconditioner allocates it)");
+  int sy, sz, nys, nrows;
+  lbar_rows(g, &sy, &sz, &nys, &nrows);
   double* sums = c->abar_work;                  // [3][kLPad]
   double* mco = c->abar_work + 3 * kLPad;       // matM's coefficients
   double* abar64 = c->abar_work + 6 * kLPad;
@@ -379,22 +421,24 @@ int abar_update(xpic_ctx* c)
   XPIC_CALL(comm_allreduce_sum(c, sums, 3 * kLPad)); // the same surrogate on every slab
   const double count = (double)nrows * g.nx * c->comm.nranks;
   hipLaunchKernelGGL(k_abar, dim3(2), dim3(256), 0, c->stream, sums, mco, 1.0 / count, c->abar32, abar64);
+  double* bounds = c->red_out + 64; // [64, 70): behind the reductions' and the host all-reduce's slots
+  hipLaunchKernelGGL(k_abar_bounds, dim3(3), dim3(64), 0, c->stream, abar64, mco, bounds);
   XPIC_HIP(hipGetLastError());
-  // spectral interval of Abar for the Chebyshev polynomial: matM's exact interval [2, 2 + 2 dt^2 sum 1/h^2], widened
-  // at the top by the largest absolute row sum of Lbar (Lbar is positive semi-definite up to its small rotation part)
-  double h[3 * kLPad], hm[3 * kLPad];
-  XPIC_HIP(hipMemcpyAsync(h, abar64, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-  XPIC_HIP(hipMemcpyAsync(hm, mco, sizeof(hm), hipMemcpyDeviceToHost, c->stream));
+  double* hb = c->red_host + 48;
+  XPIC_HIP(hipMemcpyAsync(hb, bounds, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
   XPIC_HIP(hipStreamSynchronize(c->stream));
-  double rs = 0.0;
-  for (int c1 = 0; c1 < 3; ++c1) {
-    double s = 0.0;
-    for (int k = 0; k < kLStencil; ++k) s += std::fabs(h[c1 * kLPad + k] - hm[c1 * kLPad + k]);
-    rs = std::max(rs, s);
-  }
+  // Spectral interval of Abar for the Chebyshev polynomial.  Top: matM's exact 2 + 2 dt^2 sum 1/h^2 widened by the largest
+  // absolute row sum of Lbar.  Bottom: matM's exact 2 -- the Hermitian part of every particle's block is positive
+  // semi-definite ((s s^T) o (I + b b^T)) and a translation average keeps that -- PROVIDED Lbar's Gershgorin bound
+  // (rotation part of a strong B and the sub-sampled average included) leaves the interval on the positive side: if
+  // 2 + min_c (diag - sum |off-diagonal|) is not positive the surrogate is not trusted and this solve runs the matM
+  // polynomial (kind 1) instead (the sums are all-reduced, so every slab takes the same branch).
+  const double rs = std::max(hb[0], std::max(hb[1], hb[2]));
+  const double gl = std::min(hb[3], std::min(hb[4], hb[5]));
   c->abar_lo = 2.0;
   c->abar_hi = 2.0 + 2.0 * g.dt * g.dt * (1.0 / (g.dx * g.dx) + 1.0 / (g.dy * g.dy) + 1.0 / (g.dz * g.dz)) + rs;
-  c->abar_valid = true;
+  c->abar_gershgorin = 2.0 + gl;
+  c->abar_valid = std::isfinite(rs) && 2.0 + gl > 0.0;
   return 0;
 }
 
