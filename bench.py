@@ -51,6 +51,8 @@ def parse_args(argv=None):
                     help="skip the device copy probe (1 GiB device-to-device copies: the achievable copy rate of THIS box, "
                          "SURVEY 8(d); on by default, outside the timed region)")
     ap.add_argument("--plain-gmres", action="store_true", help="unpreconditioned GMRES(30), as the CPU oracle runs")
+    ap.add_argument("--fill-kernel", type=int, default=None, choices=[0, 1],
+                    help="mass-matrix assembly: 1 warp-specialised kernel, 0 the classic 4-wave kernel (default: the library's)")
     ap.add_argument("--cheb-degree", type=int, default=0, help="override the Chebyshev preconditioner degree (experiments)")
     ap.add_argument("--precond", type=int, default=None, choices=[0, 1, 2, 3],
                     help="xpic_set_preconditioner kind (default: the library's)")
@@ -454,6 +456,8 @@ def rank_body(args, rank, world, local_rank, job):
         torch.cuda.synchronize()
         job.barrier()
 
+    if args.scheme != "basic" and args.fill_kernel is not None:
+        ctx.set_fill_kernel(args.fill_kernel)
     if args.plain_gmres and args.scheme != "basic":
         ctx.set_preconditioner(0)
     elif (args.cheb_degree > 0 or args.precond is not None) and args.scheme != "basic":
@@ -564,9 +568,10 @@ def rank_body(args, rank, world, local_rank, job):
         tf = flop_launch / (avg_ms * 1e-3) / 1e12
         bytes_launch = (48.0 + 2952.0 / args.ppc) * count_local / launches_per_step
         fill = {
-            "kernel": "k_ecsim_fill (mass matrix + currI; one colour launch)", "bound": "mfma",
+            "kernel": ("k_ecsim_fill_ws" if ctx.fill_variant()[2] else "k_ecsim_fill") + " (mass matrix + currI; one colour launch)",
+            "bound": "mfma",
             "achieved": tf, "peak": FP64_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TF,
-            "traffic": pmc_traffic(args.scheme, n3, "k_ecsim_fill") if world == 1 else None,
+            "traffic": pmc_traffic(args.scheme, n3, "k_ecsim_fill_ws" if ctx.fill_variant()[2] else "k_ecsim_fill<") if world == 1 else None,
             "flop_per_particle": FILL_FLOP_PER_PARTICLE, "flop_per_launch": flop_launch,
             "launches": n_fill, "launches_per_step": launches_per_step, "avg_ms": avg_ms,
             "ms_per_assembly": ms_fill / args.steps,

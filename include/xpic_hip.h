@@ -172,6 +172,13 @@ int xpic_set_tolerances(xpic_ctx* ctx, double rtol, double atol, int maxit);
  * Kind 3 checks its surrogate per solve (2 + the Gershgorin lower bound of <matL> must be positive) and otherwise runs
  * that solve with kind 1. */
 int xpic_set_preconditioner(xpic_ctx* ctx, int kind, int degree);
+/* The mass-matrix assembly (fill_ecsim_current) has two bodies: kind 1 (default) the warp-specialised kernel (one 8-wave
+ * workgroup per CU: producer waves run the per-particle algebra and the window's read-modify-write, consumer waves the
+ * matrix-core accumulation), used where nx is a multiple of 4 and no extent is below 3; kind 0 the classic 4-wave kernel
+ * (all grids).  Same matrix up to the summation order of a cell's neighbours.  xpic_get_fill_variant: out3 = {power-of-two
+ * spacings, full-chunk body, warp-specialised body} as the next assembly of this context will run. */
+int xpic_set_fill_kernel(xpic_ctx* ctx, int kind);
+int xpic_get_fill_variant(xpic_ctx* ctx, int* out3);
 /* MatMult on a z-slab with neighbours: on = 1 (default) posts the ghost exchange of the operand (VecScatterBegin), applies
  * the rows of the interior planes meanwhile and the rows of the boundary planes after it (VecScatterEnd), as PETSc's
  * MPIAIJ MatMult does (the reference's KSPSolve, src/impls/ecsim/simulation.cpp:266); on = 0 exchanges first. Same result.

@@ -165,6 +165,26 @@ def test_fill_current_and_matL(oracle, B0, grid):
     assert np.abs(g.get_field(X.W2) - ref).max() <= 1e-12 * np.abs(ref).max()
 
 
+@BOTH_GRIDS
+def test_both_assembly_kernels_match_the_oracle(oracle, grid):
+    """The warp-specialised assembly (the default where nx % 4 == 0: the body bench.py times) and the classic kernel on
+    the same particles: currI and matL within 1e-12 of the oracle for both, B != 0, two species."""
+    import xpic_amd as X
+
+    n, d, dt = grid
+    o, g = make_pair(oracle, "ecsim", n, d, dt, [(6, 1.0, -1.0, 1.0), (6, 1.0, +1.0, 100.0)], B0=(0.3, -0.2, 0.9), ppc=40)
+    g.set_fill_kernel(1)
+    assert g.fill_variant() == (grid is GRID_P2FX, True, True)
+    oracle.lib().orc_ecsim_fill_current(o.h)
+    Lo, ci_o = o.matL(), o.get_field("currI")
+    for kind in (1, 0):
+        g.set_fill_kernel(kind)
+        assert g.fill_variant()[2] == bool(kind)
+        g.ecsim_fill_current()
+        assert np.abs(ci_o - g.get_field(X.CURRI)).max() <= 1e-12 * np.abs(ci_o).max(), kind
+        assert np.abs(Lo - g.matL()).max() <= 1e-12 * np.abs(Lo).max(), kind
+
+
 def test_lstencil_layout_is_shared(oracle):
     import xpic_amd as X
     import ctypes as C

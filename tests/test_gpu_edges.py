@@ -86,6 +86,51 @@ def test_ragged_cells_and_long_cells(oracle):
     assert np.array_equal(co, cg) and np.abs(po - pg).max() < 1e-9
 
 
+@pytest.mark.parametrize("d", [(0.5, 0.4, 0.3), (0.5, 0.25, 0.5)], ids=["general", "pow2"])
+def test_assembly_kernels_on_pass_boundaries(oracle, d):
+    """Both assembly kernels (xpic_set_fill_kernel: 1 = warp-specialised producer / consumer waves with 44-slot stage
+    buffers, 0 = classic 64-slot passes) on one pencil whose cells hold 0, 1, 3, 4, 5, 43, 44, 45, 47, 48, 63, 64, 65,
+    87, 88, 89, 131, 133 and 700 particles -- every way a cell can end on, just before or just after a pass or a K = 4
+    step -- with vacuum in between, two species, B != 0: currI and matL equal the oracle's to 1e-12 for both."""
+    import xpic_amd as X
+
+    n = (24, 7, 6)
+    o, g = pair(oracle, "ecsim", n, d, 0.5)
+    rng = np.random.default_rng(12)
+    counts = [0, 1, 3, 4, 5, 43, 44, 45, 47, 48, 63, 64, 65, 87, 88, 89, 131, 133, 700, 0, 2, 46, 90, 7]
+    for sp, (q, m) in enumerate(((-1.0, 1.0), (1.0, 30.0))):
+        o.add_sort(10, 1.0, q, m)
+        g.add_sort(10, 1.0, q, m, capacity=20000)
+        pts = []
+        for cx, cnt in enumerate(counts if sp == 0 else counts[::-1]):
+            for (cy, cz) in ((3, 2), (4, 2), (0, 5)):  # two y-neighbouring pencils and one across the periodic z edge
+                c = cnt if (cy, cz) == (3, 2) else cnt // 3
+                if c:
+                    r = (np.array([cx, cy, cz]) + rng.random((c, 3))) * np.array(d)
+                    pts.append(np.hstack([r, rng.normal(0, 0.2, (c, 3))]))
+        pts = np.vstack(pts)
+        assert o.add_particles(sp, pts) == g.add_particles(sp, pts) == len(pts)
+    B = rng.normal(0, 0.3, o.fshape()) + np.array([0.1, -0.2, 0.4])
+    for name, fid in (("B", X.B), ("B0", X.B0)):
+        o.set_field(name, B)
+        g.set_field(fid, B)
+    oracle.lib().orc_ecsim_fill_current(o.h)
+    Lo = o.matL()
+    g.set_fill_kernel(1)
+    assert g.fill_variant() == (d[1] == 0.25, True, True)
+    for kind in (1, 0, 1):
+        g.set_fill_kernel(kind)
+        assert g.fill_variant()[2] == bool(kind)
+        g.ecsim_fill_current()
+        Lg = g.matL()
+        assert np.abs(Lo - Lg).max() <= 1e-12 * np.abs(Lo).max(), kind
+        assert np.count_nonzero(Lg) == np.count_nonzero(Lo), kind
+        same_fields(o, g, ["currI"], 1e-12)
+        for sp in range(2):
+            a, b = o.sort_current(sp, "currI"), g.sort_current(sp, X.CURRI)
+            assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max(), (kind, sp)
+
+
 def test_single_particle_basic(oracle):
     import xpic_amd as X
 

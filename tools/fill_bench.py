@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times xpic_ecsim_fill_current alone (no solve: usable with the FILL_EXP builds whose results are garbage).
-usage: fill_bench.py [grid] [ppc] [reps]"""
+usage: fill_bench.py [grid] [ppc] [reps] [kernels]     kernels: e.g. "1 0 1 0" = A/B/A/B of the warp-specialised (1) and classic (0) body"""
 import os
 import sys
 
@@ -18,8 +18,19 @@ B = np.zeros(ctx.fshape())
 B[..., 2] = 0.2
 ctx.set_field(X.B, B)
 ctx.set_field(X.B0, B)
+kinds = [int(k) for k in sys.argv[4].split()] if len(sys.argv) > 4 else [1]
 ctx.ecsim_fill_current()
 ctx.profile_enable(True)
+for kind in kinds[:-1]:
+    ctx.set_fill_kernel(kind)
+    ctx.ecsim_fill_current()
+    ctx.profile_reset()
+    for _ in range(reps):
+        ctx.ecsim_fill_current()
+    nl, ms = ctx.profile_get("fill_current")
+    print("kernel %d %s: %.2f ms per assembly (%d colour launches, %.3f ms each)" % (kind, ctx.fill_variant(), ms / reps, nl // reps, ms / nl), flush=True)
+ctx.set_fill_kernel(kinds[-1])
+ctx.ecsim_fill_current()
 ctx.profile_reset()
 for _ in range(reps):
     ctx.ecsim_fill_current()
@@ -31,8 +42,22 @@ if hasattr(ctx.L, "xpic_debug_fill_stamps"):
     names = ["loop top", "phase 1", "phase 2", "prefetch + RMW issue", "barrier 1", "seed + barrier 2",
              "merge + barrier 3", "flush", "barrier 4"]
     tot = st[:9].sum()
-    print("section shares of wave 0 (s_memtime ticks, all workgroups, warm-up included):")
-    for k, nm in enumerate(names):
-        print("  %-22s %6.2f %%" % (nm, 100 * st[k] / tot))
+    if tot > 0:
+        print("section shares of wave 0 (s_memtime ticks, all workgroups, warm-up included):")
+        for k, nm in enumerate(names):
+            print("  %-22s %6.2f %%" % (nm, 100 * st[k] / tot))
+if hasattr(ctx.L, "xpic_debug_fill_ws_stamps") and kinds[-1] == 1:
+    import ctypes as C
+    st = np.zeros(16)
+    ctx.synchronize()
+    ctx.L.xpic_debug_fill_ws_stamps(st.ctypes.data_as(C.POINTER(C.c_double)), 0)
+    for base, role, names in ((0, "consumer wave 0", ["wait FULL", "header", "phase 2", "post FREE", "offsets + chunk tail", "wait SEEDED", "merge + bump", "-"]),
+                              (8, "producer wave 4", ["wait FREE / poll", "flush + seed", "cell prologue / prefetch", "phase 1", "header + next loads + post FULL", "drain wait", "tail", "-"])):
+        tot = st[base:base + 8].sum()
+        print("section shares of %s (s_memtime ticks, all workgroups, warm-up included):" % role)
+        for k, nm in enumerate(names):
+            if st[base + k]:
+                print("  %-34s %6.2f %%" % (nm, 100 * st[base + k] / tot))
 nl, ms = ctx.profile_get("fill_current")
+print("kernel %d %s: " % (kinds[-1], ctx.fill_variant()), end="")
 print("fill_current: %.2f ms per assembly (%d colour launches, %.3f ms each)" % (ms / reps, nl // reps, ms / nl))

@@ -8,6 +8,6 @@ for e in $1; do
   F="-DXPIC_EXPERIMENT -DFILL_EXP=$e"; [ "$e" = s ] && F="-DXPIC_EXPERIMENT -DFILL_STAMPS"; export XPIC_ALLOW_EXPERIMENT=1
   make -s xpic_amd/libxpic_hip.so EXTRA="$F" > gpurun_out/fill_exp_build_$e.log 2>&1 || { tail gpurun_out/fill_exp_build_$e.log; exit 1; }
   echo -n "FILL_EXP=$e: "
-  timeout -k 10 300 python tools/fill_bench.py ${2:-256} ${3:-64} 3 2> gpurun_out/fill_exp_$e.err | tail -12 || { tail -3 gpurun_out/fill_exp_$e.err; }
+  timeout -k 10 300 python tools/fill_bench.py ${2:-256} ${3:-64} 3 2> gpurun_out/fill_exp_$e.err | tail -40 || { tail -3 gpurun_out/fill_exp_$e.err; }
 done
 rm -f xpic_amd/csrc/ecsim.o

@@ -367,6 +367,8 @@ int xpic_create(const xpic_geometry* geom, int scheme, xpic_ctx** out)
       c->cheb_degree_M = c->cheb_degree_M_auto = kM < 2 ? 2 : (kM > 48 ? 48 : kM);
     }
     XPIC_CALL(build_ltab(c));
+    XPIC_HIP(hipMalloc(&c->fill_err, sizeof(int)));
+    XPIC_HIP(hipMemsetAsync(c->fill_err, 0, sizeof(int), c->stream));
     XPIC_CALL(ensure_flexible_workspace(c));
   }
   XPIC_HIP(hipStreamSynchronize(c->stream));
@@ -380,7 +382,7 @@ int xpic_destroy(xpic_ctx* ctx)
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& s : ctx->sorts) sort_free(s);
   for (int f = 0; f < XPIC_NFIELDS; ++f) (void)hipFree(ctx->field[f]);
-  (void)hipFree(ctx->matL); (void)hipFree(ctx->ltab); (void)hipFree(ctx->kry_V); (void)hipFree(ctx->kry_w);
+  (void)hipFree(ctx->matL); (void)hipFree(ctx->ltab); (void)hipFree(ctx->fill_err); (void)hipFree(ctx->kry_V); (void)hipFree(ctx->kry_w);
   (void)hipFree(ctx->kry_t); (void)hipFree(ctx->kry_Z); (void)hipFree(ctx->kry_p[0]); (void)hipFree(ctx->kry_p[1]); (void)hipFree(ctx->kry_p[2]);
   (void)hipFree(ctx->red_partial); (void)hipFree(ctx->red_out); (void)hipHostFree(ctx->red_host);
   (void)hipFree(ctx->scan_tmp);
@@ -683,6 +685,22 @@ int xpic_set_preconditioner(xpic_ctx* ctx, int kind, int degree)
   if (degree > 0) ctx->cheb_degree = ctx->cheb_degree_M = ctx->cheb_degree_user;
   else { ctx->cheb_degree = ctx->cheb_degree_auto; ctx->cheb_degree_M = ctx->cheb_degree_M_auto; } // back to the automatic choice
   return ensure_flexible_workspace(ctx);
+}
+
+int xpic_set_fill_kernel(xpic_ctx* ctx, int kind)
+{
+  CTX_CHECK(ctx);
+  XPIC_CHECK(kind == 0 || kind == 1, "unknown assembly kernel (0 classic, 1 warp-specialised)");
+  ctx->fill_kernel = kind;
+  return 0;
+}
+
+int xpic_get_fill_variant(xpic_ctx* ctx, int* out3)
+{
+  CTX_CHECK(ctx);
+  XPIC_CHECK(out3, "null argument");
+  ecsim_fill_variant(ctx, &out3[0], &out3[1], &out3[2]);
+  return 0;
 }
 
 int xpic_set_overlap(xpic_ctx* ctx, int on)

@@ -22,6 +22,9 @@
 #else
 #define XPIC_TU_EXPERIMENT 0
 #endif
+#ifndef XPIC_DEFAULT_FILL_KERNEL
+#define XPIC_DEFAULT_FILL_KERNEL 0 // the assembly body a new context runs (xpic_set_fill_kernel): whichever measures faster at 256^3 x 64
+#endif
 
 namespace xpic {
 
@@ -164,6 +167,8 @@ struct xpic_ctx {
   double* field[XPIC_NFIELDS] = {};
   double* matL = nullptr; // [c1][nzl][ny][123][nx]
   int* ltab = nullptr;    // [1296] block entry -> packed (k, c1, o1) descriptor
+  int* fill_err = nullptr; // set by k_ecsim_fill_ws when one of its bounded waits gave up
+  int fill_kernel = XPIC_DEFAULT_FILL_KERNEL; // 1: warp-specialised assembly (8-wave workgroups, producer / consumer waves) where the grid allows; 0: classic
   std::vector<xpic::Sort> sorts;
   // Krylov workspace
   double* kry_V = nullptr; // (m+1) vectors
@@ -275,6 +280,7 @@ int momentum_sums_global(xpic_ctx* c, Sort& s, const double* E, double* out6);
 // ecsim.hip
 int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, double* matL, bool first_sort);
 int build_ltab(xpic_ctx* c);
+void ecsim_fill_variant(const xpic_ctx* c, int* p2, int* fx, int* ws);
 
 // esirkepov.hip: mode 0 basic::push, 1 ecsimcorr first_push, 2 ecsimcorr second_push
 int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double* B, double* J, double* pred_w_host);

@@ -735,6 +735,507 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
   }
 }
 
+
+// =====================================================================================================================
+// k_ecsim_fill_ws -- the same assembly with its two halves on different waves (round 4).
+//
+// The kernel above runs every wave through phase 1 (VALU, lane = particle), phase 2 (matrix cores), merge and flush in
+// turn, two waves per SIMD: whether a SIMD's two waves complement each other (one feeding the matrix pipe while the other
+// issues vector / memory instructions) is left to chance, each wave issues a third of the time, and the merge window
+// aliases the stage, so a chunk's merge + flush cannot overlap the next chunk's phase 1.  Here ONE workgroup of 8 waves
+// owns the CU (all 160 KB of LDS) and the roles are fixed:
+//   * waves 4..7 are PRODUCERS (one per SIMD): cell by cell, pass by pass they load the particles, run phase 1 and leave
+//     the octant-compacted operands in one of the TWO stage buffers of their pair; between passes they flush the finished
+//     columns of the merge window (the read-modify-write of matL / currI) and re-seed it;
+//   * waves 0..3 are CONSUMERS (wave w shares its SIMD with producer w + 4): they run phase 2 out of the stage buffers,
+//     keep the cell block in registers and merge it into the window when the cell is complete.
+// The window (46.6 KB) has LDS of its own: a chunk's flush runs beside the next chunk's phases 1 and 2.  Nothing in the
+// main loop is a workgroup barrier: a pair hands stage buffers over through two sequence numbers in LDS (FULL / FREE),
+// the window changes hands through two counters (MERGED: consumers that merged a chunk, SEEDED: producers that flushed
+// and re-seeded it).  A consumer never waits for another consumer's cell, only -- a chunk later -- for the flush.
+// Every wait is a bounded spin: a wave that waited longer than any schedule can need raises the ABORT word and leaves,
+// the others follow, and the host reports the assembly as failed instead of hanging the GPU.
+// Work per cell, colours, first touch, the window's line table and the octant accumulators are those of k_ecsim_fill:
+// the matrix it assembles is the same up to the summation order of the window's atomics.
+// =====================================================================================================================
+#ifndef FILL_WS_KCP
+#define FILL_WS_KCP 44
+#endif
+constexpr int kWsCP = FILL_WS_KCP;            // slots of one stage buffer (two per pair: 4 x 2 x 44 x 304 B = 107 KB)
+constexpr int kWsStage = kWsCP * kPitch;      // doubles of one stage buffer
+constexpr int kWsThreads = 512;
+constexpr int kWsProd = 256;                  // producer threads (own the window's lines in the flush)
+constexpr int kWsOwn = (kLines + kWsProd - 1) / kWsProd;
+constexpr unsigned kWsSpinLimit = 1u << 22;   // polls of ~100 cycles: three orders of magnitude beyond any legitimate wait
+enum { kFlFull = 0, kFlFree = 8, kFlMerged = 16, kFlSeeded = 17, kFlAbort = 18, kFlCount = 20 };
+static_assert(kWsCP % 4 == 0 && kWsCP <= 64, "a stage buffer holds whole K = 4 steps of at most one wave of particles");
+static_assert(FILL_LEAN_LDS == 1, "k_ecsim_fill_ws reads the transposed per-lane offset table");
+static_assert((kLines * kWP + 64 + kW) * 8 + 8 * kWsStage * 8 + kPitch * 8 + kW * 54 * 8 + kW * 2 * 12 * 4 + kFlCount * 4 <= 160 * 1024,
+  "window + stage buffers exceed the LDS of a CU");
+
+typedef __attribute__((address_space(3))) unsigned LdsWord;
+
+#ifdef FILL_STAMPS
+// section timers of the warp-specialised kernel (experiment build): [0, 8) consumer wave 0, [8, 16) producer wave 4 of every workgroup
+__device__ unsigned long long g_fill_ws_stamps[16];
+#define WSTAMP(k)                                                 \
+  do {                                                            \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    ws_acc_[k] += now_ - ws_t_;                                   \
+    ws_t_ = now_;                                                 \
+  } while (0)
+#define WSTAMP_INIT unsigned long long ws_t_ = __builtin_readcyclecounter(); unsigned long long ws_acc_[8] = {}
+#define WSTAMP_DUMP(base, cond)                                                                     \
+  do {                                                                                              \
+    if ((cond) && lane == 0)                                                                        \
+      for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_fill_ws_stamps[(base) + k_], ws_acc_[k_]);        \
+  } while (0)
+}  // namespace
+}  // namespace xpic
+extern "C" int xpic_debug_fill_ws_stamps(double* out, int reset)
+{
+  unsigned long long h[16];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(xpic::g_fill_ws_stamps), sizeof(h)) != hipSuccess) return 1;
+  for (int i = 0; i < 16; ++i) out[i] = (double)h[i];
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(xpic::g_fill_ws_stamps), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+namespace xpic {
+namespace {
+#else
+#define WSTAMP(k)
+#define WSTAMP_INIT
+#define WSTAMP_DUMP(base, cond)
+#endif
+
+// LDS words that other waves of the workgroup write: always read / written by explicit DS instructions
+__device__ inline unsigned lds_peek(const unsigned* p)
+{
+  unsigned v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((const LdsWord*)p) : "memory");
+  return __builtin_amdgcn_readfirstlane(v);
+}
+// publish: everything this wave sent to the LDS before is complete (a wave's DS operations finish in order), then lane 0 writes
+__device__ inline void lds_post(unsigned* p, unsigned v, int lane)
+{
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"((LdsWord*)p), "v"(v) : "memory");
+}
+__device__ inline void lds_bump(unsigned* p, int lane)
+{
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"((LdsWord*)p), "v"(1u) : "memory");
+}
+// wait until *p has reached `target` (sequence numbers only grow); false: aborted (this wave or another one gave up)
+__device__ inline bool lds_wait(const unsigned* p, unsigned target, unsigned* flags)
+{
+  for (unsigned it = 0;; ++it) {
+    if ((int)(lds_peek(p) - target) >= 0) return true;
+    if ((it & 63u) == 63u) {
+      if (lds_peek(flags + kFlAbort)) return false;
+      if (it > kWsSpinLimit) {
+        asm volatile("ds_write_b32 %0, %1" ::"v"((LdsWord*)(flags + kFlAbort)), "v"(1u) : "memory");
+        return false;
+      }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+template <bool P2>
+__global__ void __launch_bounds__(kWsThreads, 1) k_ecsim_fill_ws(GridDev g, SortDev s, const double* __restrict__ B,
+  double* currI, double* matL, const unsigned short* __restrict__ dtab, const int* __restrict__ linetab, const int* __restrict__ cowr, double q, double m,
+  double mpw, int cy0, int cystep, int ncy, int cz0, int czstep, int my_order, int ncol_y, int per_y, int per_z, int first_sort,
+  int* __restrict__ err)
+{
+  const int cy = cy0 + (int)(blockIdx.x % ncy) * cystep;
+  const int cz = cz0 + (int)(blockIdx.x / ncy) * czstep;
+
+  __shared__ __attribute__((aligned(16))) double win[kLines * kWP + 64 + kW]; // + the per-lane dummy targets of the merge
+  __shared__ __attribute__((aligned(16))) double stage[kW * 2 * kWsStage];
+  __shared__ __attribute__((aligned(16))) double zslot[kPitch];
+  __shared__ double bnb[kW][54];
+  __shared__ __attribute__((aligned(16))) int hdr[kW][2][12]; // per stage buffer: the 8 octant counts, last-pass flag
+  __shared__ unsigned flags[kFlCount];
+
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const double dt = g.dt;
+  for (int i = threadIdx.x; i < kLines * kWP + 64 + kW; i += kWsThreads) win[i] = 0.0;
+  if (threadIdx.x < kPitch) zslot[threadIdx.x] = 0.0;
+  if (threadIdx.x < kFlCount) flags[threadIdx.x] = 0u;
+  __syncthreads(); // the only workgroup barrier of the kernel
+  const int nch = g.nx / kW;
+  const long pencil0 = ((long)cz * g.ny + cy) * g.nx;
+
+  if (wave < kW) {
+    // =============================================== consumer =====================================================
+    const int w = wave;
+    const int kk = lane >> 4, qb = (lane >> 2) & 3, qj = lane & 3;
+    const int offA8 = 8 * (qj * 2 + (qb >> 1)), offB8 = 8 * (qj * 2 + (qb & 1));
+    const int offI18 = 8 * (kOffAB + 9 + (qb >> 1));
+    double acc[kAcc];
+#pragma unroll
+    for (int e = 0; e < kAcc; ++e) acc[e] = 0.0;
+    __builtin_amdgcn_s_setprio(2); // the wave with matrix instructions to issue goes first on its SIMD
+    unsigned pass = 0;
+    WSTAMP_INIT;
+    for (int j = 0; j < nch; ++j) {
+      for (;;) {
+        const int b = pass & 1;
+        if (!lds_wait(flags + kFlFull + w * 2 + b, pass + 1, flags)) { if (lane == 0) atomicOr(err, 1); return; }
+        WSTAMP(0);
+        const int4 h0 = *(const int4*)&hdr[w][b][0], h1 = *(const int4*)&hdr[w][b][4];
+        const int ocnt[8] = {__builtin_amdgcn_readfirstlane(h0.x), __builtin_amdgcn_readfirstlane(h0.y),
+          __builtin_amdgcn_readfirstlane(h0.z), __builtin_amdgcn_readfirstlane(h0.w), __builtin_amdgcn_readfirstlane(h1.x),
+          __builtin_amdgcn_readfirstlane(h1.y), __builtin_amdgcn_readfirstlane(h1.z), __builtin_amdgcn_readfirstlane(h1.w)};
+        const bool lastpass = __builtin_amdgcn_readfirstlane(hdr[w][b][8]) != 0;
+        const double* st = stage + (w * 2 + b) * kWsStage;
+        int run = 0;
+        WSTAMP(1);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+          const int no = ocnt[o];
+          const double* seg = st + run * kPitch;
+          run += no;
+          const int nst = lastpass ? (no + 3) >> 2 : no >> 2;
+          LdsBytes spr = (LdsBytes)(const char*)(seg + kk * kPitch);
+          const LdsBytes seg_end = (LdsBytes)(const char*)(seg + no * kPitch);
+          for (int t = 0; t < nst; ++t, spr += 4 * kPitch * 8) {
+            const LdsBytes sb = spr < seg_end ? spr : (LdsBytes)(const char*)zslot;
+            const LdsDouble* sp = (const LdsDouble*)sb;
+            const LdsDouble* spA = (const LdsDouble*)(sb + offA8);
+            const LdsDouble* spB = (const LdsDouble*)(sb + offB8);
+            double a[3], bb[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { a[c] = spA[c * 8]; bb[c] = spB[c * 8]; }
+            const LdsDouble2* u = (const LdsDouble2*)(sp + kOffAB);
+            const dpair u0 = u[0], u1 = u[1], u2 = u[2], u3 = u[3];
+            const double ab[9] = {u0.x, u0.y, u1.x, u1.y, u2.x, u2.y, u3.x, u3.y, sp[kOffAB + 8]};
+            double bm[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) bm[e] = bb[e % 3] * ab[e];
+            const double ai1 = qb < 2 ? bb[0] : bb[1], ai2 = bb[2];
+            const double bi1 = *(const LdsDouble*)(sb + offI18), bi2 = sp[kOffAB + 11];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c1 = 0; c1 < 3; ++c1)
+#pragma unroll
+              for (int c2 = 0; c2 < 3; ++c2)
+                acc[acc_main(c1, c2, o)] =
+                  __builtin_amdgcn_mfma_f64_4x4x4f64(a[c1], bm[c1 * 3 + c2], acc[acc_main(c1, c2, o)], 0, 0, 0);
+            acc[acc_cur1(o)] = __builtin_amdgcn_mfma_f64_4x4x4f64(ai1, bi1, acc[acc_cur1(o)], 0, 0, 0);
+            acc[acc_cur2(o)] = __builtin_amdgcn_mfma_f64_4x4x4f64(ai2, bi2, acc[acc_cur2(o)], 0, 0, 0);
+          }
+        }
+        WSTAMP(2);
+        lds_post(flags + kFlFree + w * 2 + b, pass + 1, lane); // every operand read of this buffer has returned
+        WSTAMP(3);
+        ++pass;
+        if (lastpass) break;
+      }
+      // ---- merge the cell block into the window: lane's element of accumulator e goes to byte wdst[e] (+ 8 * wave)
+      unsigned wdst[kAcc];
+      {
+        const uint4* dq = reinterpret_cast<const uint4*>(dtab + lane * kDtabPitch);
+#pragma unroll
+        for (int k = 0; k < kDtabPitch / 8; ++k) {
+          const uint4 w4 = dq[k];
+          const unsigned ww[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+          for (int h = 0; h < 8; ++h)
+            if (k * 8 + h < kAcc) wdst[k * 8 + h] = (ww[h >> 1] >> (16 * (h & 1))) & 0xffffu;
+        }
+      }
+      WSTAMP(4);
+      if (!lds_wait(flags + kFlSeeded, (unsigned)(kW * j), flags)) { if (lane == 0) atomicOr(err, 1); return; } // the window holds chunk j - 1's carry, re-seeded
+      WSTAMP(5);
+      char* wv = (char*)(win + w);
+#pragma unroll
+      for (int e = 0; e < kAcc; ++e) {
+        unsafeAtomicAdd((double*)(wv + wdst[e]), acc[e]);
+        acc[e] = 0.0;
+      }
+      lds_bump(flags + kFlMerged, lane);
+      WSTAMP(6);
+    }
+    WSTAMP_DUMP(0, w == 0);
+    return;
+  }
+
+  // ================================================= producer =======================================================
+  const int w = wave - kW;
+  const int t = threadIdx.x - kWsProd;
+  // window lines this thread owns in the flush (line = t + mm * kWsProd): address of their column 0, first-touch flag in bit 0
+  uintptr_t lbase[kWsOwn];
+#pragma unroll
+  for (int mm = 0; mm < kWsOwn; ++mm) {
+    const int line = t + mm * kWsProd;
+    lbase[mm] = 0;
+    if (line >= kLines) continue;
+    const int ld = linetab[line];
+    const int ry = g.wy(cy + ((ld >> 2) & 3) - 1);
+    const int rz = cz + ((ld >> 4) & 3) - 1;
+    const int rzw = g.G == 0 ? (rz < 0 ? rz + g.nzl : (rz >= g.nzl ? rz - g.nzl : rz)) : rz + 1;
+    double* base = line < kMatLines
+      ? matL + g.lindex(ld & 3, rzw, ry, 0, ld >> 6)
+      : currI + (ld & 3) * g.cstride + g.node(0, ry, g.wz(rz));
+    bool first = first_sort && line < kMatLines; // no co-writer of this line runs in an earlier launch: store, do not add
+    if (first) {
+      const int bodyy = g.ny - g.ny % per_y, bodyz = g.nzl - g.nzl % per_z;
+      for (int e = 0; e < 8 && first; ++e) {
+        const int cw = cowr[line * 8 + e];
+        if (cw == 0x7fffffff) break;
+        const int oy = (cw & 0xff) - 8, oz = ((cw >> 8) & 0xff) - 8;
+        int py = cy + oy, pz = cz + oz;
+        py = py < 0 ? py + g.ny : (py >= g.ny ? py - g.ny : py);
+        if (g.G == 0) pz = pz < 0 ? pz + g.nzl : (pz >= g.nzl ? pz - g.nzl : pz);
+        else if (pz < 0 || pz >= g.nzl) continue;
+        const int ca = py < bodyy ? py % per_y : per_y + (py - bodyy);
+        const int cb = g.G == 0 ? (pz < bodyz ? pz % per_z : per_z + (pz - bodyz)) : pz % per_z;
+        if (cb * ncol_y + ca < my_order) first = false;
+      }
+    }
+    lbase[mm] = (uintptr_t)base | (first ? 1u : 0u);
+  }
+
+  // ---- the window's read-modify-write.  old[] = the current values of the next chunk's finished columns, requested a
+  // chunk ahead (the addresses depend on the chunk alone); flush_chunk adds the window's four finished columns, stores,
+  // moves the two unfinished columns to the front and clears the rest (the seed of the next chunk's merge).
+  double old[kWsOwn][kW];
+  auto request_old = [&](int jc) {
+#pragma unroll
+    for (int mm = 0; mm < kWsOwn; ++mm) {
+      const int line = t + mm * kWsProd;
+#pragma unroll
+      for (int c = 0; c < kW; ++c) old[mm][c] = 0.0;
+      const uintptr_t lb = lbase[mm];
+      if (!lb || (lb & 1) || jc >= nch) continue;
+      const GlobalDouble* ptr = (const GlobalDouble*)(lb & ~(uintptr_t)1) + (long)jc * (line < kMatLines ? kLBlock : kW);
+#pragma unroll
+      for (int c = 0; c < kW; c += 2) {
+        const dpair v = *(const GlobalPair*)(ptr + c);
+        old[mm][c] = v.x; old[mm][c + 1] = v.y;
+      }
+    }
+  };
+  auto flush_chunk = [&](int jc) {
+#pragma unroll
+    for (int mm = 0; mm < kWsOwn; ++mm) {
+      const int line = t + mm * kWsProd;
+      const uintptr_t lb = lbase[mm];
+      if (!lb) continue;
+      double* wl = win + line * kWP;
+      double wv[kSlots];
+#pragma unroll
+      for (int c = 0; c < kSlots; ++c) wv[c] = wl[c];
+      GlobalDouble* ptr = (GlobalDouble*)(lb & ~(uintptr_t)1) + (long)jc * (line < kMatLines ? kLBlock : kW);
+#pragma unroll
+      for (int c = 0; c < kW; c += 2)
+        *(GlobalPair*)(ptr + c) = dpair{old[mm][c] + wv[c], old[mm][c + 1] + wv[c + 1]};
+      wl[0] = wv[kW]; wl[1] = wv[kW + 1];
+#pragma unroll
+      for (int c = 2; c < kSlots; ++c) wl[c] = 0.0;
+    }
+    request_old(jc + 1);
+    lds_bump(flags + kFlSeeded, lane);
+  };
+  int jf = 0; // next chunk to flush
+  WSTAMP_INIT;
+  auto try_flush = [&]() {
+    if (jf < nch && (int)(lds_peek(flags + kFlMerged) - (unsigned)(kW * (jf + 1))) >= 0) { WSTAMP(0); flush_chunk(jf); ++jf; WSTAMP(1); }
+  };
+
+  auto cell_x = [&](int i) { return (i + 1 == g.nx) ? 0 : i + 1; };
+  int box;
+  const double* const brow = bnb_row(g, B, lane, cy, cz, &box);
+  Prefetch pf;
+  auto prefetch_cell = [&](int i) {
+    pf.start = 0; pf.cnt = 0; pf.b = 0.0;
+    if (i >= g.nx) return;
+    const int cx = cell_x(i);
+    using UniformInts = const __attribute__((address_space(4))) int*;
+    UniformInts cs = (UniformInts)(s.cell_start + pencil0);
+    const int cxu = __builtin_amdgcn_readfirstlane(cx);
+    pf.start = cs[cxu];
+    pf.cnt = cs[cxu + 1] - pf.start;
+    pf.b = brow ? brow[g.wx(cx + box)] : 0.0;
+    if (lane < min(kWsCP, pf.cnt)) {
+      const long p = (long)pf.start + lane;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { pf.p[a] = s.r[a][p]; pf.p[3 + a] = s.v[a][p]; }
+    }
+  };
+  prefetch_cell(w);
+  request_old(0);
+
+  const double fb = (0.5 * dt) * q / m;
+  const double qw = q * mpw;
+  const double Aq = 0.5 * dt * dt * mpw * q * q / m;
+  unsigned pass = 0;
+  for (int j = 0; j < nch; ++j) {
+    const int i = j * kW + w;
+    const int start = pf.start, cnt = pf.cnt;
+    if (lane < 54) bnb[w][lane] = pf.b;
+    double cur[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) cur[a] = pf.p[a];
+    prefetch_cell(i + kW); // the next cell's first particles travel during this cell's passes
+    int handed = min(kWsCP, cnt);
+    bool real = lane < handed;
+    WSTAMP(2);
+    for (;;) {
+      const bool lastpass = handed >= cnt;
+      const int b = pass & 1;
+      // the buffer's previous content (pass - 2) has been consumed; while waiting, flush what is ready
+      if (pass >= 2) {
+        unsigned it = 0;
+        while ((int)(lds_peek(flags + kFlFree + w * 2 + b) - (pass - 1)) < 0) {
+          const int was = jf;
+          try_flush();
+          if (jf != was) continue;
+          if ((++it & 63u) == 0u) {
+            if (lds_peek(flags + kFlAbort)) { if (lane == 0) atomicOr(err, 1); return; }
+            if (it > kWsSpinLimit) {
+              asm volatile("ds_write_b32 %0, %1" ::"v"((LdsWord*)(flags + kFlAbort)), "v"(1u) : "memory");
+              if (lane == 0) atomicOr(err, 1);
+              return;
+            }
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      try_flush();
+      WSTAMP(0);
+      double* st = stage + (w * 2 + b) * kWsStage;
+      wave_sync();
+      const W1T<P2> wt(g, cur[0], cur[1], cur[2]);
+      const int ox = wt.is[0] - wt.in[0] + 1, oy = wt.is[1] - wt.in[1] + 1, oz = wt.is[2] - wt.in[2] + 1;
+      const int oct = real ? (ox | (oy << 1) | (oz << 2)) : 8;
+      int ocnt[8], slot = 0;
+      bool keep = false;
+      {
+        int run = 0;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+          const unsigned long long mk = __ballot(oct == o);
+          ocnt[o] = __popcll(mk);
+          if (oct == o) {
+            const int rk = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+            slot = run + rk;
+            keep = !lastpass && rk >= (ocnt[o] & ~3);
+          }
+          run += ocnt[o];
+        }
+      }
+      if (real) {
+        double2* dst = (double2*)(st + slot * kPitch);
+        const double* nb = bnb[w];
+        double nbv[3][8];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+              nbv[0][(k * 2 + jj) * 2 + ii] = nb[((oz + k) * 3 + (oy + jj)) * 2 + ii];
+              nbv[1][(k * 2 + jj) * 2 + ii] = nb[18 + ((oz + k) * 2 + jj) * 3 + (ox + ii)];
+              nbv[2][(k * 2 + jj) * 2 + ii] = nb[36 + (k * 3 + (oy + jj)) * 3 + (ox + ii)];
+            }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb) {
+            const double tx = wt.wn[2][a] * wt.wn[1][bb];
+            dst[0 + a * 2 + bb] = double2{tx * wt.ws[0][0], tx * wt.ws[0][1]};
+            dst[4 + a * 2 + bb] = double2{wt.wn[2][a] * wt.ws[1][0] * wt.wn[0][bb], wt.wn[2][a] * wt.ws[1][1] * wt.wn[0][bb]};
+            dst[8 + a * 2 + bb] = double2{wt.ws[2][0] * wt.wn[1][a] * wt.wn[0][bb], wt.ws[2][1] * wt.wn[1][a] * wt.wn[0][bb]};
+          }
+        const double v[3] = {cur[3], cur[4], cur[5]};
+        double Bp[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+              Bp[0] += nbv[0][(k * 2 + jj) * 2 + ii] * (wt.ws[2][k] * wt.ws[1][jj] * wt.wn[0][ii]);
+              Bp[1] += nbv[1][(k * 2 + jj) * 2 + ii] * (wt.ws[2][k] * wt.wn[1][jj] * wt.ws[0][ii]);
+              Bp[2] += nbv[2][(k * 2 + jj) * 2 + ii] * (wt.wn[2][k] * wt.ws[1][jj] * wt.ws[0][ii]);
+            }
+        const double bx = Bp[0] * fb, by = Bp[1] * fb, bz = Bp[2] * fb;
+        const double b2 = bx * bx + by * by + bz * bz;
+        const double vb = v[0] * bx + v[1] * by + v[2] * bz;
+        const double cxv = +(v[1] * bz - v[2] * by), cyv = -(v[0] * bz - v[2] * bx), czv = +(v[0] * by - v[1] * bx);
+        const double rb = 1.0 / (1. + b2);
+        const double iq = qw * rb;
+        const double A_p = Aq * rb;
+        dst[12] = double2{A_p * (1.0 + bx * bx), A_p * (+bz + bx * by)};
+        dst[13] = double2{A_p * (-by + bx * bz), A_p * (-bz + by * bx)};
+        dst[14] = double2{A_p * (1.0 + by * by), A_p * (+bx + by * bz)};
+        dst[15] = double2{A_p * (+by + bz * bx), A_p * (-bx + bz * by)};
+        dst[16] = double2{A_p * (1.0 + bz * bz), iq * (v[0] + cxv + vb * bx)};
+        dst[17] = double2{iq * (v[1] + cyv + vb * by), iq * (v[2] + czv + vb * bz)};
+      }
+      WSTAMP(3);
+      if (lane == 0) {
+        *(int4*)&hdr[w][b][0] = int4{ocnt[0], ocnt[1], ocnt[2], ocnt[3]};
+        *(int4*)&hdr[w][b][4] = int4{ocnt[4], ocnt[5], ocnt[6], ocnt[7]};
+        hdr[w][b][8] = lastpass ? 1 : 0;
+      }
+      // next pass of this cell: the free lanes take the next particles
+      bool real_next = false;
+      if (!lastpass) {
+        const unsigned long long km = __ballot(keep);
+        const int take = min(cnt - handed, kWsCP - (int)__popcll(km));
+        const unsigned long long fm = ~km;
+        const int fr = __builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
+        const bool get = !keep && fr < take;
+        if (get) {
+          const long p = (long)start + handed + fr;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) { cur[a] = s.r[a][p]; cur[3 + a] = s.v[a][p]; }
+        }
+        real_next = keep || get;
+        handed += take;
+      }
+      lds_post(flags + kFlFull + w * 2 + b, pass + 1, lane); // operands and header are in place
+      WSTAMP(4);
+      ++pass;
+      if (lastpass) break;
+      real = real_next;
+    }
+  }
+  // ---- drain: the chunks still to be flushed, then the two columns left over (x = nx, nx + 1 = 0, 1 periodically),
+  // which this thread has already written: added with atomics
+  WSTAMP(2);
+  while (jf < nch) {
+    if (!lds_wait(flags + kFlMerged, (unsigned)(kW * (jf + 1)), flags)) { if (lane == 0) atomicOr(err, 1); return; }
+    WSTAMP(5);
+    flush_chunk(jf);
+    ++jf;
+    WSTAMP(1);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int mm = 0; mm < kWsOwn; ++mm) {
+    const int line = t + mm * kWsProd;
+    if (line < kLines && lbase[mm]) {
+      double* base = (double*)(lbase[mm] & ~(uintptr_t)1);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const double v = win[line * kWP + c];
+        if (v != 0.0) unsafeAtomicAdd(base + g.wx(c), v);
+      }
+    }
+  }
+  WSTAMP(6);
+  WSTAMP_DUMP(8, w == 0);
+}
+
 }  // namespace
 
 // Tables.  The (row, col) node pairs of the cell block are those of
@@ -904,15 +1405,29 @@ static void colour_class(int n, int period, int colour, int* first, int* step, i
   else { *first = body + (colour - period); *step = 1; *count = 1; }
 }
 
+// which body ecsim_fill_sort runs on this context's grid: {power-of-two spacings, full chunks, warp-specialised}
+void ecsim_fill_variant(const xpic_ctx* c, int* p2, int* fx, int* ws)
+{
+  const GridDev& g = c->g;
+  const bool alias = g.ny < 3 || (g.G == 0 && g.nzl < 3);
+  *p2 = g.pow2 ? 1 : 0;
+  *fx = (g.nx % kW == 0 && !alias) ? 1 : 0;
+  *ws = (*fx && c->fill_kernel == 1) ? 1 : 0;
+}
+
 int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, double* matL, bool first_sort)
 {
   if (s.n == 0) return 0;
   const GridDev& g = c->g;
+  int p2, fxi, wsi;
+  ecsim_fill_variant(c, &p2, &fxi, &wsi);
+  const bool ws = wsi != 0;
   // y is periodic inside the slab; z is periodic only when the slab is the whole box: with z-neighbours the rows
   // below plane 0 / above plane nzl-1 are ghost rows of this rank alone, so plain residues mod per_z suffice
   int per_y, per_z;
-  colour_periods(g, 2 * c->num_cus, &per_y, &per_z);
+  colour_periods(g, (ws ? 1 : 2) * c->num_cus, &per_y, &per_z); // workgroup slots of the chip: the 8-wave kernel owns a CU
   const int ncol_y = per_y + g.ny % per_y, ncol_z = g.G == 0 ? per_z + g.nzl % per_z : per_z;
+  if (ws) XPIC_HIP(hipMemsetAsync(c->fill_err, 0, sizeof(int), c->stream));
   for (int b = 0; b < ncol_z; ++b)
     for (int a = 0; a < ncol_y; ++a) {
       int cy0, cys, ncy, cz0, czs, ncz;
@@ -923,14 +1438,29 @@ int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, d
       Timed t(c, "fill_current"); // one entry per colour launch: the average is the kernel's own launch duration
       const bool alias = g.ny < 3 || (g.G == 0 && g.nzl < 3);
       const bool fx = g.nx % kW == 0 && !alias;
+      const unsigned short* dtab = (const unsigned short*)(c->ltab + kLines + kLines * 8);
+      if (ws) {
+        auto kern = g.pow2 ? k_ecsim_fill_ws<true> : k_ecsim_fill_ws<false>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(ncy * ncz)), dim3(kWsThreads), 0, c->stream, g, s.d, B, currI_sort, matL, dtab,
+          c->ltab, c->ltab + kLines, s.par.q, s.par.m, s.par.n / (double)s.par.Np, cy0, cys, ncy, cz0, czs, b * ncol_y + a, ncol_y,
+          per_y, per_z, first_sort ? 1 : 0, c->fill_err);
+        continue;
+      }
       auto kern = g.pow2 ? (fx ? k_ecsim_fill<true, true> : k_ecsim_fill<true, false>)
                          : (fx ? k_ecsim_fill<false, true> : k_ecsim_fill<false, false>);
       hipLaunchKernelGGL(kern, dim3((unsigned)(ncy * ncz)), dim3(kThreads), 0, c->stream, g, s.d, B,
-        currI_sort, matL, (const unsigned short*)(c->ltab + kLines + kLines * 8), c->ltab, c->ltab + kLines, s.par.q, s.par.m,
+        currI_sort, matL, dtab, c->ltab, c->ltab + kLines, s.par.q, s.par.m,
         s.par.n / (double)s.par.Np, cy0, cys, ncy, cz0, czs, b * ncol_y + a, ncol_y, per_y, per_z, first_sort && !alias ? 1 : 0,
         alias ? 1 : 0);
     }
   XPIC_HIP(hipGetLastError());
+  if (ws) {
+    // the pipeline's bounded waits: a wave that gave up has left the matrix incomplete -- fail the assembly loudly
+    int* herr = (int*)(c->red_host + 60);
+    XPIC_HIP(hipMemcpyAsync(herr, c->fill_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    XPIC_HIP(hipStreamSynchronize(c->stream));
+    XPIC_CHECK(*herr == 0, "k_ecsim_fill_ws: a producer / consumer wait timed out (assembly incomplete)");
+  }
   return 0;
 }
 
