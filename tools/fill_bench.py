@@ -48,13 +48,15 @@ if hasattr(ctx.L, "xpic_debug_fill_stamps"):
             print("  %-22s %6.2f %%" % (nm, 100 * st[k] / tot))
 if hasattr(ctx.L, "xpic_debug_fill_ws_stamps") and kinds[-1] == 1:
     import ctypes as C
-    st = np.zeros(16)
+    st = np.zeros(32)
     ctx.synchronize()
     ctx.L.xpic_debug_fill_ws_stamps(st.ctypes.data_as(C.POINTER(C.c_double)), 0)
-    for base, role, names in ((0, "consumer wave 0", ["wait FULL", "header", "phase 2", "post FREE", "offsets + chunk tail", "wait SEEDED", "merge + bump", "-"]),
-                              (8, "producer wave 4", ["wait FREE / poll", "flush + seed", "cell prologue / prefetch", "phase 1", "header + next loads + post FULL", "drain wait", "tail", "-"])):
+    cons = ["wait FULL", "header", "phase 2", "post FREE", "-", "wait SEEDED", "merge + bump", "-"]
+    for base, role, names in ((0, "consumer oz = 0 (wave 0)", cons), (8, "consumer oz = 1 (wave 4)", cons),
+                              (16, "producer (wave 8)", ["wait FREE", "-", "cell prologue / prefetch", "phase 1", "header + next loads + post FULL", "-", "-", "-"]),
+                              (24, "flusher (wave 12)", ["wait MERGED", "flush + seed", "request old", "tail", "-", "-", "-", "-"])):
         tot = st[base:base + 8].sum()
-        print("section shares of %s (s_memtime ticks, all workgroups, warm-up included):" % role)
+        print("section shares of the %s, %.3g ticks (all workgroups, warm-up included):" % (role, tot))
         for k, nm in enumerate(names):
             if st[base + k]:
                 print("  %-34s %6.2f %%" % (nm, 100 * st[base + k] / tot))

@@ -29,6 +29,8 @@
 #include <array>
 #include <cstdint>
 #include <map>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -75,6 +77,9 @@ extern "C" int xpic_debug_fill_stamps(double* out, int reset)
 #endif
 #ifndef FILL_PRIOT
 #define FILL_PRIOT 0
+#endif
+#ifndef FILL_NO_READ2
+#define FILL_NO_READ2 0
 #endif
 #ifndef FILL_DRAIN
 #define FILL_DRAIN 3 // explicit waits for global reads where they cost nothing (see the comment in front of the flush)
@@ -492,8 +497,20 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
             const LdsDouble* spA = (const LdsDouble*)(sb + offA8);
             const LdsDouble* spB = (const LdsDouble*)(sb + offB8);
             double a[3], b[3];
+#if FILL_NO_READ2
+            // (ds_read2_b64 moves 128 B per LDS cycle, ds_read_b64 256: keep the compiler from pairing the reads of one
+            // base by hiding the second address behind an opaque copy)
+            {
+              LdsBytes sA1 = sb + offA8 + 64, sB1 = sb + offB8 + 64, sA2 = sb + offA8 + 128, sB2 = sb + offB8 + 128;
+              asm volatile("" : "+v"(sA1), "+v"(sB1), "+v"(sA2), "+v"(sB2));
+              a[0] = spA[0]; b[0] = spB[0];
+              a[1] = *(const LdsDouble*)sA1; b[1] = *(const LdsDouble*)sB1;
+              a[2] = *(const LdsDouble*)sA2; b[2] = *(const LdsDouble*)sB2;
+            }
+#else
 #pragma unroll
             for (int c = 0; c < 3; ++c) { a[c] = spA[c * 8]; b[c] = spB[c * 8]; }
+#endif
             // the step's 9 A_p*matB per particle: the same 72 bytes for the 16 lanes of a particle (a DPP row
             // broadcast of one 8-byte read per lane was measured 6 % slower: the VALU is the scarcer resource here)
             const LdsDouble2* u = (const LdsDouble2*)(sp + kOffAB);
@@ -510,7 +527,13 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
             // (and the blocks 2, 3 of the second) have no target in the merge (they go to the lane's dummy double): every
             // lane passes I_p[c], read at a lane-dependent offset, and nothing has to be selected or zeroed
             const double ai1 = qb < 2 ? b[0] : b[1], ai2 = b[2];
+#if FILL_NO_READ2
+            LdsBytes sI2 = sb + 8 * (kOffAB + 11);
+            asm volatile("" : "+v"(sI2));
+            const double bi1 = *(const LdsDouble*)(sb + offI18), bi2 = *(const LdsDouble*)sI2;
+#else
             const double bi1 = *(const LdsDouble*)(sb + offI18), bi2 = sp[kOffAB + 11];
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c1 = 0; c1 < 3; ++c1)
@@ -737,47 +760,72 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
 
 
 // =====================================================================================================================
-// k_ecsim_fill_ws -- the same assembly with its two halves on different waves (round 4).
+// k_ecsim_fill_ws -- the same assembly with its parts on different waves (round 4).
 //
 // The kernel above runs every wave through phase 1 (VALU, lane = particle), phase 2 (matrix cores), merge and flush in
 // turn, two waves per SIMD: whether a SIMD's two waves complement each other (one feeding the matrix pipe while the other
 // issues vector / memory instructions) is left to chance, each wave issues a third of the time, and the merge window
-// aliases the stage, so a chunk's merge + flush cannot overlap the next chunk's phase 1.  Here ONE workgroup of 8 waves
-// owns the CU (all 160 KB of LDS) and the roles are fixed:
-//   * waves 4..7 are PRODUCERS (one per SIMD): cell by cell, pass by pass they load the particles, run phase 1 and leave
-//     the octant-compacted operands in one of the TWO stage buffers of their pair; between passes they flush the finished
-//     columns of the merge window (the read-modify-write of matL / currI) and re-seed it;
-//   * waves 0..3 are CONSUMERS (wave w shares its SIMD with producer w + 4): they run phase 2 out of the stage buffers,
-//     keep the cell block in registers and merge it into the window when the cell is complete.
+// aliases the stage, so a chunk's merge + flush cannot overlap the next chunk's phase 1.  Here ONE workgroup of 16 waves
+// owns the CU (all 160 KB of LDS, 128 registers per lane) and every SIMD holds one wave of each of four fixed roles, which
+// work on the same cell of a chunk of 4:
+//   * PRODUCER (waves 8..11): cell by cell, pass by pass it loads the particles, runs phase 1 and leaves the
+//     octant-compacted operands in one of the TWO stage buffers of its SIMD;
+//   * two CONSUMERS (waves 0..3: the octants with oz = 0, waves 4..7: oz = 1) run phase 2 out of the stage buffers -- two
+//     matrix-instruction streams per SIMD that cover each other's operand-read latency -- keep their part of the cell block
+//     in registers (26 of the 36 accumulators each) and merge it into the window when the cell is complete;
+//   * FLUSHER (waves 12..15): owns the window's lines; when all consumers have merged a chunk it adds the four finished
+//     columns to matL / currI (read-modify-write, the old values requested a chunk ahead: its memory counter holds nothing
+//     else), moves the two unfinished columns to the front and clears the rest.
 // The window (46.6 KB) has LDS of its own: a chunk's flush runs beside the next chunk's phases 1 and 2.  Nothing in the
-// main loop is a workgroup barrier: a pair hands stage buffers over through two sequence numbers in LDS (FULL / FREE),
-// the window changes hands through two counters (MERGED: consumers that merged a chunk, SEEDED: producers that flushed
-// and re-seeded it).  A consumer never waits for another consumer's cell, only -- a chunk later -- for the flush.
-// Every wait is a bounded spin: a wave that waited longer than any schedule can need raises the ABORT word and leaves,
-// the others follow, and the host reports the assembly as failed instead of hanging the GPU.
+// main loop is a workgroup barrier: stage buffers change hands through sequence numbers in LDS (FULL / FREE), the window
+// through two counters (MERGED: consumer waves that merged a chunk, SEEDED: flusher waves that flushed and re-seeded it).
+// A consumer never waits for another consumer's cell, only -- a chunk later -- for the flush.  Every wait is a bounded
+// spin: a wave that waited longer than any schedule can need raises the ABORT word and leaves, the others follow, and the
+// host reports the assembly as failed instead of hanging the GPU.
 // Work per cell, colours, first touch, the window's line table and the octant accumulators are those of k_ecsim_fill:
 // the matrix it assembles is the same up to the summation order of the window's atomics.
 // =====================================================================================================================
 #ifndef FILL_WS_KCP
 #define FILL_WS_KCP 44
 #endif
-constexpr int kWsCP = FILL_WS_KCP;            // slots of one stage buffer (two per pair: 4 x 2 x 44 x 304 B = 107 KB)
+#ifndef FILL_WS_PRIO_C
+#define FILL_WS_PRIO_C 2 // s_setprio of the consumers / the producer / the flusher
+#endif
+#ifndef FILL_WS_PRIO_P
+#define FILL_WS_PRIO_P 1
+#endif
+#ifndef FILL_WS_PRIO_F
+#define FILL_WS_PRIO_F 0
+#endif
+constexpr int kWsCP = FILL_WS_KCP;            // slots of one stage buffer (two per SIMD: 4 x 2 x 44 x 304 B = 107 KB)
 constexpr int kWsStage = kWsCP * kPitch;      // doubles of one stage buffer
-constexpr int kWsThreads = 512;
-constexpr int kWsProd = 256;                  // producer threads (own the window's lines in the flush)
-constexpr int kWsOwn = (kLines + kWsProd - 1) / kWsProd;
+constexpr int kWsThreads = 1024;
+constexpr int kWsFlush = 256;                 // flusher threads (own the window's lines)
+constexpr int kWsOwn = (kLines + kWsFlush - 1) / kWsFlush;
 constexpr unsigned kWsSpinLimit = 1u << 22;   // polls of ~100 cycles: three orders of magnitude beyond any legitimate wait
-enum { kFlFull = 0, kFlFree = 8, kFlMerged = 16, kFlSeeded = 17, kFlAbort = 18, kFlCount = 20 };
+enum { kFlFull = 0, kFlFree = 8 /* [half][w][b] */, kFlMerged = 24, kFlSeeded = 25, kFlAbort = 26, kFlCount = 28 };
 static_assert(kWsCP % 4 == 0 && kWsCP <= 64, "a stage buffer holds whole K = 4 steps of at most one wave of particles");
 static_assert(FILL_LEAN_LDS == 1, "k_ecsim_fill_ws reads the transposed per-lane offset table");
-static_assert((kLines * kWP + 64 + kW) * 8 + 8 * kWsStage * 8 + kPitch * 8 + kW * 54 * 8 + kW * 2 * 12 * 4 + kFlCount * 4 <= 160 * 1024,
-  "window + stage buffers exceed the LDS of a CU");
+static_assert((kLines * kWP + 64 + kW) * 8 + 8 * kWsStage * 8 + kPitch * 8 + kW * 54 * 8 + kW * 2 * 12 * 4 + kFlCount * 4 + 64 * kDtabPitch * 2 <= 160 * 1024,
+  "window + stage buffers + offset table exceed the LDS of a CU");
+
+// is accumulator e touched by the octants of half h (oz = h)?
+__host__ __device__ constexpr bool acc_in_half(int e, int h)
+{
+  for (int o = h * 4; o < h * 4 + 4; ++o) {
+    for (int c1 = 0; c1 < 3; ++c1)
+      for (int c2 = 0; c2 < 3; ++c2)
+        if (acc_main(c1, c2, o) == e) return true;
+    if (acc_cur1(o) == e || acc_cur2(o) == e) return true;
+  }
+  return false;
+}
 
 typedef __attribute__((address_space(3))) unsigned LdsWord;
 
 #ifdef FILL_STAMPS
-// section timers of the warp-specialised kernel (experiment build): [0, 8) consumer wave 0, [8, 16) producer wave 4 of every workgroup
-__device__ unsigned long long g_fill_ws_stamps[16];
+// section timers of the warp-specialised kernel (experiment build): 8 per role, of the role's first wave in every workgroup
+__device__ unsigned long long g_fill_ws_stamps[32];
 #define WSTAMP(k)                                                 \
   do {                                                            \
     const unsigned long long now_ = __builtin_readcyclecounter(); \
@@ -794,11 +842,11 @@ __device__ unsigned long long g_fill_ws_stamps[16];
 }  // namespace xpic
 extern "C" int xpic_debug_fill_ws_stamps(double* out, int reset)
 {
-  unsigned long long h[16];
+  unsigned long long h[32];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(xpic::g_fill_ws_stamps), sizeof(h)) != hipSuccess) return 1;
-  for (int i = 0; i < 16; ++i) out[i] = (double)h[i];
+  for (int i = 0; i < 32; ++i) out[i] = (double)h[i];
   if (reset) {
-    unsigned long long z[16] = {};
+    unsigned long long z[32] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(xpic::g_fill_ws_stamps), z, sizeof(z)) != hipSuccess) return 1;
   }
   return 0;
@@ -845,6 +893,25 @@ __device__ inline bool lds_wait(const unsigned* p, unsigned target, unsigned* fl
   }
 }
 
+template <int HALF, int... Es>
+__device__ __forceinline__ void ws_merge(std::integer_sequence<int, Es...>, char* wv, const uint4 (&dq)[kDtabPitch / 8], double (&acc)[kAcc])
+{
+  // (the offsets are read from their LDS table at every merge: kept in registers across the pencil they were spilled, and
+  // the merge reloaded them from scratch one by one -- 14 serialized round trips, 45 % of a consumer's time)
+  // lane's element of accumulator e goes to window byte offset(e) (16-bit entries of the transposed table) + 8 * w
+  auto one = [&](auto tag) {
+    constexpr int e = decltype(tag)::value;
+    if constexpr (acc_in_half(e, HALF)) {
+      const uint4 q4 = dq[e / 8];
+      const unsigned word = ((e % 8) >> 1) == 0 ? q4.x : ((e % 8) >> 1) == 1 ? q4.y : ((e % 8) >> 1) == 2 ? q4.z : q4.w;
+      const unsigned off = (word >> (16 * (e & 1))) & 0xffffu;
+      unsafeAtomicAdd((double*)(wv + off), acc[e]);
+      acc[e] = 0.0;
+    }
+  };
+  (one(std::integral_constant<int, Es>{}), ...);
+}
+
 template <bool P2>
 __global__ void __launch_bounds__(kWsThreads, 1) k_ecsim_fill_ws(GridDev g, SortDev s, const double* __restrict__ B,
   double* currI, double* matL, const unsigned short* __restrict__ dtab, const int* __restrict__ linetab, const int* __restrict__ cowr, double q, double m,
@@ -860,26 +927,29 @@ __global__ void __launch_bounds__(kWsThreads, 1) k_ecsim_fill_ws(GridDev g, Sort
   __shared__ double bnb[kW][54];
   __shared__ __attribute__((aligned(16))) int hdr[kW][2][12]; // per stage buffer: the 8 octant counts, last-pass flag
   __shared__ unsigned flags[kFlCount];
+  __shared__ __attribute__((aligned(16))) unsigned short dtl[64 * kDtabPitch]; // per-lane window offsets of the merge
 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const double dt = g.dt;
   for (int i = threadIdx.x; i < kLines * kWP + 64 + kW; i += kWsThreads) win[i] = 0.0;
+  for (int i = threadIdx.x; i < 64 * kDtabPitch; i += kWsThreads) dtl[i] = dtab[i];
   if (threadIdx.x < kPitch) zslot[threadIdx.x] = 0.0;
   if (threadIdx.x < kFlCount) flags[threadIdx.x] = 0u;
   __syncthreads(); // the only workgroup barrier of the kernel
   const int nch = g.nx / kW;
   const long pencil0 = ((long)cz * g.ny + cy) * g.nx;
+  const int w = wave & 3; // the SIMD's cell of a chunk
 
-  if (wave < kW) {
-    // =============================================== consumer =====================================================
-    const int w = wave;
+  // =================================================== consumers ====================================================
+  auto consumer = [&](auto half_tag) {
+    constexpr int HALF = decltype(half_tag)::value;
     const int kk = lane >> 4, qb = (lane >> 2) & 3, qj = lane & 3;
     const int offA8 = 8 * (qj * 2 + (qb >> 1)), offB8 = 8 * (qj * 2 + (qb & 1));
     const int offI18 = 8 * (kOffAB + 9 + (qb >> 1));
     double acc[kAcc];
 #pragma unroll
     for (int e = 0; e < kAcc; ++e) acc[e] = 0.0;
-    __builtin_amdgcn_s_setprio(2); // the wave with matrix instructions to issue goes first on its SIMD
+    __builtin_amdgcn_s_setprio(FILL_WS_PRIO_C);
     unsigned pass = 0;
     WSTAMP_INIT;
     for (int j = 0; j < nch; ++j) {
@@ -893,10 +963,10 @@ __global__ void __launch_bounds__(kWsThreads, 1) k_ecsim_fill_ws(GridDev g, Sort
           __builtin_amdgcn_readfirstlane(h1.y), __builtin_amdgcn_readfirstlane(h1.z), __builtin_amdgcn_readfirstlane(h1.w)};
         const bool lastpass = __builtin_amdgcn_readfirstlane(hdr[w][b][8]) != 0;
         const double* st = stage + (w * 2 + b) * kWsStage;
-        int run = 0;
+        int run = HALF ? ocnt[0] + ocnt[1] + ocnt[2] + ocnt[3] : 0;
         WSTAMP(1);
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
+        for (int o = HALF * 4; o < HALF * 4 + 4; ++o) {
           const int no = ocnt[o];
           const double* seg = st + run * kPitch;
           run += no;
@@ -909,8 +979,18 @@ __global__ void __launch_bounds__(kWsThreads, 1) k_ecsim_fill_ws(GridDev g, Sort
             const LdsDouble* spA = (const LdsDouble*)(sb + offA8);
             const LdsDouble* spB = (const LdsDouble*)(sb + offB8);
             double a[3], bb[3];
+#if FILL_NO_READ2
+            {
+              LdsBytes sA1 = sb + offA8 + 64, sB1 = sb + offB8 + 64, sA2 = sb + offA8 + 128, sB2 = sb + offB8 + 128;
+              asm volatile("" : "+v"(sA1), "+v"(sB1), "+v"(sA2), "+v"(sB2));
+              a[0] = spA[0]; bb[0] = spB[0];
+              a[1] = *(const LdsDouble*)sA1; bb[1] = *(const LdsDouble*)sB1;
+              a[2] = *(const LdsDouble*)sA2; bb[2] = *(const LdsDouble*)sB2;
+            }
+#else
 #pragma unroll
             for (int c = 0; c < 3; ++c) { a[c] = spA[c * 8]; bb[c] = spB[c * 8]; }
+#endif
             const LdsDouble2* u = (const LdsDouble2*)(sp + kOffAB);
             const dpair u0 = u[0], u1 = u[1], u2 = u[2], u3 = u[3];
             const double ab[9] = {u0.x, u0.y, u1.x, u1.y, u2.x, u2.y, u3.x, u3.y, sp[kOffAB + 8]};
@@ -918,7 +998,13 @@ __global__ void __launch_bounds__(kWsThreads, 1) k_ecsim_fill_ws(GridDev g, Sort
 #pragma unroll
             for (int e = 0; e < 9; ++e) bm[e] = bb[e % 3] * ab[e];
             const double ai1 = qb < 2 ? bb[0] : bb[1], ai2 = bb[2];
+#if FILL_NO_READ2
+            LdsBytes sI2 = sb + 8 * (kOffAB + 11);
+            asm volatile("" : "+v"(sI2));
+            const double bi1 = *(const LdsDouble*)(sb + offI18), bi2 = *(const LdsDouble*)sI2;
+#else
             const double bi1 = *(const LdsDouble*)(sb + offI18), bi2 = sp[kOffAB + 11];
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c1 = 0; c1 < 3; ++c1)
@@ -931,123 +1017,133 @@ __global__ void __launch_bounds__(kWsThreads, 1) k_ecsim_fill_ws(GridDev g, Sort
           }
         }
         WSTAMP(2);
-        lds_post(flags + kFlFree + w * 2 + b, pass + 1, lane); // every operand read of this buffer has returned
+        lds_post(flags + kFlFree + (HALF * kW + w) * 2 + b, pass + 1, lane); // every operand read of this buffer has returned
         WSTAMP(3);
         ++pass;
         if (lastpass) break;
       }
-      // ---- merge the cell block into the window: lane's element of accumulator e goes to byte wdst[e] (+ 8 * wave)
-      unsigned wdst[kAcc];
-      {
-        const uint4* dq = reinterpret_cast<const uint4*>(dtab + lane * kDtabPitch);
-#pragma unroll
-        for (int k = 0; k < kDtabPitch / 8; ++k) {
-          const uint4 w4 = dq[k];
-          const unsigned ww[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-          for (int h = 0; h < 8; ++h)
-            if (k * 8 + h < kAcc) wdst[k * 8 + h] = (ww[h >> 1] >> (16 * (h & 1))) & 0xffffu;
-        }
-      }
-      WSTAMP(4);
-      if (!lds_wait(flags + kFlSeeded, (unsigned)(kW * j), flags)) { if (lane == 0) atomicOr(err, 1); return; } // the window holds chunk j - 1's carry, re-seeded
+      // ---- merge this half of the cell block into the window
+      if (!lds_wait(flags + kFlSeeded, (unsigned)(kW * j), flags)) { if (lane == 0) atomicOr(err, 1); return; } // re-seeded after chunk j - 1
       WSTAMP(5);
-      char* wv = (char*)(win + w);
+      uint4 dq[kDtabPitch / 8]; // the lane's window offsets of its accumulator elements: 36 16-bit entries
+      {
+        const uint4* dp = reinterpret_cast<const uint4*>(dtl + lane * kDtabPitch);
 #pragma unroll
-      for (int e = 0; e < kAcc; ++e) {
-        unsafeAtomicAdd((double*)(wv + wdst[e]), acc[e]);
-        acc[e] = 0.0;
+        for (int k = 0; k < kDtabPitch / 8; ++k) dq[k] = dp[k];
       }
+      ws_merge<HALF>(std::make_integer_sequence<int, kAcc>{}, (char*)(win + w), dq, acc);
       lds_bump(flags + kFlMerged, lane);
       WSTAMP(6);
     }
-    WSTAMP_DUMP(0, w == 0);
+    WSTAMP_DUMP(HALF * 8, w == 0);
+  };
+  if (wave < kW) { consumer(std::integral_constant<int, 0>{}); return; }
+  if (wave < 2 * kW) { consumer(std::integral_constant<int, 1>{}); return; }
+
+  if (wave >= 3 * kW) {
+    // ================================================= flusher ======================================================
+    __builtin_amdgcn_s_setprio(FILL_WS_PRIO_F);
+    const int t = threadIdx.x - 3 * kW * 64;
+    // window lines this thread owns (line = t + mm * kWsFlush): address of their column 0, first-touch flag in bit 0
+    uintptr_t lbase[kWsOwn];
+#pragma unroll
+    for (int mm = 0; mm < kWsOwn; ++mm) {
+      const int line = t + mm * kWsFlush;
+      lbase[mm] = 0;
+      if (line >= kLines) continue;
+      const int ld = linetab[line];
+      const int ry = g.wy(cy + ((ld >> 2) & 3) - 1);
+      const int rz = cz + ((ld >> 4) & 3) - 1;
+      const int rzw = g.G == 0 ? (rz < 0 ? rz + g.nzl : (rz >= g.nzl ? rz - g.nzl : rz)) : rz + 1;
+      double* base = line < kMatLines
+        ? matL + g.lindex(ld & 3, rzw, ry, 0, ld >> 6)
+        : currI + (ld & 3) * g.cstride + g.node(0, ry, g.wz(rz));
+      bool first = first_sort && line < kMatLines; // no co-writer of this line runs in an earlier launch: store, do not add
+      if (first) {
+        const int bodyy = g.ny - g.ny % per_y, bodyz = g.nzl - g.nzl % per_z;
+        for (int e = 0; e < 8 && first; ++e) {
+          const int cw = cowr[line * 8 + e];
+          if (cw == 0x7fffffff) break;
+          const int oy = (cw & 0xff) - 8, oz = ((cw >> 8) & 0xff) - 8;
+          int py = cy + oy, pz = cz + oz;
+          py = py < 0 ? py + g.ny : (py >= g.ny ? py - g.ny : py);
+          if (g.G == 0) pz = pz < 0 ? pz + g.nzl : (pz >= g.nzl ? pz - g.nzl : pz);
+          else if (pz < 0 || pz >= g.nzl) continue;
+          const int ca = py < bodyy ? py % per_y : per_y + (py - bodyy);
+          const int cb = g.G == 0 ? (pz < bodyz ? pz % per_z : per_z + (pz - bodyz)) : pz % per_z;
+          if (cb * ncol_y + ca < my_order) first = false;
+        }
+      }
+      lbase[mm] = (uintptr_t)base | (first ? 1u : 0u);
+    }
+    // old[] = the current values of the next chunk's finished columns, requested a chunk ahead (the addresses depend on
+    // the chunk alone; these loads and the flush's stores are all this wave has in its memory counter)
+    double old[kWsOwn][kW];
+    auto request_old = [&](int jc) {
+#pragma unroll
+      for (int mm = 0; mm < kWsOwn; ++mm) {
+        const int line = t + mm * kWsFlush;
+#pragma unroll
+        for (int c = 0; c < kW; ++c) old[mm][c] = 0.0;
+        const uintptr_t lb = lbase[mm];
+        if (!lb || (lb & 1) || jc >= nch) continue;
+        const GlobalDouble* ptr = (const GlobalDouble*)(lb & ~(uintptr_t)1) + (long)jc * (line < kMatLines ? kLBlock : kW);
+#pragma unroll
+        for (int c = 0; c < kW; c += 2) {
+          const dpair v = *(const GlobalPair*)(ptr + c);
+          old[mm][c] = v.x; old[mm][c + 1] = v.y;
+        }
+      }
+    };
+    request_old(0);
+    WSTAMP_INIT;
+    for (int jc = 0; jc < nch; ++jc) {
+      if (!lds_wait(flags + kFlMerged, (unsigned)(2 * kW * (jc + 1)), flags)) { if (lane == 0) atomicOr(err, 1); return; }
+      WSTAMP(0);
+      // add the window's four finished columns, store, move the two unfinished columns to the front, clear the rest
+#pragma unroll
+      for (int mm = 0; mm < kWsOwn; ++mm) {
+        const int line = t + mm * kWsFlush;
+        const uintptr_t lb = lbase[mm];
+        if (!lb) continue;
+        double* wl = win + line * kWP;
+        double wv[kSlots];
+#pragma unroll
+        for (int c = 0; c < kSlots; ++c) wv[c] = wl[c];
+        GlobalDouble* ptr = (GlobalDouble*)(lb & ~(uintptr_t)1) + (long)jc * (line < kMatLines ? kLBlock : kW);
+#pragma unroll
+        for (int c = 0; c < kW; c += 2)
+          *(GlobalPair*)(ptr + c) = dpair{old[mm][c] + wv[c], old[mm][c + 1] + wv[c + 1]};
+        wl[0] = wv[kW]; wl[1] = wv[kW + 1];
+#pragma unroll
+        for (int c = 2; c < kSlots; ++c) wl[c] = 0.0;
+      }
+      lds_bump(flags + kFlSeeded, lane);
+      WSTAMP(1);
+      request_old(jc + 1);
+      WSTAMP(2);
+    }
+    // ---- the two columns left over are x = nx, nx + 1 = 0, 1 (periodic): columns this thread has already written,
+    // added with atomics (2 of nx columns)
+#pragma unroll
+    for (int mm = 0; mm < kWsOwn; ++mm) {
+      const int line = t + mm * kWsFlush;
+      if (line < kLines && lbase[mm]) {
+        double* base = (double*)(lbase[mm] & ~(uintptr_t)1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const double v = win[line * kWP + c];
+          if (v != 0.0) unsafeAtomicAdd(base + g.wx(c), v);
+        }
+      }
+    }
+    WSTAMP(3);
+    WSTAMP_DUMP(24, w == 0);
     return;
   }
 
   // ================================================= producer =======================================================
-  const int w = wave - kW;
-  const int t = threadIdx.x - kWsProd;
-  // window lines this thread owns in the flush (line = t + mm * kWsProd): address of their column 0, first-touch flag in bit 0
-  uintptr_t lbase[kWsOwn];
-#pragma unroll
-  for (int mm = 0; mm < kWsOwn; ++mm) {
-    const int line = t + mm * kWsProd;
-    lbase[mm] = 0;
-    if (line >= kLines) continue;
-    const int ld = linetab[line];
-    const int ry = g.wy(cy + ((ld >> 2) & 3) - 1);
-    const int rz = cz + ((ld >> 4) & 3) - 1;
-    const int rzw = g.G == 0 ? (rz < 0 ? rz + g.nzl : (rz >= g.nzl ? rz - g.nzl : rz)) : rz + 1;
-    double* base = line < kMatLines
-      ? matL + g.lindex(ld & 3, rzw, ry, 0, ld >> 6)
-      : currI + (ld & 3) * g.cstride + g.node(0, ry, g.wz(rz));
-    bool first = first_sort && line < kMatLines; // no co-writer of this line runs in an earlier launch: store, do not add
-    if (first) {
-      const int bodyy = g.ny - g.ny % per_y, bodyz = g.nzl - g.nzl % per_z;
-      for (int e = 0; e < 8 && first; ++e) {
-        const int cw = cowr[line * 8 + e];
-        if (cw == 0x7fffffff) break;
-        const int oy = (cw & 0xff) - 8, oz = ((cw >> 8) & 0xff) - 8;
-        int py = cy + oy, pz = cz + oz;
-        py = py < 0 ? py + g.ny : (py >= g.ny ? py - g.ny : py);
-        if (g.G == 0) pz = pz < 0 ? pz + g.nzl : (pz >= g.nzl ? pz - g.nzl : pz);
-        else if (pz < 0 || pz >= g.nzl) continue;
-        const int ca = py < bodyy ? py % per_y : per_y + (py - bodyy);
-        const int cb = g.G == 0 ? (pz < bodyz ? pz % per_z : per_z + (pz - bodyz)) : pz % per_z;
-        if (cb * ncol_y + ca < my_order) first = false;
-      }
-    }
-    lbase[mm] = (uintptr_t)base | (first ? 1u : 0u);
-  }
-
-  // ---- the window's read-modify-write.  old[] = the current values of the next chunk's finished columns, requested a
-  // chunk ahead (the addresses depend on the chunk alone); flush_chunk adds the window's four finished columns, stores,
-  // moves the two unfinished columns to the front and clears the rest (the seed of the next chunk's merge).
-  double old[kWsOwn][kW];
-  auto request_old = [&](int jc) {
-#pragma unroll
-    for (int mm = 0; mm < kWsOwn; ++mm) {
-      const int line = t + mm * kWsProd;
-#pragma unroll
-      for (int c = 0; c < kW; ++c) old[mm][c] = 0.0;
-      const uintptr_t lb = lbase[mm];
-      if (!lb || (lb & 1) || jc >= nch) continue;
-      const GlobalDouble* ptr = (const GlobalDouble*)(lb & ~(uintptr_t)1) + (long)jc * (line < kMatLines ? kLBlock : kW);
-#pragma unroll
-      for (int c = 0; c < kW; c += 2) {
-        const dpair v = *(const GlobalPair*)(ptr + c);
-        old[mm][c] = v.x; old[mm][c + 1] = v.y;
-      }
-    }
-  };
-  auto flush_chunk = [&](int jc) {
-#pragma unroll
-    for (int mm = 0; mm < kWsOwn; ++mm) {
-      const int line = t + mm * kWsProd;
-      const uintptr_t lb = lbase[mm];
-      if (!lb) continue;
-      double* wl = win + line * kWP;
-      double wv[kSlots];
-#pragma unroll
-      for (int c = 0; c < kSlots; ++c) wv[c] = wl[c];
-      GlobalDouble* ptr = (GlobalDouble*)(lb & ~(uintptr_t)1) + (long)jc * (line < kMatLines ? kLBlock : kW);
-#pragma unroll
-      for (int c = 0; c < kW; c += 2)
-        *(GlobalPair*)(ptr + c) = dpair{old[mm][c] + wv[c], old[mm][c + 1] + wv[c + 1]};
-      wl[0] = wv[kW]; wl[1] = wv[kW + 1];
-#pragma unroll
-      for (int c = 2; c < kSlots; ++c) wl[c] = 0.0;
-    }
-    request_old(jc + 1);
-    lds_bump(flags + kFlSeeded, lane);
-  };
-  int jf = 0; // next chunk to flush
-  WSTAMP_INIT;
-  auto try_flush = [&]() {
-    if (jf < nch && (int)(lds_peek(flags + kFlMerged) - (unsigned)(kW * (jf + 1))) >= 0) { WSTAMP(0); flush_chunk(jf); ++jf; WSTAMP(1); }
-  };
-
+  __builtin_amdgcn_s_setprio(FILL_WS_PRIO_P);
   auto cell_x = [&](int i) { return (i + 1 == g.nx) ? 0 : i + 1; };
   int box;
   const double* const brow = bnb_row(g, B, lane, cy, cz, &box);
@@ -1069,19 +1165,24 @@ __global__ void __launch_bounds__(kWsThreads, 1) k_ecsim_fill_ws(GridDev g, Sort
     }
   };
   prefetch_cell(w);
-  request_old(0);
 
   const double fb = (0.5 * dt) * q / m;
   const double qw = q * mpw;
   const double Aq = 0.5 * dt * dt * mpw * q * q / m;
   unsigned pass = 0;
+  WSTAMP_INIT;
   for (int j = 0; j < nch; ++j) {
     const int i = j * kW + w;
+    // the particles requested a cell ago are waited for HERE, before the next request goes out: left to the compiler the
+    // wait sits at their first use, behind the new request, and -- the memory counter being in order -- covers that too
+    // (a full HBM round trip at the head of every cell: 20 % of the producer's time)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     const int start = pf.start, cnt = pf.cnt;
     if (lane < 54) bnb[w][lane] = pf.b;
     double cur[6];
 #pragma unroll
     for (int a = 0; a < 6; ++a) cur[a] = pf.p[a];
+    asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5])); // copies made before the request below
     prefetch_cell(i + kW); // the next cell's first particles travel during this cell's passes
     int handed = min(kWsCP, cnt);
     bool real = lane < handed;
@@ -1089,25 +1190,11 @@ __global__ void __launch_bounds__(kWsThreads, 1) k_ecsim_fill_ws(GridDev g, Sort
     for (;;) {
       const bool lastpass = handed >= cnt;
       const int b = pass & 1;
-      // the buffer's previous content (pass - 2) has been consumed; while waiting, flush what is ready
+      // both consumers have finished with the buffer's previous content (pass - 2)
       if (pass >= 2) {
-        unsigned it = 0;
-        while ((int)(lds_peek(flags + kFlFree + w * 2 + b) - (pass - 1)) < 0) {
-          const int was = jf;
-          try_flush();
-          if (jf != was) continue;
-          if ((++it & 63u) == 0u) {
-            if (lds_peek(flags + kFlAbort)) { if (lane == 0) atomicOr(err, 1); return; }
-            if (it > kWsSpinLimit) {
-              asm volatile("ds_write_b32 %0, %1" ::"v"((LdsWord*)(flags + kFlAbort)), "v"(1u) : "memory");
-              if (lane == 0) atomicOr(err, 1);
-              return;
-            }
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
+        if (!lds_wait(flags + kFlFree + w * 2 + b, pass - 1, flags) ||
+            !lds_wait(flags + kFlFree + (kW + w) * 2 + b, pass - 1, flags)) { if (lane == 0) atomicOr(err, 1); return; }
       }
-      try_flush();
       WSTAMP(0);
       double* st = stage + (w * 2 + b) * kWsStage;
       wave_sync();
@@ -1130,21 +1217,30 @@ __global__ void __launch_bounds__(kWsThreads, 1) k_ecsim_fill_ws(GridDev g, Sort
           run += ocnt[o];
         }
       }
+      // next pass of this cell: the free lanes take the next particles.  Requested NOW, as soon as the lanes that keep
+      // their particle are known, so that the loads travel under the rest of this pass (requested at the end of the pass
+      // they were a full HBM round trip at the head of the next one)
+      // (straight into the lanes' own registers: the position is dead behind the weights above, the velocity is copied first)
+      bool real_next = false;
+      double v[3] = {cur[3], cur[4], cur[5]};
+      asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
+      if (!lastpass) {
+        const unsigned long long km = __ballot(keep);
+        const int take = min(cnt - handed, kWsCP - (int)__popcll(km));
+        const unsigned long long fm = ~km;
+        const int fr = __builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
+        const bool get = !keep && fr < take;
+        if (get) {
+          const long p = (long)start + handed + fr;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) { cur[a] = s.r[a][p]; cur[3 + a] = s.v[a][p]; }
+        }
+        real_next = keep || get;
+        handed += take;
+      }
       if (real) {
         double2* dst = (double2*)(st + slot * kPitch);
         const double* nb = bnb[w];
-        double nbv[3][8];
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
-              nbv[0][(k * 2 + jj) * 2 + ii] = nb[((oz + k) * 3 + (oy + jj)) * 2 + ii];
-              nbv[1][(k * 2 + jj) * 2 + ii] = nb[18 + ((oz + k) * 2 + jj) * 3 + (ox + ii)];
-              nbv[2][(k * 2 + jj) * 2 + ii] = nb[36 + (k * 3 + (oy + jj)) * 3 + (ox + ii)];
-            }
-        asm volatile("" ::: "memory");
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1154,18 +1250,50 @@ __global__ void __launch_bounds__(kWsThreads, 1) k_ecsim_fill_ws(GridDev g, Sort
             dst[4 + a * 2 + bb] = double2{wt.wn[2][a] * wt.ws[1][0] * wt.wn[0][bb], wt.wn[2][a] * wt.ws[1][1] * wt.wn[0][bb]};
             dst[8 + a * 2 + bb] = double2{wt.ws[2][0] * wt.wn[1][a] * wt.wn[0][bb], wt.ws[2][1] * wt.wn[1][a] * wt.wn[0][bb]};
           }
-        const double v[3] = {cur[3], cur[4], cur[5]};
+        // interpolate_B_s1 out of the cell's LDS neighbourhood, component by component (8 values in flight at a time: the
+        // producer has 128 registers and time to spare; all 24 at once were spilled), same product and sum order per component
         double Bp[3] = {0.0, 0.0, 0.0};
+        {
+          double nv[8];
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+          for (int k = 0; k < 2; ++k)
 #pragma unroll
-          for (int jj = 0; jj < 2; ++jj)
+            for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
-              Bp[0] += nbv[0][(k * 2 + jj) * 2 + ii] * (wt.ws[2][k] * wt.ws[1][jj] * wt.wn[0][ii]);
-              Bp[1] += nbv[1][(k * 2 + jj) * 2 + ii] * (wt.ws[2][k] * wt.wn[1][jj] * wt.ws[0][ii]);
-              Bp[2] += nbv[2][(k * 2 + jj) * 2 + ii] * (wt.wn[2][k] * wt.ws[1][jj] * wt.ws[0][ii]);
-            }
+              for (int ii = 0; ii < 2; ++ii) nv[(k * 2 + jj) * 2 + ii] = nb[((oz + k) * 3 + (oy + jj)) * 2 + ii];
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+              for (int ii = 0; ii < 2; ++ii) Bp[0] += nv[(k * 2 + jj) * 2 + ii] * (wt.ws[2][k] * wt.ws[1][jj] * wt.wn[0][ii]);
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+              for (int ii = 0; ii < 2; ++ii) nv[(k * 2 + jj) * 2 + ii] = nb[18 + ((oz + k) * 2 + jj) * 3 + (ox + ii)];
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+              for (int ii = 0; ii < 2; ++ii) Bp[1] += nv[(k * 2 + jj) * 2 + ii] * (wt.ws[2][k] * wt.wn[1][jj] * wt.ws[0][ii]);
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+              for (int ii = 0; ii < 2; ++ii) nv[(k * 2 + jj) * 2 + ii] = nb[36 + (k * 3 + (oy + jj)) * 3 + (ox + ii)];
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+              for (int ii = 0; ii < 2; ++ii) Bp[2] += nv[(k * 2 + jj) * 2 + ii] * (wt.wn[2][k] * wt.ws[1][jj] * wt.ws[0][ii]);
+        }
         const double bx = Bp[0] * fb, by = Bp[1] * fb, bz = Bp[2] * fb;
         const double b2 = bx * bx + by * by + bz * bz;
         const double vb = v[0] * bx + v[1] * by + v[2] * bz;
@@ -1186,22 +1314,6 @@ __global__ void __launch_bounds__(kWsThreads, 1) k_ecsim_fill_ws(GridDev g, Sort
         *(int4*)&hdr[w][b][4] = int4{ocnt[4], ocnt[5], ocnt[6], ocnt[7]};
         hdr[w][b][8] = lastpass ? 1 : 0;
       }
-      // next pass of this cell: the free lanes take the next particles
-      bool real_next = false;
-      if (!lastpass) {
-        const unsigned long long km = __ballot(keep);
-        const int take = min(cnt - handed, kWsCP - (int)__popcll(km));
-        const unsigned long long fm = ~km;
-        const int fr = __builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
-        const bool get = !keep && fr < take;
-        if (get) {
-          const long p = (long)start + handed + fr;
-#pragma unroll
-          for (int a = 0; a < 3; ++a) { cur[a] = s.r[a][p]; cur[3 + a] = s.v[a][p]; }
-        }
-        real_next = keep || get;
-        handed += take;
-      }
       lds_post(flags + kFlFull + w * 2 + b, pass + 1, lane); // operands and header are in place
       WSTAMP(4);
       ++pass;
@@ -1209,31 +1321,7 @@ __global__ void __launch_bounds__(kWsThreads, 1) k_ecsim_fill_ws(GridDev g, Sort
       real = real_next;
     }
   }
-  // ---- drain: the chunks still to be flushed, then the two columns left over (x = nx, nx + 1 = 0, 1 periodically),
-  // which this thread has already written: added with atomics
-  WSTAMP(2);
-  while (jf < nch) {
-    if (!lds_wait(flags + kFlMerged, (unsigned)(kW * (jf + 1)), flags)) { if (lane == 0) atomicOr(err, 1); return; }
-    WSTAMP(5);
-    flush_chunk(jf);
-    ++jf;
-    WSTAMP(1);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int mm = 0; mm < kWsOwn; ++mm) {
-    const int line = t + mm * kWsProd;
-    if (line < kLines && lbase[mm]) {
-      double* base = (double*)(lbase[mm] & ~(uintptr_t)1);
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const double v = win[line * kWP + c];
-        if (v != 0.0) unsafeAtomicAdd(base + g.wx(c), v);
-      }
-    }
-  }
-  WSTAMP(6);
-  WSTAMP_DUMP(8, w == 0);
+  WSTAMP_DUMP(16, w == 0);
 }
 
 }  // namespace
