@@ -54,7 +54,7 @@ def parse_args(argv=None):
     ap.add_argument("--fill-kernel", type=int, default=None, choices=[0, 1],
                     help="mass-matrix assembly: 1 warp-specialised kernel, 0 the classic 4-wave kernel (default: the library's)")
     ap.add_argument("--cheb-degree", type=int, default=0, help="override the Chebyshev preconditioner degree (experiments)")
-    ap.add_argument("--precond", type=int, default=None, choices=[0, 1, 2, 3],
+    ap.add_argument("--precond", type=int, default=None, choices=[0, 1, 2, 3, 4],
                     help="xpic_set_preconditioner kind (default: the library's)")
     ap.add_argument("--scheme", default="ecsim", choices=["ecsim", "ecsimcorr", "basic"],
                     help="ecsim is the headline workload (BASELINE configs[2]); basic = configs[1], ecsimcorr = configs[4] "
@@ -546,7 +546,9 @@ def rank_body(args, rank, world, local_rank, job):
         "ksp_method": None if args.scheme == "basic" else (
             "GMRES(30), no preconditioner" if args.plain_gmres or args.precond == 0 else
             "flexible GMRES(30), right-preconditioned by a Chebyshev polynomial in " +
-            ("matM + <matL> (the translation average of the assembled mass matrix: one constant 123-point stencil, fp32)"
+            ("matM + diag(r) <matL> (the translation average of the assembled mass matrix, its rows scaled by the local "
+             "density ratio r: one 123-point stencil, fp32)" if args.precond == 4 else
+             "matM + <matL> (the translation average of the assembled mass matrix: one constant 123-point stencil, fp32)"
              if args.precond in (None, 3) else "matM (fp32 work vectors)" if args.precond == 1 else "matM (fp64)") +
             "; outer iterations, each = 1 matA apply + the polynomial's stencil applies"),
         "ksp_iterations_per_step": its_total / world / args.steps,

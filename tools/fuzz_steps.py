@@ -35,7 +35,7 @@ def _case(case, rng, worst, verbose, nxmax, slab=False):
     if slab:
         g.comm_init_rccl(X.rccl_unique_id())
     if scheme != "basic":
-        g.set_preconditioner(int(rng.integers(0, 4)))  # none, polynomial in matM (fp32 / fp64 vectors), in matM + <matL>
+        g.set_preconditioner(int(rng.integers(0, 5)))  # none, polynomial in matM (fp32 / fp64 vectors), in matM + <matL> (+ density-scaled rows)
     # Poisson background + a few heavy cells + empty stretches
     ppc = float(rng.choice([0.3, 3.0, 20.0, 70.0]))
     cnt = rng.poisson(ppc, n[::-1])

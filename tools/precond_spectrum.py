@@ -91,3 +91,70 @@ def cheb(deg):
     return Z
 for deg in (6, 8, 10, 12):
     gmres_its(cheb(deg), "P = Chebyshev_%d(matM + Lbar)" % deg)
+
+# ---- round 4 (review item 5): surrogates that see the LOCAL density.  Lbar is exact for a uniform plasma; what is left for
+# GMRES is the particle noise of matL, about half of which is count noise (Poisson(ppc) particles per cell).
+#   (a) rows of Lbar scaled by the local density seen in the row's own diagonal entry:  Abar_a = matM + diag(r) Lbar,
+#       r[node, c1] = matL[node][c1][diag] / Lbar[c1][diag];
+#   (b) the same, and the exact local 3 x 3 same-node block of matL in place of Lbar's centre taps;
+#   (c) symmetric scaling  diag(sqrt r) Lbar diag(sqrt r)  (keeps the surrogate's symmetric part positive definite).
+# Exact inverses on the small box: if none of them gives 3 iterations at the reference's tolerance, no kernel is built.
+kdiag = [[k for k in range(K) if dec[c1][k] == (c1, (0, 0, 0))][0] for c1 in range(3)]
+Lb0 = Lm.mean(axis=(0, 1, 2))                                   # [c1][k]
+r = np.stack([Lm[..., c1, kdiag[c1]] / Lb0[c1, kdiag[c1]] for c1 in range(3)], axis=-1)   # z y x c1
+print("local density ratio r: mean %.4f std %.4f min %.3f max %.3f" % (r.mean(), r.std(), r.min(), r.max()))
+La = Lbar * r[..., None]
+Aa = Mden + build(La).toarray()
+gmres_its(np.linalg.inv(Aa), "P = (matM + diag(r) Lbar)^-1 (exact)")
+ev = np.linalg.eigvals(A @ np.linalg.inv(Aa))
+print("  spectrum of A Abar_a^-1: real [%.4f, %.4f], |imag| max %.4f" % (ev.real.min(), ev.real.max(), np.abs(ev.imag).max()))
+Lbl = La.copy()
+for c1 in range(3):
+    for k in range(K):
+        if dec[c1][k][1] == (0, 0, 0):
+            Lbl[..., c1, k] = Lm[..., c1, k]
+Ab2 = Mden + build(Lbl).toarray()
+gmres_its(np.linalg.inv(Ab2), "P = (matM + diag(r) Lbar, local 3x3)^-1")
+ev = np.linalg.eigvals(A @ np.linalg.inv(Ab2))
+print("  spectrum: real [%.4f, %.4f], |imag| max %.4f" % (ev.real.min(), ev.real.max(), np.abs(ev.imag).max()))
+sr = np.sqrt(np.maximum(r, 0.0)).reshape(-1)                    # node-major, c1 fastest: the vector layout
+Ac = Mden + (sr[:, None] * Lbsp.toarray()) * sr[None, :]
+gmres_its(np.linalg.inv(Ac), "P = (matM + sqrt(r) Lbar sqrt(r))^-1 (exact)")
+ev = np.linalg.eigvals(A @ np.linalg.inv(Ac))
+print("  spectrum: real [%.4f, %.4f], |imag| max %.4f" % (ev.real.min(), ev.real.max(), np.abs(ev.imag).max()))
+# reference points: what the count noise alone is worth -- the surrogate with the EXACT cell densities (not available to a
+# constant stencil) and the ideal of a block-diagonal correction
+for tol in (1e-7, 1e-6):
+    for (Pm, label) in ((Abinv, "Lbar"), (np.linalg.inv(Ac), "sqrt(r) Lbar sqrt(r)")):
+        its = [0]
+        def cb(rk): its[0] += 1
+        x, info = spl.gmres(spl.aslinearoperator(A @ Pm), rhs, rtol=tol, atol=0, restart=30, maxiter=20, callback=cb, callback_type="pr_norm")
+        res = np.linalg.norm(rhs - A @ Pm @ x) / np.linalg.norm(rhs)
+        print("rtol %.0e  %-24s iterations %d, true relative residual %.2e" % (tol, label, its[0], res))
+
+# ---- the same with the surrogate's inverse replaced by the fixed Chebyshev polynomial the GPU applies (fp64 here)
+def cheb_of(Am, lo, hi, deg):
+    theta, delta = 0.5 * (hi + lo), 0.5 * (hi - lo)
+    sigma1 = theta / delta
+    rho = 1.0 / sigma1
+    R = np.eye(3 * N)
+    Z = R / theta
+    D = Z.copy()
+    for i in range(1, deg):
+        rho_new = 1.0 / (2 * sigma1 - rho)
+        D = rho_new * rho * D + (2 * rho_new / delta) * (R - Am @ Z)
+        Z = Z + D
+        rho = rho_new
+    return Z
+rs = np.abs(Lb0).sum(axis=1).max()
+hi0 = 2.0 + 2.0 * dt * dt * 3.0 / (dx * dx)
+for (Am, label, hi) in ((Aa, "matM + diag(r) Lbar", hi0 + r.max() * rs), (Ac, "matM + sqrt(r) Lbar sqrt(r)", hi0 + r.max() * rs)):
+    eva = np.linalg.eigvals(Am)
+    print("%s: spectrum real [%.4f, %.4f], |imag| max %.4f; interval used [2, %.3f]" % (label, eva.real.min(), eva.real.max(), np.abs(eva.imag).max(), hi))
+    for deg in (8, 10, 12, 14):
+        P = cheb_of(Am, 2.0, hi, deg)
+        its = [0]
+        def cb(rk): its[0] += 1
+        x, info = spl.gmres(spl.aslinearoperator(A @ P), rhs, rtol=1e-7, atol=0, restart=30, maxiter=20, callback=cb, callback_type="pr_norm")
+        res = np.linalg.norm(rhs - A @ P @ x) / np.linalg.norm(rhs)
+        print("  Chebyshev_%-2d  iterations %d, true relative residual %.2e" % (deg, its[0], res))

@@ -80,7 +80,7 @@ static int ensure_flexible_workspace(xpic_ctx* c)
     if (c->kry_Z) { XPIC_HIP(hipStreamSynchronize(c->stream)); XPIC_HIP(hipFree(c->kry_Z)); c->kry_Z = nullptr; }
     return 0;
   }
-  if (c->precond == 3 && c->matL) XPIC_CALL(abar_alloc(c)); // kind 3's surrogate: buffers and matM's coefficients
+  if (c->precond >= 3 && c->matL) XPIC_CALL(abar_alloc(c)); // kinds 3, 4: the surrogate's buffers and matM's coefficients
   if (c->kry_Z) return 0;
   XPIC_HIP(hipMalloc(&c->kry_Z, sizeof(double) * c->nvec * 30));
   XPIC_HIP(hipMemsetAsync(c->kry_Z, 0, sizeof(double) * c->nvec * 30, c->stream));
@@ -386,7 +386,7 @@ int xpic_destroy(xpic_ctx* ctx)
   (void)hipFree(ctx->kry_t); (void)hipFree(ctx->kry_Z); (void)hipFree(ctx->kry_p[0]); (void)hipFree(ctx->kry_p[1]); (void)hipFree(ctx->kry_p[2]);
   (void)hipFree(ctx->red_partial); (void)hipFree(ctx->red_out); (void)hipHostFree(ctx->red_host);
   (void)hipFree(ctx->scan_tmp);
-  (void)hipFree(ctx->abar32); (void)hipFree(ctx->abar_work);
+  (void)hipFree(ctx->abar32); (void)hipFree(ctx->abar_work); (void)hipFree(ctx->abar_r);
   for (int i = 0; i < 4; ++i) (void)hipFree(ctx->halo_buf[i]);
   comm_free(ctx);
   for (auto& kv : ctx->prof)
@@ -679,7 +679,7 @@ int xpic_solve(xpic_ctx* ctx, int op, int rhs, int x, double rtol, double atol, 
 int xpic_set_preconditioner(xpic_ctx* ctx, int kind, int degree)
 {
   CTX_CHECK(ctx);
-  XPIC_CHECK(kind >= 0 && kind <= 3, "unknown preconditioner kind");
+  XPIC_CHECK(kind >= 0 && kind <= 4, "unknown preconditioner kind");
   ctx->precond = kind;
   ctx->cheb_degree_user = degree > 0 ? (degree > 64 ? 64 : degree) : 0;
   if (degree > 0) ctx->cheb_degree = ctx->cheb_degree_M = ctx->cheb_degree_user;

@@ -99,6 +99,20 @@ int comm_allreduce_sum_host(xpic_ctx* c, double* hbuf, int n)
   return 0;
 }
 
+// max of one non-negative value over the slabs, through the sum transport: every rank contributes its own slot
+int comm_allreduce_max_host(xpic_ctx* c, double* v)
+{
+  if (c->comm.kind == 0) return 0;
+  XPIC_CHECK(c->comm.nranks <= 32, "host all-reduce limited to 32 ranks");
+  double buf[32] = {};
+  buf[c->comm.rank] = *v;
+  XPIC_CALL(comm_allreduce_sum_host(c, buf, c->comm.nranks));
+  double m = 0.0;
+  for (int i = 0; i < c->comm.nranks; ++i) m = buf[i] > m ? buf[i] : m;
+  *v = m;
+  return 0;
+}
+
 void comm_free(xpic_ctx* c)
 {
   if (c->comm_stream) {

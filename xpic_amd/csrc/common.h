@@ -22,6 +22,10 @@
 #else
 #define XPIC_TU_EXPERIMENT 0
 #endif
+#ifndef XPIC_DEFAULT_PRECOND
+#define XPIC_DEFAULT_PRECOND 3 // 3: polynomial in matM + <matL>; 4: its rows scaled by the local density (precond.hip: 3x the
+// convergence rate, but at 256^3 x 64 its third residual is 1.17e-7 |b| against the tolerance's 1e-7: still 4 iterations, each dearer)
+#endif
 #ifndef XPIC_DEFAULT_FILL_KERNEL
 #define XPIC_DEFAULT_FILL_KERNEL 0 // the assembly body a new context runs (xpic_set_fill_kernel): whichever measures faster at 256^3 x 64
 #endif
@@ -176,7 +180,7 @@ struct xpic_ctx {
   double* kry_t = nullptr; // preconditioner scratch (fp32 copy of its input)
   double* kry_Z = nullptr; // flexible GMRES: the preconditioned basis z_j = P v_j (allocated by the first preconditioned solve)
   double* kry_p[3] = {nullptr, nullptr, nullptr}; // Chebyshev preconditioner work vectors
-  int precond = 3;     // 0 none; Chebyshev polynomial (right preconditioning) in matM on fp32 (1) / fp64 (2) work vectors,
+  int precond = XPIC_DEFAULT_PRECOND; // 0 none; Chebyshev polynomial (right preconditioning) in matM on fp32 (1) / fp64 (2) work vectors,
                        // 3: in matM + the translation average of matL (precond.hip) for the predict solve
   int num_cus = 256; // hipDeviceAttributeMultiprocessorCount (the colour schedule of the assembly counts workgroup rounds)
   int cheb_degree = 0; // steps of the Chebyshev iteration on matM (set at create from the spectral interval)
@@ -185,6 +189,7 @@ struct xpic_ctx {
   int cheb_degree_auto = 0, cheb_degree_M_auto = 0; // the automatic degrees of xpic_create (restored by degree <= 0)
   float* abar32 = nullptr;    // kind 3: the 3 x 124 coefficients of Abar = matM + <matL>
   double* abar_work = nullptr; // sums, matM's coefficients, fp64 Abar, per-row partials
+  float* abar_r = nullptr;     // kind 4: local density ratio of every row (fp32 field layout) + one word for their maximum
   double abar_lo = 0, abar_hi = 0; // spectral interval of Abar
   double abar_gershgorin = 0;      // 2 + Gershgorin lower bound of Lbar: kind 3 is used only while this is positive
   bool abar_valid = false;
@@ -290,6 +295,7 @@ int comm_ring(xpic_ctx* c, const void* down, size_t ndown, const void* up, size_
   void* from_down, size_t nfrom_down);
 int comm_allreduce_sum(xpic_ctx* c, double* dbuf, int n);
 int comm_allreduce_sum_host(xpic_ctx* c, double* hbuf, int n);
+int comm_allreduce_max_host(xpic_ctx* c, double* v); // one non-negative value
 void comm_free(xpic_ctx* c);
 int ensure_halo_buf(xpic_ctx* c, size_t bytes);
 

@@ -37,8 +37,9 @@ int gmres(xpic_ctx* c, int op, const double* b, double* x, double rtol, double a
   // kry_Z is sized with the context (xpic_create / xpic_set_preconditioner): an allocation here, in the middle of a step,
   // could fail on one slab alone and leave the others waiting in the solve's collectives
   XPIC_CHECK(!pc || c->kry_Z, "flexible GMRES workspace missing (xpic_set_preconditioner allocates it)");
-  // kind 3: the predict solve's polynomial is in matM + <matL>, rebuilt from the matL this solve runs on
-  bool pc_abar = pc && c->precond == 3 && op == XPIC_OP_MATA_GMRES;
+  // kinds 3, 4: the predict solve's polynomial is in matM + <matL> (4: rows scaled by the local density), rebuilt from the
+  // matL this solve runs on
+  bool pc_abar = pc && c->precond >= 3 && op == XPIC_OP_MATA_GMRES;
   if (pc_abar) {
     XPIC_CALL(abar_update(c));
     // the surrogate's Gershgorin check failed (precond.hip): this solve falls back to the matM polynomial, on every slab

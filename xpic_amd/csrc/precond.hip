@@ -14,7 +14,9 @@
 // at 64 ppc (tools/precond_spectrum.py, dense eigenvalues on a 10^3 box), 4 iterations instead of 6 -- each of
 // them costs a 50 GB sweep of matL.  The GMRES around it is flexible (krylov.hip): the polynomial runs on fp32
 // copies of its vectors with fp32 arithmetic, the stopping rule stays the true fp64 residual.
+#include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <utility>
 #include <vector>
 
@@ -26,6 +28,9 @@ namespace xpic {
 namespace {
 
 constexpr int kB = 256;
+#ifndef BAR_SCHED_SCALED
+#define BAR_SCHED_SCALED 1 // kind 4's body (12 more live values) gets one scheduling region per (c2, dz) group: without it 2.2 KB of spills per lane
+#endif
 #ifndef BAR_SCHED_GROUP
 #define BAR_SCHED_GROUP 0 // scheduling regions of k_cheb_bar: 1 = one per (c2, dz) group of lines, 5 = one per c2, 0 = none (measured equal)
 #endif
@@ -158,6 +163,49 @@ __host__ __device__ constexpr int tap_pos(int c2, int dz, int dy, int I)
   return n;
 }
 
+// ---- kind 4: the surrogate scaled by the LOCAL density.  Abar_r = matM + diag(r) Lbar with r[node][c1] = matL's own
+// diagonal entry of the row over Lbar's: the rows of the average follow the particle count of their neighbourhood (about
+// half of the variance of matL around Lbar is count noise), spec(matA Abar_r^-1) = [0.992, 1.007] against [0.983, 1.017]
+// on the 10^3 box of tools/precond_spectrum.py: 3 GMRES iterations instead of 4 at rtol 1e-7.  Applied by the same
+// stencil kernel: matM's 13 taps per row are summed a second time on their own (their window values are already in
+// registers), and (Abar_r z) = matM z + r ((Abar z) - matM z).
+// matM = 2 I + 0.5 dt^2 rot- rot+: row component c1 couples to itself at the node and its four neighbours across c1's own
+// axis, and to c2 != c1 at d[c1] in {0, 1}, d[c2] in {-1, 0} (verified against the probed coefficients in abar_alloc)
+__host__ __device__ constexpr bool is_matM_tap(int c1, int c2, int dx, int dy, int dz)
+{
+  const int d[3] = {dx, dy, dz};
+  if (c1 == c2) {
+    if (d[c1] != 0) return false;
+    int s1 = 0;
+    for (int a = 0; a < 3; ++a) s1 += d[a] < 0 ? -d[a] : d[a];
+    return s1 <= 1;
+  }
+  const int c3 = 3 - c1 - c2;
+  return (d[c1] == 0 || d[c1] == 1) && (d[c2] == 0 || d[c2] == -1) && d[c3] == 0;
+}
+__host__ __device__ constexpr bool mline_used(int c2, int dy, int dz)
+{
+  for (int c1 = 0; c1 < 3; ++c1)
+    for (int dx = -2; dx <= 2; ++dx)
+      if (lencode(c1, c2, dx, dy, dz) >= 0 && is_matM_tap(c1, c2, dx, dy, dz)) return true;
+  return false;
+}
+constexpr int kMPitch = 8; // matM taps of one stencil line: at most 5
+__host__ __device__ constexpr int mline_slot(int L)
+{
+  int n = 0;
+  for (int l = 0; l < L; ++l) n += mline_used(l / 25, l % 5 - 2, (l / 5) % 5 - 2) ? 1 : 0;
+  return n;
+}
+constexpr int kMLinesUsed = mline_slot(75);
+__host__ __device__ constexpr int mtap_pos(int c2, int dz, int dy, int I)
+{
+  int n = 0;
+  for (int i = 0; i < I; ++i) n += (lencode(i % 3, c2, i / 3 - 2, dy, dz) >= 0 && is_matM_tap(i % 3, c2, i / 3 - 2, dy, dz)) ? 1 : 0;
+  return n;
+}
+static_assert(mtap_pos(0, 0, 0, 15) <= kMPitch && mtap_pos(1, 0, 0, 15) <= kMPitch && mtap_pos(2, 0, 0, 15) <= kMPitch, "matM line table pitch");
+
 // The stencil is expanded at compile time (integer sequences, as k_matA's term list): tap I = (dx + 2) * 3 + c1 of the
 // line (C2, DZ, DY) exists iff lencode() >= 0 -- a constant expression here, not a run-time test.
 __global__ void k_abar(const double* __restrict__ sums, const double* __restrict__ mco, double inv_count, float* packed,
@@ -172,10 +220,35 @@ __global__ void k_abar(const double* __restrict__ sums, const double* __restrict
   const LEntry e = ldecode(c1, k);
   const int L = (e.c2 * 5 + e.d[2] + 2) * 5 + e.d[1] + 2;
   packed[line_slot(L) * kCoefPitch + tap_pos(e.c2, e.d[2], e.d[1], (e.d[0] + 2) * 3 + c1)] = (float)v;
+  // matM's own coefficients, packed per line behind the full table (kind 4)
+  if (is_matM_tap(c1, e.c2, e.d[0], e.d[1], e.d[2]))
+    packed[kLinesUsed * kCoefPitch + mline_slot(L) * kMPitch + mtap_pos(e.c2, e.d[2], e.d[1], (e.d[0] + 2) * 3 + c1)] = (float)mco[i];
 }
 
-template <int C2, int DZ, int DY, int I>
-__device__ __forceinline__ void bar_tap(float (&acc)[2][3], const float (&v)[6], const float (&cf)[kCoefPitch])
+// kind 4: r[c1][node] = matL[node][c1][diagonal] / Lbar[c1][diagonal] (1 where the average has no diagonal: vacuum), in the
+// layout of a fp32 field vector; the largest ratio goes to *rmax (as the bits of a positive float: integer max)
+__global__ void __launch_bounds__(256) k_rscale(GridDev g, const double* __restrict__ matL, const double* __restrict__ abar64,
+  const double* __restrict__ mco, float* __restrict__ rsc, unsigned* __restrict__ rmax)
+{
+  const int c1 = blockIdx.y;
+  const int kd = lencode(c1, c1, 0, 0, 0);
+  const double lb = abar64[c1 * kLPad + kd] - mco[c1 * kLPad + kd];
+  const double inv = lb > 0.0 ? 1.0 / lb : 0.0;
+  float mx = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < g.nown; i += (long)gridDim.x * 256) {
+    const int x = (int)(i % g.nx), y = (int)((i / g.nx) % g.ny), z = (int)(i / g.plane);
+    const double dg = matL[g.lindex(c1, z + (g.G ? 1 : 0), y, x, kd)];
+    const float r = lb > 0.0 ? (float)(dg * inv) : 1.f;
+    rsc[c1 * g.cstride + (long)g.G * g.plane + i] = r;
+    mx = fmaxf(mx, r);
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(rmax, __float_as_uint(mx));
+}
+
+template <bool SCALED, int C2, int DZ, int DY, int I>
+__device__ __forceinline__ void bar_tap(float (&acc)[2][3], float (&accM)[2][3], const float (&v)[6], const float (&cf)[kCoefPitch],
+  const float (&cm)[kMPitch])
 {
   constexpr int dx = I / 3 - 2, c1 = I % 3;
   if constexpr (lencode(c1, C2, dx, DY, DZ) >= 0) {
@@ -183,12 +256,18 @@ __device__ __forceinline__ void bar_tap(float (&acc)[2][3], const float (&v)[6],
     const float a = cf[pos];
     acc[0][c1] += a * v[dx + 2];
     acc[1][c1] += a * v[dx + 3];
+    if constexpr (SCALED && is_matM_tap(c1, C2, dx, DY, DZ)) {
+      constexpr int mpos = mtap_pos(C2, DZ, DY, I);
+      const float am = cm[mpos];
+      accM[0][c1] += am * v[dx + 2];
+      accM[1][c1] += am * v[dx + 3];
+    }
   }
 }
 
-template <int C2, int DZ, int DY, int... Is>
-__device__ __forceinline__ void bar_line(std::integer_sequence<int, Is...>, float (&acc)[2][3], const fpair* tile,
-  const int (&sbase)[5], int lbase, const fquad* ctab)
+template <bool SCALED, int C2, int DZ, int DY, int... Is>
+__device__ __forceinline__ void bar_line(std::integer_sequence<int, Is...>, float (&acc)[2][3], float (&accM)[2][3], const fpair* tile,
+  const int (&sbase)[5], int lbase, const fquad* ctab, const fquad* mtab)
 {
   if constexpr (line_used(C2, DY, DZ)) {
     // float-pair units: every offset here is even, and saying so (a pair-typed array) makes the reads ds_read_b64
@@ -202,30 +281,42 @@ __device__ __forceinline__ void bar_line(std::integer_sequence<int, Is...>, floa
     { const fquad q = cq[0]; cf[0] = q.x; cf[1] = q.y; cf[2] = q.z; cf[3] = q.w; }
     if constexpr (ntap > 4) { const fquad q = cq[1]; cf[4] = q.x; cf[5] = q.y; cf[6] = q.z; cf[7] = q.w; }
     if constexpr (ntap > 8) { const fquad q = cq[2]; cf[8] = q.x; cf[9] = q.y; cf[10] = q.z; cf[11] = q.w; }
-    (bar_tap<C2, DZ, DY, Is>(acc, v, cf), ...);
+    float cm[kMPitch] = {};
+    if constexpr (SCALED && mline_used(C2, DY, DZ)) {
+      constexpr int mtap = mtap_pos(C2, DZ, DY, 15);
+      constexpr int mslot = mline_slot(L);
+      const fquad* mq = mtab + mslot * (kMPitch / 4);
+      { const fquad q = mq[0]; cm[0] = q.x; cm[1] = q.y; cm[2] = q.z; cm[3] = q.w; }
+      if constexpr (mtap > 4) { const fquad q = mq[1]; cm[4] = q.x; cm[5] = q.y; cm[6] = q.z; cm[7] = q.w; }
+    }
+    (bar_tap<SCALED, C2, DZ, DY, Is>(acc, accM, v, cf, cm), ...);
   }
   // one scheduling region per (c2, dz) group of lines: left alone the scheduler hoists all reads of a plane to the
   // top (spills); a group is <= 15 window reads in flight over ~150 FMAs, and the other wave of the SIMD covers the rest
-  if constexpr (DY == 2 && (BAR_SCHED_GROUP == 1 || (BAR_SCHED_GROUP == 5 && DZ == 2))) __builtin_amdgcn_sched_barrier(0);
+  if constexpr (DY == 2 && (BAR_SCHED_GROUP == 1 || (BAR_SCHED_GROUP == 5 && DZ == 2) || (SCALED && BAR_SCHED_SCALED))) __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int... Ls> // L = (c2 * 5 + dz + 2) * 5 + dy + 2
-__device__ __forceinline__ void bar_apply(std::integer_sequence<int, Ls...>, float (&acc)[2][3], const fpair* tile,
-  const int (&sbase)[5], int lbase, const fquad* ctab)
+template <bool SCALED, int... Ls> // L = (c2 * 5 + dz + 2) * 5 + dy + 2
+__device__ __forceinline__ void bar_apply(std::integer_sequence<int, Ls...>, float (&acc)[2][3], float (&accM)[2][3], const fpair* tile,
+  const int (&sbase)[5], int lbase, const fquad* ctab, const fquad* mtab)
 {
-  (bar_line<Ls / 25, (Ls / 5) % 5 - 2, Ls % 5 - 2>(std::make_integer_sequence<int, 15>{}, acc, tile, sbase, lbase, ctab), ...);
+  (bar_line<SCALED, Ls / 25, (Ls / 5) % 5 - 2, Ls % 5 - 2>(std::make_integer_sequence<int, 15>{}, acc, accM, tile, sbase, lbase, ctab, mtab), ...);
 }
 
 // PAIR: nx is even -- every lane's two nodes (x, x + 1; x even) and every window pair are one aligned 8-byte (fp32) or
 // 16-byte (fp64) access; odd nx takes the scalar accesses
-template <bool FIRST, bool LAST, bool PAIR>
+// SCALED (kind 4): the rows of Lbar carry the local density ratio rsc (a fp32 vector in the field layout)
+template <bool FIRST, bool LAST, bool PAIR, bool SCALED>
 __global__ void __launch_bounds__(kB, 2) k_cheb_bar(GridDev g, const float* __restrict__ coef_, const double* __restrict__ r64,
   float* __restrict__ r32, const float* __restrict__ zin, float* __restrict__ d, float* __restrict__ zout,
-  double* __restrict__ out64, double cd, double cr, double itheta, int nbx, int nby, int zc)
+  double* __restrict__ out64, double cd, double cr, double itheta, int nbx, int nby, int zc, const float* __restrict__ rsc)
 {
   __shared__ __attribute__((aligned(16))) fpair tile2[kZW * kPlaneF / 2];
   __shared__ __attribute__((aligned(16))) fquad ctab[kLinesUsed * kCoefPitch / 4];
+  __shared__ __attribute__((aligned(16))) fquad mtab[SCALED ? kMLinesUsed * kMPitch / 4 : 1];
   for (int i = threadIdx.x; i < kLinesUsed * kCoefPitch; i += kB) ((float*)ctab)[i] = coef_[i]; // packed by k_abar
+  if (SCALED)
+    for (int i = threadIdx.x; i < kMLinesUsed * kMPitch; i += kB) ((float*)mtab)[i] = coef_[kLinesUsed * kCoefPitch + i];
   const int lane = threadIdx.x & 63, wy = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bx = blockIdx.x % nbx, by = (blockIdx.x / nbx) % nby, bz = blockIdx.x / (nbx * nby);
   const int x0 = bx * kTX, y0 = by * kTY, z0 = bz * zc;
@@ -292,10 +383,11 @@ __global__ void __launch_bounds__(kB, 2) k_cheb_bar(GridDev g, const float* __re
       // the right-hand side and the direction of this lane's two nodes are requested BEFORE the stencil sums: their HBM
       // latency runs under the 738 FMAs instead of behind them
       const long oc0 = (long)g.wz(z) * g.plane + (long)y * g.nx + x;
-      fpair rv2[3], dv2[3];
+      fpair rv2[3], dv2[3], rs2[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const long oc = c * g.cstride + oc0;
+        if (SCALED) rs2[c] = PAIR ? *reinterpret_cast<const fpair*>(rsc + oc) : fpair{rsc[oc], two ? rsc[oc + 1] : 1.f};
         if (PAIR) {
           if (FIRST) { const dpairv t = *reinterpret_cast<const dpairv*>(r64 + oc); rv2[c] = fpair{(float)t.x, (float)t.y}; }
           else { rv2[c] = *reinterpret_cast<const fpair*>(r32 + oc); dv2[c] = *reinterpret_cast<const fpair*>(d + oc); }
@@ -305,15 +397,24 @@ __global__ void __launch_bounds__(kB, 2) k_cheb_bar(GridDev g, const float* __re
           else { rv2[c] = fpair{r32[oc], two ? r32[oc + 1] : 0.f}; dv2[c] = fpair{d[oc], two ? d[oc + 1] : 0.f}; }
         }
       }
-      float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+      float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, accM[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
       int sbase[5]; // float offset of the window plane of z + dz
 #pragma unroll
       for (int dz = -2; dz <= 2; ++dz) sbase[dz + 2] = ((z + dz - z0 + 2) % kZW) * kPlaneF;
       const int lbase = (wy + kH) * kPX + 2 * lane;
-      bar_apply(std::make_integer_sequence<int, 75>{}, acc, tile2, sbase, lbase, ctab);
+      bar_apply<SCALED>(std::make_integer_sequence<int, 75>{}, acc, accM, tile2, sbase, lbase, ctab, mtab);
       // pin the sums here: their only users sit behind the stores below, and the optimizer otherwise sinks all 738 FMAs
       // there while the 135 LDS reads stay in front (270 live VGPRs: spills)
       asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]));
+      if (SCALED) {
+        asm volatile("" : "+v"(accM[0][0]), "+v"(accM[0][1]), "+v"(accM[0][2]), "+v"(accM[1][0]), "+v"(accM[1][1]), "+v"(accM[1][2]));
+        // (Abar_r z) = matM z + r (Lbar z), Lbar z = (Abar z) - (matM z)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          acc[0][c] = accM[0][c] + rs2[c].x * (acc[0][c] - accM[0][c]);
+          acc[1][c] = accM[1][c] + rs2[c].y * (acc[1][c] - accM[1][c]);
+        }
+      }
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const long oc = c * g.cstride + oc0;
@@ -390,11 +491,21 @@ int abar_alloc(xpic_ctx* c)
   const GridDev& g = c->g;
   int sy, sz, nys, nrows;
   lbar_rows(g, &sy, &sz, &nys, &nrows);
-  XPIC_HIP(hipMalloc(&c->abar32, sizeof(float) * kLinesUsed * kCoefPitch));
-  XPIC_HIP(hipMemsetAsync(c->abar32, 0, sizeof(float) * kLinesUsed * kCoefPitch, c->stream));
+  const size_t ntab = (size_t)kLinesUsed * kCoefPitch + (size_t)kMLinesUsed * kMPitch; // full table, then matM's own taps
+  XPIC_HIP(hipMalloc(&c->abar32, sizeof(float) * ntab));
+  XPIC_HIP(hipMemsetAsync(c->abar32, 0, sizeof(float) * ntab, c->stream));
+  XPIC_HIP(hipMalloc(&c->abar_r, sizeof(float) * c->nvec + 16)); // kind 4: local density ratios (fp32 field layout) + the max word
+  XPIC_HIP(hipMemsetAsync(c->abar_r, 0, sizeof(float) * c->nvec + 16, c->stream));
   XPIC_HIP(hipMalloc(&c->abar_work, sizeof(double) * (3 * kLPad * 3 + ((size_t)nrows + kSegs) * 3 * kLBlock)));
   double mco[3 * kLPad];
   matM_stencil(g, mco);
+  // the compile-time list of matM's taps (is_matM_tap) against the probed coefficients
+  for (int c1 = 0; c1 < 3; ++c1)
+    for (int k = 0; k < kLStencil; ++k) {
+      const LEntry e = ldecode(c1, k);
+      XPIC_CHECK((mco[c1 * kLPad + k] != 0.0) == is_matM_tap(c1, e.c2, e.d[0], e.d[1], e.d[2]) || g.dt == 0.0,
+        "matM's stencil does not match the tap list of the scaled surrogate");
+    }
   XPIC_HIP(hipMemcpyAsync(c->abar_work + 3 * kLPad, mco, sizeof(mco), hipMemcpyHostToDevice, c->stream));
   XPIC_HIP(hipStreamSynchronize(c->stream)); // mco is a stack array
   return 0;
@@ -421,12 +532,30 @@ int abar_update(xpic_ctx* c)
   XPIC_CALL(comm_allreduce_sum(c, sums, 3 * kLPad)); // the same surrogate on every slab
   const double count = (double)nrows * g.nx * c->comm.nranks;
   hipLaunchKernelGGL(k_abar, dim3(2), dim3(256), 0, c->stream, sums, mco, 1.0 / count, c->abar32, abar64);
-  double* bounds = c->red_out + 64; // [64, 70): behind the reductions' and the host all-reduce's slots
+  double* bounds = c->red_out + 64; // [64, 71): behind the reductions' and the host all-reduce's slots
   hipLaunchKernelGGL(k_abar_bounds, dim3(3), dim3(64), 0, c->stream, abar64, mco, bounds);
+  const bool scaled = c->precond == 4;
+  unsigned* rmax_w = (unsigned*)(c->abar_r + c->nvec);
+  if (scaled) {
+    XPIC_HIP(hipMemsetAsync(rmax_w, 0, sizeof(unsigned), c->stream));
+    const unsigned nb = (unsigned)std::min<long>((g.nown + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_rscale, dim3(nb, 3), dim3(256), 0, c->stream, g, c->matL, abar64, mco, c->abar_r, rmax_w);
+    XPIC_HIP(hipMemcpyAsync(bounds + 6, rmax_w, sizeof(unsigned), hipMemcpyDeviceToDevice, c->stream));
+  }
   XPIC_HIP(hipGetLastError());
   double* hb = c->red_host + 48;
-  XPIC_HIP(hipMemcpyAsync(hb, bounds, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
+  XPIC_HIP(hipMemcpyAsync(hb, bounds, sizeof(double) * 7, hipMemcpyDeviceToHost, c->stream));
   XPIC_HIP(hipStreamSynchronize(c->stream));
+  double rmax = 1.0;
+  if (scaled) {
+    unsigned bits;
+    memcpy(&bits, hb + 6, sizeof(bits));
+    float f;
+    memcpy(&f, &bits, sizeof(f));
+    double loc = (double)f;
+    XPIC_CALL(comm_allreduce_max_host(c, &loc)); // the same interval (and the same degree) on every slab
+    rmax = std::max(1.0, loc);
+  }
   // Spectral interval of Abar for the Chebyshev polynomial.  Top: matM's exact 2 + 2 dt^2 sum 1/h^2 widened by the largest
   // absolute row sum of Lbar.  Bottom: matM's exact 2 -- the Hermitian part of every particle's block is positive
   // semi-definite ((s s^T) o (I + b b^T)) and a translation average keeps that -- PROVIDED Lbar's Gershgorin bound
@@ -436,9 +565,9 @@ int abar_update(xpic_ctx* c)
   const double rs = std::max(hb[0], std::max(hb[1], hb[2]));
   const double gl = std::min(hb[3], std::min(hb[4], hb[5]));
   c->abar_lo = 2.0;
-  c->abar_hi = 2.0 + 2.0 * g.dt * g.dt * (1.0 / (g.dx * g.dx) + 1.0 / (g.dy * g.dy) + 1.0 / (g.dz * g.dz)) + rs;
+  c->abar_hi = 2.0 + 2.0 * g.dt * g.dt * (1.0 / (g.dx * g.dx) + 1.0 / (g.dy * g.dy) + 1.0 / (g.dz * g.dz)) + rmax * rs;
   c->abar_gershgorin = 2.0 + gl;
-  c->abar_valid = std::isfinite(rs) && 2.0 + gl > 0.0;
+  c->abar_valid = std::isfinite(rs) && std::isfinite(rmax) && 2.0 + rmax * std::min(gl, 0.0) > 0.0;
   return 0;
 }
 
@@ -450,9 +579,12 @@ int cheb_abar_inverse(xpic_ctx* c, const double* r, double* out)
   XPIC_CHECK(c->abar_valid, "the matL surrogate of the preconditioner was not built (abar_update)");
   const double a = c->abar_lo, b = c->abar_hi;
   const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma1 = theta / delta;
-  // error bound 2 rho^k / (1 + rho^2k) <= 2.5 % (what is left for GMRES is the 2 % noise of matL around its average)
+  // error bound 2 rho^k / (1 + rho^2k) <= 2.5 % (what is left for GMRES is the 2 % noise of matL around its average);
+  // kind 4 leaves 0.8 % and needs the polynomial at 0.25 % to keep its third iteration below the tolerance (degree 12
+  // instead of 8 at dt = 1, h = 0.5: tools/precond_spectrum.py)
+  const bool scaled = c->precond == 4;
   const double kappa = b / a, rh = (std::sqrt(kappa) - 1.0) / (std::sqrt(kappa) + 1.0);
-  int degree = c->cheb_degree_user > 0 ? c->cheb_degree_user : (int)std::ceil(std::log(0.0125) / std::log(rh));
+  int degree = c->cheb_degree_user > 0 ? c->cheb_degree_user : (int)std::ceil(std::log(scaled ? 0.00125 : 0.0125) / std::log(rh));
   degree = degree < 2 ? 2 : (degree > 64 ? 64 : degree);
   float* d = (float*)c->kry_p[0];
   float* z0 = (float*)c->kry_p[1];
@@ -472,18 +604,20 @@ int cheb_abar_inverse(xpic_ctx* c, const double* r, double* out)
     const bool first = i == 1, last = i == degree - 1;
     if (first) XPIC_CALL(halo_fill(c, const_cast<double*>(r), 2));
     else XPIC_CALL(halo_fill_f32(c, z0, 2));
+#define LAUNCH2(F, L, P, S)                                                                                                \
+  hipLaunchKernelGGL((k_cheb_bar<F, L, P, S>), grid, block, 0, c->stream, g, c->abar32, r, r32, z0, d, z1, out, cd, cr, it, nbx, \
+    nby, zc, c->abar_r)
 #define LAUNCH(F, L)                                                                                                        \
   do {                                                                                                                      \
-    if (g.nx % 2 == 0) hipLaunchKernelGGL((k_cheb_bar<F, L, true>), grid, block, 0, c->stream, g, c->abar32, r, r32, z0, d,  \
-      z1, out, cd, cr, it, nbx, nby, zc);                                                                                   \
-    else hipLaunchKernelGGL((k_cheb_bar<F, L, false>), grid, block, 0, c->stream, g, c->abar32, r, r32, z0, d, z1, out, cd,  \
-      cr, it, nbx, nby, zc);                                                                                                \
+    if (g.nx % 2 == 0) { if (scaled) LAUNCH2(F, L, true, true); else LAUNCH2(F, L, true, false); }                          \
+    else { if (scaled) LAUNCH2(F, L, false, true); else LAUNCH2(F, L, false, false); }                                      \
   } while (0)
     if (first && last) LAUNCH(true, true);
     else if (first) LAUNCH(true, false);
     else if (last) LAUNCH(false, true);
     else LAUNCH(false, false);
 #undef LAUNCH
+#undef LAUNCH2
     XPIC_HIP(hipGetLastError());
     rho = rho_new;
     std::swap(z0, z1);
