@@ -467,6 +467,7 @@ def rank_body(args, rank, world, local_rank, job):
         ctx.step()
     ctx.profile_enable(True)
     ctx.profile_reset()
+    ctx.comm_stats(reset=True)
     barrier()
     t0 = time.perf_counter()
     its = 0
@@ -474,6 +475,7 @@ def rank_body(args, rank, world, local_rank, job):
         its += ctx.step()
     barrier()
     elapsed = time.perf_counter() - t0
+    comm = ctx.comm_stats()
     elapsed = job.reduce(elapsed, "max")
     its_total = job.reduce(its, "sum")
 
@@ -555,6 +557,12 @@ def rank_body(args, rank, world, local_rank, job):
         "phase_ms_per_step": {k: v[1] / args.steps for k, v in prof.items() if k != "allreduce"},
         "allreduces_per_step": prof["allreduce"][0] / args.steps,  # reductions that are all-reduces on slabs (counted on 1 GPU too)
         "device_copy_GBps": copy_rate / 1e9 if copy_rate else None,
+        # what ONE rank puts on its links per step (rank 0; every slab sends the same): point-to-point messages to the two
+        # z-neighbours (halos, particle migration, the matL ghost rows) and the all-reduces of the Krylov dot products
+        "comm_messages_per_step": comm[0] / args.steps if world > 1 else 0,
+        "comm_bytes_per_step": comm[1] / args.steps if world > 1 else 0,
+        "comm_allreduces_per_step": comm[2] / args.steps if world > 1 else 0,
+        "comm_allreduce_bytes_per_step": comm[3] / args.steps if world > 1 else 0,
         "cg_matM": cg_line,
     }
 

@@ -181,12 +181,14 @@ int xpic_set_preconditioner(xpic_ctx* ctx, int kind, int degree);
  * spacings, full-chunk body, warp-specialised body} as the next assembly of this context will run. */
 int xpic_set_fill_kernel(xpic_ctx* ctx, int kind);
 int xpic_get_fill_variant(xpic_ctx* ctx, int* out3);
-/* MatMult on a z-slab with neighbours: on = 1 (default) posts the ghost exchange of the operand (VecScatterBegin), applies
+/* MatMult on a z-slab with neighbours: on = 1 posts the ghost exchange of the operand (VecScatterBegin), applies
  * the rows of the interior planes meanwhile and the rows of the boundary planes after it (VecScatterEnd), as PETSc's
  * MPIAIJ MatMult does (the reference's KSPSolve, src/impls/ecsim/simulation.cpp:266); on = 0 exchanges first. Same result.
- * The same switch covers the assembly's ghost-row exchange of matL (posted beside the interior colour launches).
- * Default: on, except over RCCL with more than one rank, where the second-stream path has not yet run on two distinct
- * GPUs: there it is off unless this call (or XPIC_RCCL_OVERLAP=1) turns it on. */
+ * Bit 1 of `on` (on = 3) also posts the assembly's ghost-row exchange of matL behind the boundary colours, beside the
+ * interior colour launches (off by default: measured slower).
+ * Default: 0 -- on the one-GPU self-ring (the only hardware these paths have run on) both overlaps cost more than the
+ * exchanges they hide, and over RCCL with more than one rank the second-stream path has not yet run
+ * on two distinct GPUs.  XPIC_RCCL_OVERLAP=1 turns bit 0 on at xpic_comm_init_rccl. */
 int xpic_set_overlap(xpic_ctx* ctx, int on);
 
 /* timestep_implementation of the context's scheme (basic/simulation.cpp:30-43, ecsim/simulation.cpp:145-155,
@@ -249,6 +251,9 @@ int xpic_comm_init_callbacks(xpic_ctx* ctx, const xpic_comm_callbacks* cb);
 /* number of ranks of the attached communicator: ncclCommCount for RCCL, the z-slab count for callbacks, 1 without one
  * (MPI_Comm_size on PETSC_COMM_WORLD, src/utils/world.cpp:40-42) */
 int xpic_comm_size(xpic_ctx* ctx, int* nranks);
+/* traffic of this rank since the last reset: out4 = {point-to-point messages sent, bytes sent, all-reduces, their payload
+ * bytes} -- what a step puts on the links (the reference's MPI / PetscSF traffic) */
+int xpic_comm_stats(xpic_ctx* ctx, int64_t* out4, int reset);
 
 /* ---- measurement: HIP-event timers around kernel families, on the context's own stream */
 int xpic_profile_enable(xpic_ctx* ctx, int on);

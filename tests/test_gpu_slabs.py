@@ -34,7 +34,7 @@ def test_rccl_transport_on_a_self_ring():
     """The RCCL backend itself (ncclSend/ncclRecv ring, ncclAllReduce on the context's stream, the posted halo exchange
     of the operator applies on the communication stream) on the one GPU we have: a single slab that keeps its ghost
     planes and is its own lower and upper neighbour (geometry.self_ring) must reproduce the ghost-free single-slab
-    run, with and without the overlapped apply."""
+    run, with the overlapped applies and the overlapped matL ghost-row exchange (xpic_set_overlap 3) and without (0)."""
     code = r'''
 import os, sys
 import numpy as np
@@ -59,7 +59,8 @@ def build(force):
     return ctx
 
 a, b, c = build(True), build(False), build(True)
-c.set_overlap(False)  # exchange first, then one launch over all planes
+a.set_overlap(3)      # operator halos posted beside the interior rows AND the matL ghost rows beside the interior colours
+c.set_overlap(0)      # every exchange first, then one launch over all planes
 for t in range(3):
     ia, ib, ic = a.step(), b.step(), c.step()
     assert abs(ia - ib) <= 2, (ia, ib)

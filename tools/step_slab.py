@@ -15,6 +15,8 @@ ppc = int(sys.argv[5]) if len(sys.argv) > 5 else 64
 steps = 5
 ctx = X.Context(scheme, (nx, ny, nz), (0.5,) * 3, 1.0, self_ring=True)
 ctx.comm_init_rccl(X.rccl_unique_id())
+if os.environ.get("XPIC_SLAB_OVERLAP") is not None:  # 0: every exchange blocks the compute stream (A/B against the default)
+    ctx.set_overlap(int(os.environ["XPIC_SLAB_OVERLAP"]))
 s = ctx.add_sort(ppc, 1.0, -1.0, 1.0, capacity=int(ppc * nx * ny * nz * 1.05) + 4096)
 ctx.fill_synthetic(s, ppc, 0.014, seed=1234)
 B = np.zeros(ctx.fshape())
@@ -26,6 +28,7 @@ for _ in range(2):
 ctx.synchronize()
 ctx.profile_enable(True)
 ctx.profile_reset()
+ctx.comm_stats(reset=True)
 import time
 t0 = time.perf_counter()
 its = 0
@@ -39,3 +42,5 @@ prof = {k: ctx.profile_get(k) for k in names}
 print("%s slab %d x %d x %d, %d ppc (self-ring): %.2f ms/step, %.1f iterations/step" % (scheme, nx, ny, nz, ppc, ms, its / steps))
 print("  " + ", ".join("%s %.2f" % (k, v[1] / steps) for k, v in prof.items() if v[1] / steps > 0.05),
       "| all-reduces/step %.1f" % (prof["allreduce"][0] / steps))
+cs = ctx.comm_stats()
+print("  per step on the links: %.1f messages, %.1f MB sent, %.1f all-reduces of %.0f B in all" % (cs[0] / steps, cs[1] / steps / 1e6, cs[2] / steps, cs[3] / steps))

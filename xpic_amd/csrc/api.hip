@@ -144,14 +144,20 @@ static int ecsim_fill_current(xpic_ctx* c)
   XPIC_CALL(vec_set(c, c->field[XPIC_CURRI], 0.0));
   bool first_sort = first_touch;
   XPIC_CALL(halo_fill(c, c->field[XPIC_B], 1)); // DMGlobalToLocal(B) :474
-  for (auto& s : c->sorts) {
+  // the last species with particles completes the ghost rows of matL: its assembly posts their exchange behind its
+  // boundary colours (fields.hip: matL_ghost_rows_post), the neighbours' rows are added when every launch is done
+  int last = -1;
+  for (size_t i = 0; i < c->sorts.size(); ++i)
+    if (c->sorts[i].n > 0) last = (int)i;
+  for (size_t i = 0; i < c->sorts.size(); ++i) {
+    Sort& s = c->sorts[i];
     XPIC_HIP(hipMemsetAsync(s.currI, 0, sizeof(double) * c->nvec, c->stream));
-    XPIC_CALL(ecsim_fill_sort(c, s, c->field[XPIC_B], s.currI, c->matL, first_sort && s.n > 0));
+    XPIC_CALL(ecsim_fill_sort(c, s, c->field[XPIC_B], s.currI, c->matL, first_sort && s.n > 0, (int)i == last && g.G > 0));
     if (s.n > 0) first_sort = false;
     XPIC_CALL(halo_add(c, s.currI, 1));                          // DMLocalToGlobal(ADD) particles.cpp:56
     XPIC_CALL(vec_axpy(c, c->field[XPIC_CURRI], 1.0, s.currI)); // particles.cpp:57
   }
-  XPIC_CALL(matL_exchange_ghost_rows(c));
+  XPIC_CALL(matL_ghost_rows_finish(c)); // (posts first when no species had particles: the cleared rows travel)
   return 0;
 }
 
@@ -367,6 +373,11 @@ int xpic_create(const xpic_geometry* geom, int scheme, xpic_ctx** out)
       c->cheb_degree_M = c->cheb_degree_M_auto = kM < 2 ? 2 : (kM > 48 ? 48 : kM);
     }
     XPIC_CALL(build_ltab(c));
+    if (g.G > 0)
+      for (int i = 0; i < 2; ++i) { // the neighbours' matL ghost rows (3 row planes each): sized with the context
+        XPIC_HIP(hipMalloc(&c->lrow_buf[i], sizeof(double) * 3 * g.lplane()));
+        XPIC_HIP(hipMemsetAsync(c->lrow_buf[i], 0, sizeof(double) * 3 * g.lplane(), c->stream));
+      }
     XPIC_HIP(hipMalloc(&c->fill_err, sizeof(int)));
     XPIC_HIP(hipMemsetAsync(c->fill_err, 0, sizeof(int), c->stream));
     XPIC_CALL(ensure_flexible_workspace(c));
@@ -387,6 +398,7 @@ int xpic_destroy(xpic_ctx* ctx)
   (void)hipFree(ctx->red_partial); (void)hipFree(ctx->red_out); (void)hipHostFree(ctx->red_host);
   (void)hipFree(ctx->scan_tmp);
   (void)hipFree(ctx->abar32); (void)hipFree(ctx->abar_work); (void)hipFree(ctx->abar_r);
+  (void)hipFree(ctx->lrow_buf[0]); (void)hipFree(ctx->lrow_buf[1]);
   for (int i = 0; i < 4; ++i) (void)hipFree(ctx->halo_buf[i]);
   comm_free(ctx);
   for (auto& kv : ctx->prof)
@@ -706,7 +718,8 @@ int xpic_get_fill_variant(xpic_ctx* ctx, int* out3)
 int xpic_set_overlap(xpic_ctx* ctx, int on)
 {
   CTX_CHECK(ctx);
-  ctx->overlap = on != 0;
+  ctx->overlap = (on & 1) != 0;
+  ctx->overlap_lrows = (on & 2) != 0;
   ctx->overlap_explicit = true;
   return 0;
 }

@@ -41,6 +41,8 @@ int comm_ring(xpic_ctx* c, const void* down, size_t ndown, const void* up, size_
 {
   Comm& m = c->comm;
   XPIC_CHECK(m.kind != 0, "comm_ring called on a single-rank context");
+  m.sent_msgs += (ndown ? 1 : 0) + (nup ? 1 : 0);
+  m.sent_bytes += (int64_t)(ndown + nup);
   const int lo = (m.rank - 1 + m.nranks) % m.nranks, hi = (m.rank + 1) % m.nranks;
   if (m.kind == 1) {
     ncclComm_t nc = (ncclComm_t)m.nccl;
@@ -74,6 +76,8 @@ int comm_allreduce_sum(xpic_ctx* c, double* dbuf, int n)
   // every reduction that is an MPI_Allreduce on slabs is counted (on a single slab too): xpic_profile_get("allreduce")
   if (c->profiling) c->prof["allreduce"].launches += 1;
   if (m.kind == 0 || n == 0) return 0;
+  m.allreduces += 1;
+  m.allreduce_bytes += (int64_t)sizeof(double) * n;
   if (m.kind == 1) {
     XPIC_NCCL(ncclAllReduce(dbuf, dbuf, n, ncclDouble, ncclSum, (ncclComm_t)m.nccl, c->stream));
     return 0;
@@ -152,7 +156,12 @@ int xpic_comm_init_rccl(xpic_ctx* ctx, const void* id128)
   XPIC_HIP(hipSetDevice(ctx->geom.device));
   XPIC_NCCL(ncclCommInitRank(&nc, ctx->geom.nranks, id, ctx->geom.rank));
   if (!ctx->comm_stream) {
-    XPIC_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    // highest priority: when workgroup slots free up, the dispatcher serves the exchange's few workgroups before the
+    // next colour launch of the assembly queued behind 512 of its own (at equal priority the RCCL kernels of a posted
+    // exchange did not start before the compute stream ran dry: profiles/r04_trace_overlap_selfring.txt)
+    int least = 0, greatest = 0;
+    XPIC_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    XPIC_HIP(hipStreamCreateWithPriority(&ctx->comm_stream, hipStreamNonBlocking, greatest));
     for (int i = 0; i < 2; ++i) XPIC_HIP(hipEventCreateWithFlags(&ctx->comm_ev[i], hipEventDisableTiming));
   }
   ctx->comm.kind = 1;
@@ -168,6 +177,15 @@ int xpic_comm_init_rccl(xpic_ctx* ctx, const void* id128)
     const char* e = getenv("XPIC_RCCL_OVERLAP");
     ctx->overlap = e && e[0] == '1';
   }
+  return 0;
+}
+
+int xpic_comm_stats(xpic_ctx* ctx, int64_t* out4, int reset)
+{
+  XPIC_CHECK(ctx && out4, "null argument");
+  Comm& m = ctx->comm;
+  out4[0] = m.sent_msgs; out4[1] = m.sent_bytes; out4[2] = m.allreduces; out4[3] = m.allreduce_bytes;
+  if (reset) m.sent_msgs = m.sent_bytes = m.allreduces = m.allreduce_bytes = 0;
   return 0;
 }
 

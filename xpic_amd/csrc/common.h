@@ -151,6 +151,8 @@ struct Comm {
   xpic_comm_callbacks cb{};
   void* host[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t host_bytes = 0;
+  // traffic counters (xpic_comm_stats): point-to-point messages and bytes SENT by this rank, all-reduces and their payload
+  int64_t sent_msgs = 0, sent_bytes = 0, allreduces = 0, allreduce_bytes = 0;
 };
 
 struct ProfileEntry {
@@ -202,12 +204,16 @@ struct xpic_ctx {
   int maxit = 100;
   xpic::Comm comm;
   double* halo_buf[4] = {}; // send down, send up, recv from up, recv from down
+  double* lrow_buf[2] = {nullptr, nullptr}; // matL ghost rows received from the upper / lower neighbour (3 row planes each; slabs)
+  bool lrow_posted = false, lrow_on_comm_stream = false;
   size_t halo_bytes = 0;
   // overlapped operator applies (fields.hip: op_apply_overlapped): RCCL traffic of a posted halo runs on its own stream
   hipStream_t comm_stream = nullptr;
   hipEvent_t comm_ev[2] = {nullptr, nullptr}; // packed (compute -> comm), ghosts in place (comm -> compute)
   bool halo_posted = false;
-  bool overlap = true;
+  bool overlap = false; // operator applies with their halo exchange posted beside the interior rows (xpic_set_overlap bit 0).  Off by
+                        // default since round 4: on a self-ring the split apply costs 1.7 ms of a 28.7 ms slab step more than it hides
+  bool overlap_lrows = false; // the matL ghost-row exchange beside the assembly's interior colours (xpic_set_overlap bit 1)
   bool overlap_explicit = false; // set by xpic_set_overlap: xpic_comm_init_rccl then leaves the choice alone
   bool profiling = false;
   std::map<std::string, xpic::ProfileEntry> prof;
@@ -264,7 +270,9 @@ int field_export(xpic_ctx* c, const double* src_soa, double* dst_aos_host);
 int field_stats_host(xpic_ctx* c, const double* f, double* sumsq, double* mean3);
 int halo_fill(xpic_ctx* c, double* f, int width = 3); // ghost planes <- neighbours' owned planes (no-op when G == 0)
 int halo_add(xpic_ctx* c, double* f, int width);      // owned planes += neighbours' ghost planes (DMLocalToGlobal ADD)
-int matL_exchange_ghost_rows(xpic_ctx* c);
+int matL_exchange_ghost_rows(xpic_ctx* c);  // blocking: post + finish
+int matL_ghost_rows_post(xpic_ctx* c);      // ship this slab's two ghost row planes (on the communication stream when overlapping)
+int matL_ghost_rows_finish(xpic_ctx* c);    // add the neighbours' rows into the first / last owned row plane
 
 // particles.hip
 int sort_alloc(xpic_ctx* c, Sort& s, int64_t cap);
@@ -283,7 +291,7 @@ int scale_velocities(xpic_ctx* c, Sort& s, double lambda);
 int momentum_sums_global(xpic_ctx* c, Sort& s, const double* E, double* out6);
 
 // ecsim.hip
-int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, double* matL, bool first_sort);
+int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, double* matL, bool first_sort, bool post_ghost_rows);
 int build_ltab(xpic_ctx* c);
 void ecsim_fill_variant(const xpic_ctx* c, int* p2, int* fx, int* ws);
 

@@ -208,7 +208,7 @@ template <bool P2, bool FX>
 __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, SortDev s, const double* __restrict__ B,
   double* currI, double* matL, const unsigned short* __restrict__ dtab, const int* __restrict__ linetab, const int* __restrict__ cowr, double q, double m,
   double mpw, int cy0, int cystep, int ncy, int cz0, int czstep, int my_order, int ncol_y, int per_y, int per_z, int first_sort,
-  int alias_rows)
+  int alias_rows, unsigned long long zord)
 {
   const int cy = cy0 + (int)(blockIdx.x % ncy) * cystep;
   const int cz = cz0 + (int)(blockIdx.x / ncy) * czstep;
@@ -261,7 +261,8 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
       : currI + (ld & 3) * g.cstride + g.node(0, ry, g.wz(rz));
     // First touch: if no other pencil that also writes this matL line runs in an EARLIER launch, this workgroup
     // is the first writer of the step and stores instead of read-modify-write (no memset of matL, half the reads).
-    // Co-writers sit at pencil offsets (-dy', -dz') listed in cowr[line]; launch order = cz colour * ncol_y + cy colour.
+    // Co-writers sit at pencil offsets (-dy', -dz') listed in cowr[line]; launch order = (position of the cz colour in the
+    // launch sequence, zord: 4 bits per colour) * ncol_y + cy colour.
     bool first = first_sort && line < kMatLines;
     if (first) {
       const int bodyy = g.ny - g.ny % per_y, bodyz = g.nzl - g.nzl % per_z;
@@ -275,7 +276,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
         else if (pz < 0 || pz >= g.nzl) continue; // no such local pencil: the neighbour rank's rows are its own
         const int ca = py < bodyy ? py % per_y : per_y + (py - bodyy);
         const int cb = g.G == 0 ? (pz < bodyz ? pz % per_z : per_z + (pz - bodyz)) : pz % per_z;
-        if (cb * ncol_y + ca < my_order) first = false;
+        if ((int)((zord >> (4 * cb)) & 15u) * ncol_y + ca < my_order) first = false; // zord: launch position of z colour cb
       }
     }
     lbase[mm] = (uintptr_t)base | (first ? 1u : 0u);
@@ -916,7 +917,7 @@ template <bool P2>
 __global__ void __launch_bounds__(kWsThreads, 1) k_ecsim_fill_ws(GridDev g, SortDev s, const double* __restrict__ B,
   double* currI, double* matL, const unsigned short* __restrict__ dtab, const int* __restrict__ linetab, const int* __restrict__ cowr, double q, double m,
   double mpw, int cy0, int cystep, int ncy, int cz0, int czstep, int my_order, int ncol_y, int per_y, int per_z, int first_sort,
-  int* __restrict__ err)
+  int* __restrict__ err, unsigned long long zord)
 {
   const int cy = cy0 + (int)(blockIdx.x % ncy) * cystep;
   const int cz = cz0 + (int)(blockIdx.x / ncy) * czstep;
@@ -1071,7 +1072,7 @@ __global__ void __launch_bounds__(kWsThreads, 1) k_ecsim_fill_ws(GridDev g, Sort
           else if (pz < 0 || pz >= g.nzl) continue;
           const int ca = py < bodyy ? py % per_y : per_y + (py - bodyy);
           const int cb = g.G == 0 ? (pz < bodyz ? pz % per_z : per_z + (pz - bodyz)) : pz % per_z;
-          if (cb * ncol_y + ca < my_order) first = false;
+          if ((int)((zord >> (4 * cb)) & 15u) * ncol_y + ca < my_order) first = false; // zord: launch position of z colour cb
         }
       }
       lbase[mm] = (uintptr_t)base | (first ? 1u : 0u);
@@ -1503,7 +1504,7 @@ void ecsim_fill_variant(const xpic_ctx* c, int* p2, int* fx, int* ws)
   *ws = (*fx && c->fill_kernel == 1) ? 1 : 0;
 }
 
-int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, double* matL, bool first_sort)
+int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, double* matL, bool first_sort, bool post_ghost_rows)
 {
   if (s.n == 0) return 0;
   const GridDev& g = c->g;
@@ -1516,7 +1517,26 @@ int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, d
   colour_periods(g, (ws ? 1 : 2) * c->num_cus, &per_y, &per_z); // workgroup slots of the chip: the 8-wave kernel owns a CU
   const int ncol_y = per_y + g.ny % per_y, ncol_z = g.G == 0 ? per_z + g.nzl % per_z : per_z;
   if (ws) XPIC_HIP(hipMemsetAsync(c->fill_err, 0, sizeof(int), c->stream));
-  for (int b = 0; b < ncol_z; ++b)
+  // Launch sequence of the z colours.  On a slab the colours of the first and the last plane go first: their pencils are
+  // the only ones that write the two ghost row planes of matL, which the neighbours are waiting for -- with
+  // `post_ghost_rows` (the last species) the exchange is posted right behind them and travels beside the other colours.
+  XPIC_CHECK(ncol_z <= 16, "too many z colours for the launch-order word");
+  int seq[16], nseq = 0;
+  if (g.G > 0) {
+    const int b0 = 0, b1 = (g.nzl - 1) % per_z;
+    seq[nseq++] = b0;
+    if (b1 != b0) seq[nseq++] = b1;
+    for (int b = 0; b < ncol_z; ++b)
+      if (b != b0 && b != b1) seq[nseq++] = b;
+  }
+  else
+    for (int b = 0; b < ncol_z; ++b) seq[nseq++] = b;
+  unsigned long long zord = 0;
+  for (int pos = 0; pos < nseq; ++pos) zord |= (unsigned long long)pos << (4 * seq[pos]);
+  const int nboundary = g.G > 0 ? ((g.nzl - 1) % per_z != 0 ? 2 : 1) : 0;
+  for (int pos = 0; pos < nseq; ++pos) {
+    const int b = seq[pos];
+    if (post_ghost_rows && pos == nboundary) XPIC_CALL(matL_ghost_rows_post(c));
     for (int a = 0; a < ncol_y; ++a) {
       int cy0, cys, ncy, cz0, czs, ncz;
       colour_class(g.ny, per_y, a, &cy0, &cys, &ncy);
@@ -1530,17 +1550,19 @@ int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, d
       if (ws) {
         auto kern = g.pow2 ? k_ecsim_fill_ws<true> : k_ecsim_fill_ws<false>;
         hipLaunchKernelGGL(kern, dim3((unsigned)(ncy * ncz)), dim3(kWsThreads), 0, c->stream, g, s.d, B, currI_sort, matL, dtab,
-          c->ltab, c->ltab + kLines, s.par.q, s.par.m, s.par.n / (double)s.par.Np, cy0, cys, ncy, cz0, czs, b * ncol_y + a, ncol_y,
-          per_y, per_z, first_sort ? 1 : 0, c->fill_err);
+          c->ltab, c->ltab + kLines, s.par.q, s.par.m, s.par.n / (double)s.par.Np, cy0, cys, ncy, cz0, czs, pos * ncol_y + a, ncol_y,
+          per_y, per_z, first_sort ? 1 : 0, c->fill_err, zord);
         continue;
       }
       auto kern = g.pow2 ? (fx ? k_ecsim_fill<true, true> : k_ecsim_fill<true, false>)
                          : (fx ? k_ecsim_fill<false, true> : k_ecsim_fill<false, false>);
       hipLaunchKernelGGL(kern, dim3((unsigned)(ncy * ncz)), dim3(kThreads), 0, c->stream, g, s.d, B,
         currI_sort, matL, dtab, c->ltab, c->ltab + kLines, s.par.q, s.par.m,
-        s.par.n / (double)s.par.Np, cy0, cys, ncy, cz0, czs, b * ncol_y + a, ncol_y, per_y, per_z, first_sort && !alias ? 1 : 0,
-        alias ? 1 : 0);
+        s.par.n / (double)s.par.Np, cy0, cys, ncy, cz0, czs, pos * ncol_y + a, ncol_y, per_y, per_z, first_sort && !alias ? 1 : 0,
+        alias ? 1 : 0, zord);
     }
+  }
+  if (post_ghost_rows && nseq <= nboundary) XPIC_CALL(matL_ghost_rows_post(c)); // (a slab whose every colour is a boundary colour)
   XPIC_HIP(hipGetLastError());
   if (ws) {
     // the pipeline's bounded waits: a wave that gave up has left the matrix incomplete -- fail the assembly loudly

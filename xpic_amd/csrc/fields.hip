@@ -1008,24 +1008,74 @@ int halo_add(xpic_ctx* c, double* f, int width)
 
 // matL rows of the first ghost plane below / above the slab were filled by cells of this rank but belong to the
 // neighbours (MatSetValuesCOO ships such entries to the owner, src/impls/ecsim/simulation.cpp:366): send and add.
-int matL_exchange_ghost_rows(xpic_ctx* c)
+// 3 x lplane() doubles per neighbour (195 MB on a 256 x 256 slab): the only large message of a step.  It is split in
+// two: _post ships the ghost planes as soon as the assembly's boundary colours have finished them (ecsim.hip launches
+// those first) -- with RCCL and xpic_set_overlap on a second stream, beside the interior colours -- and _finish adds
+// what arrived into the first / last owned row plane once every local launch is done.
+int matL_ghost_rows_post(xpic_ctx* c)
 {
   const GridDev& g = c->g;
   if (g.G == 0) return 0;
+  XPIC_CHECK(c->lrow_buf[0] && c->lrow_buf[1], "matL ghost-row buffers missing");
+  XPIC_CHECK(!c->lrow_posted, "matL ghost rows posted twice");
   Timed t(c, "matL_ghost_rows");
-  const long per = g.lplane(); // one z-plane of one component
+  const long per = g.lplane(); // one row plane of one component
   const size_t bytes = sizeof(double) * per;
-  XPIC_CALL(ensure_halo_buf(c, bytes));
+  const int nzp = g.nzl + 2;
+  // Beside the interior colours only on request (xpic_set_overlap bit 1).  Measured on a self-ring, 256 x 256 x 32 slab
+  // (profiles/r04_step_slab_selfring.txt, r04_trace_overlap_selfring.txt): with the exchange on the high-priority second
+  // stream its RCCL kernels do run beside k_ecsim_fill (0.85 of their 0.86 ms each) and the step takes 3.6 ms LONGER --
+  // a colour launch is sized to fill every workgroup slot of the chip exactly once, so each slot an RCCL workgroup holds
+  // sends one assembly workgroup into a second round, which doubles the launch.  The blocking exchange costs its own
+  // duration and nothing else.
+  const bool side = c->overlap_lrows && c->comm.kind == 1 && c->comm_stream;
+  hipStream_t compute = c->stream;
+  if (side) {
+    XPIC_HIP(hipEventRecord(c->comm_ev[0], c->stream));
+    XPIC_HIP(hipStreamWaitEvent(c->comm_stream, c->comm_ev[0], 0));
+    c->stream = c->comm_stream; // comm_ring enqueues on the context's stream
+  }
+  int rc = 0;
+  for (int c1 = 0; c1 < 3 && rc == 0; ++c1) {
+    double* base = c->matL + (long)c1 * nzp * per;
+    // the ghost plane BELOW the slab holds rows of the z component only: a cell's X and Y rows sit on its own two node
+    // planes (lstencil.h: block_node_offset), never one below -- those two planes are all zeros and stay at home
+    const size_t down = c1 == 2 ? bytes : 0;
+    rc = comm_ring(c, base, down, base + (long)(nzp - 1) * per, bytes, c->lrow_buf[0] + (long)c1 * per, down,
+      c->lrow_buf[1] + (long)c1 * per, bytes);
+  }
+  c->stream = compute;
+  XPIC_CALL(rc);
+  if (side) XPIC_HIP(hipEventRecord(c->comm_ev[1], c->comm_stream));
+  c->lrow_posted = true;
+  c->lrow_on_comm_stream = side;
+  return 0;
+}
+
+int matL_ghost_rows_finish(xpic_ctx* c)
+{
+  const GridDev& g = c->g;
+  if (g.G == 0) return 0;
+  if (!c->lrow_posted) XPIC_CALL(matL_ghost_rows_post(c));
+  Timed t(c, "matL_ghost_rows");
+  if (c->lrow_on_comm_stream) XPIC_HIP(hipStreamWaitEvent(c->stream, c->comm_ev[1], 0));
+  c->lrow_posted = false;
+  const long per = g.lplane();
   const int nzp = g.nzl + 2;
   for (int c1 = 0; c1 < 3; ++c1) {
     double* base = c->matL + (long)c1 * nzp * per;
-    XPIC_CALL(comm_ring(c, base, bytes, base + (long)(nzp - 1) * per, bytes, c->halo_buf[2], bytes, c->halo_buf[3], bytes));
-    // upper neighbour's ghost-below rows are my top owned plane; lower neighbour's ghost-above rows my bottom plane
-    hipLaunchKernelGGL(k_add_into, dim3(plane_grid(per)), dim3(kBlock), 0, c->stream, base + (long)g.nzl * per, c->halo_buf[2], per);
-    hipLaunchKernelGGL(k_add_into, dim3(plane_grid(per)), dim3(kBlock), 0, c->stream, base + per, c->halo_buf[3], per);
-    XPIC_HIP(hipGetLastError());
+    // upper neighbour's ghost-below rows (z component only) are my top owned plane; lower neighbour's ghost-above rows my bottom plane
+    if (c1 == 2) hipLaunchKernelGGL(k_add_into, dim3(plane_grid(per)), dim3(kBlock), 0, c->stream, base + (long)g.nzl * per, c->lrow_buf[0] + (long)c1 * per, per);
+    hipLaunchKernelGGL(k_add_into, dim3(plane_grid(per)), dim3(kBlock), 0, c->stream, base + per, c->lrow_buf[1] + (long)c1 * per, per);
   }
+  XPIC_HIP(hipGetLastError());
   return 0;
+}
+
+int matL_exchange_ghost_rows(xpic_ctx* c)
+{
+  XPIC_CALL(matL_ghost_rows_post(c));
+  return matL_ghost_rows_finish(c);
 }
 
 }  // namespace xpic

@@ -16,6 +16,7 @@
 // copies of its vectors with fp32 arithmetic, the stopping rule stays the true fp64 residual.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 #include <vector>
@@ -28,6 +29,9 @@ namespace xpic {
 namespace {
 
 constexpr int kB = 256;
+#ifndef XPIC_CHEB_MIN_ZC
+#define XPIC_CHEB_MIN_ZC 8 // planes per z-chunk of k_cheb_bar at least (a chunk loads 5 more)
+#endif
 #ifndef BAR_SCHED_SCALED
 #define BAR_SCHED_SCALED 1 // kind 4's body (12 more live values) gets one scheduling region per (c2, dz) group: without it 2.2 KB of spills per lane
 #endif
@@ -591,10 +595,11 @@ int cheb_abar_inverse(xpic_ctx* c, const double* r, double* out)
   float* z1 = (float*)c->kry_p[2];
   float* r32 = (float*)c->kry_t;
   const int nbx = (g.nx + kTX - 1) / kTX, nby = (g.ny + kTY - 1) / kTY;
-  // z-chunks: enough workgroups for two per CU, chunks of at least 8 planes (4 halo planes are loaded per chunk)
-  int nzc = (int)((2 * 256 + (long)nbx * nby - 1) / ((long)nbx * nby));
+  // z-chunks: enough workgroups for two per CU, chunks of at least 8 planes (5 more planes are loaded per chunk)
+  int nzc = (int)((2 * c->num_cus + (long)nbx * nby - 1) / ((long)nbx * nby));
   int zc = (g.nzl + nzc - 1) / nzc;
-  if (zc < 8) zc = g.nzl < 8 ? g.nzl : 8;
+  if (zc < XPIC_CHEB_MIN_ZC) zc = g.nzl < XPIC_CHEB_MIN_ZC ? g.nzl : XPIC_CHEB_MIN_ZC;
+  if (const char* e = getenv("XPIC_CHEB_ZC")) { const int v = atoi(e); if (v > 0) zc = v < g.nzl ? v : g.nzl; } // (measurements)
   nzc = (g.nzl + zc - 1) / zc;
   const dim3 grid((unsigned)(nbx * nby * nzc)), block(kB);
   double rho = 1.0 / sigma1;
