@@ -81,6 +81,16 @@ extern "C" int xpic_debug_fill_stamps(double* out, int reset)
 #ifndef FILL_NO_READ2
 #define FILL_NO_READ2 0
 #endif
+// round 4, measured and left off (256^3 x 64, per assembly, A/B/A/B in one call: 96.1 as is): FILL_PEEL -- full K steps
+// without the zero-slot compare / select, the partial step peeled: 99.2 (the octant bodies double; the instruction stream,
+// not its count, pays); FILL_DTAB32 -- the merge's offsets as 32-bit words, nine loads and no unpacking: 97.2; both: 100.5;
+// FILL_NO_READ2 -- ds_read_b64 in place of the paired ds_read2_b64 operand reads (half the LDS cycles on paper): 96.7
+#ifndef FILL_PEEL
+#define FILL_PEEL 0
+#endif
+#ifndef FILL_DTAB32
+#define FILL_DTAB32 0
+#endif
 #ifndef FILL_DRAIN
 #define FILL_DRAIN 3 // explicit waits for global reads where they cost nothing (see the comment in front of the flush)
 #endif
@@ -492,8 +502,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
           // and "is there a particle for my row" is one compare of the lane's slot address with the end of the segment
           LdsBytes spr = (LdsBytes)(const char*)(seg + kk * kPitch);
           const LdsBytes seg_end = (LdsBytes)(const char*)(seg + no * kPitch);
-          for (int t = 0; t < nst; ++t, spr += 4 * kPitch * 8) {
-            const LdsBytes sb = spr < seg_end ? spr : (LdsBytes)(const char*)zslot;
+          auto kstep = [&](const LdsBytes sb) {
             const LdsDouble* sp = (const LdsDouble*)sb;
             const LdsDouble* spA = (const LdsDouble*)(sb + offA8);
             const LdsDouble* spB = (const LdsDouble*)(sb + offB8);
@@ -544,7 +553,17 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
                   __builtin_amdgcn_mfma_f64_4x4x4f64(a[c1], bm[c1 * 3 + c2], acc[acc_main(c1, c2, o)], 0, 0, 0);
             acc[acc_cur1(o)] = __builtin_amdgcn_mfma_f64_4x4x4f64(ai1, bi1, acc[acc_cur1(o)], 0, 0, 0);
             acc[acc_cur2(o)] = __builtin_amdgcn_mfma_f64_4x4x4f64(ai2, bi2, acc[acc_cur2(o)], 0, 0, 0);
-          }
+          };
+#if FILL_PEEL
+          // full steps read their four slots unconditionally; only a cell's last pass can end an octant on a partial step,
+          // whose missing rows read the zero slot (peeled: the compare and the select of every step were 3 of its 17
+          // vector instructions)
+          const int nfull = no >> 2;
+          for (int t = 0; t < nfull; ++t, spr += 4 * kPitch * 8) kstep(spr);
+          if (nst > nfull) kstep(spr < seg_end ? spr : (LdsBytes)(const char*)zslot);
+#else
+          for (int t = 0; t < nst; ++t, spr += 4 * kPitch * 8) kstep(spr < seg_end ? spr : (LdsBytes)(const char*)zslot);
+#endif
         }
 #endif
 #if FILL_PRIO || FILL_PRIO1
@@ -619,7 +638,17 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     unsigned wdst[kAcc]; // requested now, used after the window is seeded
 #pragma unroll
     for (int e = 0; e < kAcc; ++e) wdst[e] = 0;
-    if (FILL_LEAN_LDS) {
+    if (FILL_LEAN_LDS && FILL_DTAB32) {
+      // the lane's 36 offsets as 32-bit words (a second copy of the table behind the 16-bit one): nine 16-byte loads and
+      // no unpacking (the shifts and masks of the packed form were ~50 vector instructions per merge)
+      const uint4* q = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned*>(dtab + 64 * kDtabPitch) + lane * kAcc);
+#pragma unroll
+      for (int k = 0; k < kAcc / 4; ++k) {
+        const uint4 w4 = q[k];
+        wdst[4 * k] = w4.x; wdst[4 * k + 1] = w4.y; wdst[4 * k + 2] = w4.z; wdst[4 * k + 3] = w4.w;
+      }
+    }
+    else if (FILL_LEAN_LDS) {
       // the lane's 36 offsets are 72 contiguous bytes of the table (transposed on the host): five 16-byte loads
       const uint4* q = reinterpret_cast<const uint4*>(dtab + lane * kDtabPitch);
 #pragma unroll
@@ -1435,6 +1464,14 @@ int build_ltab(xpic_ctx* c)
     std::vector<unsigned short> t(64 * kDtabPitch, 0);
     for (int e = 0; e < kAcc; ++e)
       for (int lane = 0; lane < 64; ++lane) t[lane * kDtabPitch + e] = (unsigned short)(8 * dtab[e * 64 + lane]);
+    // the same offsets as 32-bit words, [lane][kAcc], behind the 16-bit table (FILL_DTAB32)
+    t.resize(64 * kDtabPitch + 2 * 64 * kAcc, 0);
+    for (int lane = 0; lane < 64; ++lane)
+      for (int e = 0; e < kAcc; ++e) {
+        const unsigned v = 8u * dtab[e * 64 + lane];
+        t[64 * kDtabPitch + 2 * (lane * kAcc + e)] = (unsigned short)(v & 0xffffu);
+        t[64 * kDtabPitch + 2 * (lane * kAcc + e) + 1] = (unsigned short)(v >> 16);
+      }
     dtab.swap(t);
   }
   const size_t total = linetab.size() + cowr.size() + (dtab.size() + 1) / 2;
