@@ -37,9 +37,13 @@ def problem(scheme, n, d, seed):
     return parts, E, B, B0
 
 
+RCCL = os.environ.get("XPIC_SLAB_TRANSPORT") == "rccl"  # one GPU per rank, RCCL over xGMI (needs >= nranks devices)
+
+
 def build(scheme, n, d, dt, rank, nranks, seed):
     parts, E, B, B0 = problem(scheme, n, d, seed)
-    ctx = X.Context(scheme, n, d, dt, device=0, rank=rank, nranks=nranks)
+    dev = int(os.environ.get("LOCAL_RANK", "0")) if RCCL and nranks > 1 else 0
+    ctx = X.Context(scheme, n, d, dt, device=dev, rank=rank, nranks=nranks)
     N = n[0] * n[1] * n[2]
     for (Np, dens, q, m), pts in zip(SORTS, parts):
         s = ctx.add_sort(Np, dens, q, m, capacity=3 * 8 * N)
@@ -82,7 +86,13 @@ def main():
     n, d = (12, 10, nzl * nranks), (0.5, 0.4, 0.25)
     dt = 0.2 if scheme != "ecsim" else 0.8
     ctx = build(scheme, n, d, dt, rank, nranks, seed=42)
-    GlooRing().attach(ctx)
+    if RCCL:
+        from xpic_amd.parallel import init_rccl
+
+        init_rccl(ctx, device=int(os.environ.get("LOCAL_RANK", "0")))
+        ctx.set_overlap(int(os.environ.get("XPIC_SLAB_OVERLAP", "0")))  # 0 blocking, 1 operator halos, 3 + matL ghost rows
+    else:
+        GlooRing().attach(ctx)
     counts0 = [ctx.count(s) for s in range(2)]
     nsteps = 3
     its = [ctx.step() for _ in range(nsteps)]

@@ -30,6 +30,27 @@ def test_slabs_reproduce_single_slab_and_oracle(scheme, world, nzl):
     assert out.stdout.count(" ok") == world
 
 
+@pytest.mark.parametrize("overlap", [0, 3])
+@pytest.mark.parametrize("scheme", ["ecsim", "ecsimcorr"])
+def test_slabs_over_rccl_on_distinct_gpus(scheme, overlap):
+    """The production transport on two DISTINCT GPUs (one process per GPU, RCCL over xGMI): blocking exchanges and the
+    second-stream forms (operator halos beside the interior rows, matL ghost rows beside the interior colours, with the
+    all-reduces of the same communicator on the compute stream) must both reproduce the single-slab run and the oracle.
+    Skipped on a one-GPU box -- which is every box this suite has run on so far: the RCCL path has only ever seen a
+    self-ring."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2",
+               XPIC_SLAB_TRANSPORT="rccl", XPIC_SLAB_OVERLAP=str(overlap))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29733", os.path.join(ROOT, "tests", "mp_slab_worker.py"), scheme, "12"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
+    assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-4000:]
+    assert out.stdout.count(" ok") == 2
+
+
 def test_rccl_transport_on_a_self_ring():
     """The RCCL backend itself (ncclSend/ncclRecv ring, ncclAllReduce on the context's stream, the posted halo exchange
     of the operator applies on the communication stream) on the one GPU we have: a single slab that keeps its ghost
