@@ -51,6 +51,8 @@ def parse_args(argv=None):
                     help="skip the device copy probe (1 GiB device-to-device copies: the achievable copy rate of THIS box, "
                          "SURVEY 8(d); on by default, outside the timed region)")
     ap.add_argument("--plain-gmres", action="store_true", help="unpreconditioned GMRES(30), as the CPU oracle runs")
+    ap.add_argument("--fused-rebin", type=int, default=None, choices=[0, 1],
+                    help="ecsim: 1 the re-binning's scatter deferred into the assembly's particle loads, 0 scatter first (default: the library's)")
     ap.add_argument("--fill-kernel", type=int, default=None, choices=[0, 1],
                     help="mass-matrix assembly: 1 warp-specialised kernel, 0 the classic 4-wave kernel (default: the library's)")
     ap.add_argument("--cheb-degree", type=int, default=0, help="override the Chebyshev preconditioner degree (experiments)")
@@ -458,6 +460,8 @@ def rank_body(args, rank, world, local_rank, job):
 
     if args.scheme != "basic" and args.fill_kernel is not None:
         ctx.set_fill_kernel(args.fill_kernel)
+    if args.scheme == "ecsim" and args.fused_rebin is not None:
+        ctx.set_fused_rebin(args.fused_rebin)
     if args.plain_gmres and args.scheme != "basic":
         ctx.set_preconditioner(0)
     elif (args.cheb_degree > 0 or args.precond is not None) and args.scheme != "basic":
@@ -501,7 +505,7 @@ def rank_body(args, rank, world, local_rank, job):
                    "iters_per_s": cg_its / dt_cg, "algorithmic_GBps": 11 * 24 * N * cg_its / dt_cg / 1e9}
 
     prof = {k: ctx.profile_get(k) for k in ("matA_apply", "solve_matA", "fill_current", "move_bin", "scatter",
-                                            "second_push", "mdot", "maxpy", "matL_zero", "scan", "rot_apply",
+                                            "second_push", "mdot", "maxpy", "matL_zero", "scan", "index", "rot_apply",
                                             "halo", "migrate", "matL_ghost_rows", "basic_push", "corr_first_push", "precond_setup",
                                             "corr_second_push", "solve_matM", "precond", "matL_apply", "rebin",
                                             "allreduce")}
@@ -637,7 +641,7 @@ def rank_body(args, rank, world, local_rank, job):
         }
         # algorithmic HBM bytes per particle and step of the ecsim particle phases: first_push 72 +
         # assembly 48 (+ 2952 B of matL per cell) + second_push 72 + re-binning 96
-        ms_part = sum(prof[k][1] for k in ("fill_current", "second_push", "move_bin", "scatter", "scan", "rebin")) / args.steps
+        ms_part = sum(prof[k][1] for k in ("fill_current", "second_push", "move_bin", "scatter", "scan", "index", "rebin")) / args.steps
         bpp = 72 + 48 + 72 + 96 + 2952.0 / args.ppc
         gbs = bpp * count_local / (ms_part * 1e-3) / 1e9
         line["roofline_particles"] = {

@@ -180,6 +180,11 @@ int xpic_set_preconditioner(xpic_ctx* ctx, int kind, int degree);
  * (all grids).  Same matrix up to the summation order of a cell's neighbours.  xpic_get_fill_variant: out3 = {power-of-two
  * spacings, full-chunk body, warp-specialised body} as the next assembly of this context will run. */
 int xpic_set_fill_kernel(xpic_ctx* ctx, int kind);
+/* The ecsim step's first_push + update_cells (ecsim/simulation.cpp:174-189) re-bins the particles; on = 1 (default)
+ * defers the scatter pass of that re-binning into the assembly that follows: the assembly reads every particle anyway,
+ * so it gathers the records through a source index, applies the move and the periodic wrap and writes the sorted copy on
+ * its way.  Same particles, same order, same arithmetic as on = 0 (scatter first).  Single slab, classic assembly kernel. */
+int xpic_set_fused_rebin(xpic_ctx* ctx, int on);
 int xpic_get_fill_variant(xpic_ctx* ctx, int* out3);
 /* MatMult on a z-slab with neighbours: on = 1 posts the ghost exchange of the operand (VecScatterBegin), applies
  * the rows of the interior planes meanwhile and the rows of the boundary planes after it (VecScatterEnd), as PETSc's

@@ -37,7 +37,7 @@ for _ in range(steps):
 ctx.synchronize()
 ms = (time.perf_counter() - t0) / steps * 1e3
 names = ("fill_current", "solve_matA", "solve_matM", "matA_apply", "precond", "scatter", "second_push", "move_bin", "halo",
-         "migrate", "matL_ghost_rows", "matL_zero", "precond_setup", "rot_apply", "mdot", "maxpy", "corr_first_push", "corr_second_push", "matL_apply", "scan", "allreduce")
+         "migrate", "index", "matL_ghost_rows", "matL_zero", "precond_setup", "rot_apply", "mdot", "maxpy", "corr_first_push", "corr_second_push", "matL_apply", "scan", "allreduce")
 prof = {k: ctx.profile_get(k) for k in names}
 print("%s slab %d x %d x %d, %d ppc (self-ring): %.2f ms/step, %.1f iterations/step" % (scheme, nx, ny, nz, ppc, ms, its / steps))
 print("  " + ", ".join("%s %.2f" % (k, v[1] / steps) for k, v in prof.items() if v[1] / steps > 0.05),

@@ -27,7 +27,7 @@ SYMBOLS = [
     "xpic_matL_apply", "xpic_matA_apply", "xpic_matL_get", "xpic_lstencil_decode", "xpic_ecsim_first_push",
     "xpic_update_cells", "xpic_ecsim_fill_current", "xpic_ecsim_second_push", "xpic_basic_push",
     "xpic_ecsimcorr_first_push", "xpic_ecsimcorr_second_push", "xpic_ecsimcorr_final_update",
-    "xpic_calculate_energy", "xpic_ecsimcorr_scalars", "xpic_solve", "xpic_set_tolerances", "xpic_set_preconditioner", "xpic_set_overlap", "xpic_comm_stats", "xpic_set_fill_kernel", "xpic_get_fill_variant", "xpic_step",
+    "xpic_calculate_energy", "xpic_ecsimcorr_scalars", "xpic_solve", "xpic_set_tolerances", "xpic_set_preconditioner", "xpic_set_overlap", "xpic_comm_stats", "xpic_set_fill_kernel", "xpic_set_fused_rebin", "xpic_get_fill_variant", "xpic_step",
     "xpic_energy", "xpic_momentum", "xpic_charge_density", "xpic_moment_density", "xpic_cell_traversal", "xpic_implicit_esirkepov_interpolate",
     "xpic_implicit_esirkepov_decompose", "xpic_charge_collect", "xpic_charge_columns", "xpic_comm_rccl_unique_id", "xpic_comm_init_rccl", "xpic_comm_init_callbacks", "xpic_comm_size",
     "xpic_profile_enable", "xpic_profile_reset", "xpic_profile_get", "xpic_probe_copy_bandwidth",
@@ -319,6 +319,10 @@ class Context:
     def set_fill_kernel(self, kind):
         """0: classic 4-wave assembly kernel; 1 (default): warp-specialised 8-wave kernel where the grid allows"""
         self._ck(self.L.xpic_set_fill_kernel(self.h, int(kind)))
+
+    def set_fused_rebin(self, on):
+        """ecsim step: 1 (default) the re-binning's scatter is deferred into the assembly's particle loads, 0 scatter first"""
+        self._ck(self.L.xpic_set_fused_rebin(self.h, int(on)))
 
     def fill_variant(self):
         """(power-of-two spacings, full-chunk body, warp-specialised body) of the next assembly"""

@@ -173,7 +173,8 @@ static int ecsim_final_update(xpic_ctx* c)
 // ecsim::Simulation::timestep_implementation (src/impls/ecsim/simulation.cpp:145-253)
 static int step_ecsim(xpic_ctx* c, int* its)
 {
-  for (auto& s : c->sorts) XPIC_CALL(sort_rebin(c, s, c->g.dt, true)); // first_push + update_cells :174-189
+  // first_push + update_cells :174-189 (the scatter of the re-binning deferred into the assembly's particle loads)
+  for (auto& s : c->sorts) XPIC_CALL(sort_rebin(c, s, c->g.dt, true, c->fused_rebin));
   XPIC_CALL(ecsim_fill_current(c));
   XPIC_CALL(advance_fields(c, XPIC_OP_MATA_GMRES, c->field[XPIC_CURRI], c->field[XPIC_EP], its)); // :191-210
   XPIC_CALL(halo_fill(c, c->field[XPIC_EP]));
@@ -697,6 +698,13 @@ int xpic_set_preconditioner(xpic_ctx* ctx, int kind, int degree)
   if (degree > 0) ctx->cheb_degree = ctx->cheb_degree_M = ctx->cheb_degree_user;
   else { ctx->cheb_degree = ctx->cheb_degree_auto; ctx->cheb_degree_M = ctx->cheb_degree_M_auto; } // back to the automatic choice
   return ensure_flexible_workspace(ctx);
+}
+
+int xpic_set_fused_rebin(xpic_ctx* ctx, int on)
+{
+  CTX_CHECK(ctx);
+  ctx->fused_rebin = on != 0;
+  return 0;
 }
 
 int xpic_set_fill_kernel(xpic_ctx* ctx, int kind)

@@ -22,6 +22,9 @@
 #else
 #define XPIC_TU_EXPERIMENT 0
 #endif
+#ifndef XPIC_DEFAULT_FUSED_REBIN
+#define XPIC_DEFAULT_FUSED_REBIN 1
+#endif
 #ifndef XPIC_DEFAULT_PRECOND
 #define XPIC_DEFAULT_PRECOND 3 // 3: polynomial in matM + <matL>; 4: its rows scaled by the local density (precond.hip: 3x the
 // convergence rate, but at 256^3 x 64 its third residual is 1.17e-7 |b| against the tolerance's 1e-7: still 4 iterations, each dearer)
@@ -121,6 +124,7 @@ struct SortDev {
   int* rank;      // arrival rank of the particle inside its new cell
   int* cell_count;
   int* cell_start; // [ncell+1 (+ kCellStartPad readable)] exclusive prefix of cell_count
+  int* src;        // deferred scatter: source index (old order) of the particle that belongs in slot d of the new order
 };
 
 struct Sort {
@@ -129,6 +133,12 @@ struct Sort {
   int64_t n = 0;
   // cell[], rank[], cell_count (and the migration buffers) already hold the binning of r + v * prebinned_step
   bool prebinned = false;
+  // Deferred scatter (sort_rebin(.., defer = true)): cell_start / src describe the NEW order while r, v still hold the OLD,
+  // un-moved records; the mass-matrix assembly reads them through src, applies the move and writes the sorted records into
+  // r2, v2 on its way (ecsim.hip) -- the scatter pass of the re-binning is gone.  Everything else calls sort_materialize first.
+  bool deferred = false, def_wrap = false;
+  double def_step = 0;
+  int64_t def_n_old = 0;
   double prebinned_step = 0;
   int64_t prebinned_n = 0;
   SortDev d{};
@@ -174,6 +184,7 @@ struct xpic_ctx {
   double* matL = nullptr; // [c1][nzl][ny][123][nx]
   int* ltab = nullptr;    // [1296] block entry -> packed (k, c1, o1) descriptor
   int* fill_err = nullptr; // set by k_ecsim_fill_ws when one of its bounded waits gave up
+  bool fused_rebin = XPIC_DEFAULT_FUSED_REBIN != 0; // ecsim step: the re-binning's scatter is deferred into the assembly's particle loads
   int fill_kernel = XPIC_DEFAULT_FILL_KERNEL; // 1: warp-specialised assembly (8-wave workgroups, producer / consumer waves) where the grid allows; 0: classic
   std::vector<xpic::Sort> sorts;
   // Krylov workspace
@@ -277,7 +288,9 @@ int matL_ghost_rows_finish(xpic_ctx* c);    // add the neighbours' rows into the
 // particles.hip
 int sort_alloc(xpic_ctx* c, Sort& s, int64_t cap);
 void sort_free(Sort& s);
-int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap);
+int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap, bool defer = false);
+int sort_materialize(xpic_ctx* c, Sort& s); // run the scatter a deferred re-binning left out (no-op otherwise)
+void sort_deferred_done(Sort& s);             // the assembly has written the sorted records: swap the buffers
 int sort_move(xpic_ctx* c, Sort& s, double step); // r += step*v in place, cells left stale // (optional move by step*v), wrap, bin, scatter
 int sort_append_host(xpic_ctx* c, Sort& s, int64_t n, const double* pts6, int64_t* added);
 int sort_download(xpic_ctx* c, Sort& s, double* pts6, int32_t* cell_of);

@@ -85,6 +85,18 @@ extern "C" int xpic_debug_fill_stamps(double* out, int reset)
 // without the zero-slot compare / select, the partial step peeled: 99.2 (the octant bodies double; the instruction stream,
 // not its count, pays); FILL_DTAB32 -- the merge's offsets as 32-bit words, nine loads and no unpacking: 97.2; both: 100.5;
 // FILL_NO_READ2 -- ds_read_b64 in place of the paired ds_read2_b64 operand reads (half the LDS cycles on paper): 96.7
+#ifndef FILL_GA_EXP
+#define FILL_GA_EXP 0 // experiments (results garbage): 1 the gathering assembly without its stores
+#endif
+#if FILL_GA_EXP && !defined(XPIC_EXPERIMENT)
+#error "FILL_GA_EXP is an experiment switch: build with -DXPIC_EXPERIMENT as well"
+#endif
+#ifndef FILL_GA_NOCHAIN
+#define FILL_GA_NOCHAIN 0 // experiment (results garbage): the gathering assembly without its index indirection -- what the stores and the move cost alone
+#endif
+#if FILL_GA_NOCHAIN && !defined(XPIC_EXPERIMENT)
+#error "FILL_GA_NOCHAIN is an experiment switch: build with -DXPIC_EXPERIMENT as well"
+#endif
 #ifndef FILL_PEEL
 #define FILL_PEEL 0
 #endif
@@ -193,7 +205,14 @@ struct Prefetch {
   int start, cnt;  // cell_start of the cell this wave handles next
   double p[6];     // x, y, z, vx, vy, vz of lane's particle of the next pass
   double b;        // lane's value of the next cell's 54-value B neighbourhood
+  int srcx;        // gathering assembly: source index of slot start + kCP + lane (the second pass's records)
 };
+// gathering assembly: what is requested TWO cells ahead -- the cell's range and the source indices of its first slots
+struct PrefetchIdx {
+  int start, cnt;
+  int src, srcx;   // source index of slot start + lane / start + kCP + lane
+};
+constexpr long kGatherWindow = 1L << 28; // a record's old index lies within this many slots of its new one (checked by k_index)
 
 // B neighbourhood of cell (cx,cy,cz) = every B value a CIC gather from inside that cell can touch:
 //   Bx at (xn in cx..cx+1, ys in cy-1..cy+1, zs in cz-1..cz+1)   -> [ 0,18): (kl*3 + jl)*2 + i
@@ -214,11 +233,15 @@ __device__ inline const double* bnb_row(const GridDev& g, const double* __restri
 
 // P2: power-of-two spacings (exact reciprocals, device_common.h); FX: nx is a multiple of the chunk width, so every
 // chunk is full and its flush is the aligned 32-byte form (the partial-chunk code paths compile away)
-template <bool P2, bool FX>
+// GA ("gather"): the sort's re-binning deferred its scatter (particles.hip: sort_rebin(.., defer)): slot d of a cell holds
+// the index src[d] of its record in the OLD order; the record is moved by `step`, wrapped (the same arithmetic as k_scatter)
+// and written to r2 / v2 [d] on its way into phase 1 -- the scatter pass of the re-binning (56 B read + 48 B written per
+// particle, 27 ms of the 256^3 x 64 step) shrinks to the index pass and these stores.
+template <bool P2, bool FX, bool GA>
 __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, SortDev s, const double* __restrict__ B,
   double* currI, double* matL, const unsigned short* __restrict__ dtab, const int* __restrict__ linetab, const int* __restrict__ cowr, double q, double m,
   double mpw, int cy0, int cystep, int ncy, int cz0, int czstep, int my_order, int ncol_y, int per_y, int per_z, int first_sort,
-  int alias_rows, unsigned long long zord)
+  int alias_rows, unsigned long long zord, double step, int* __restrict__ gerr)
 {
   const int cy = cy0 + (int)(blockIdx.x % ncy) * cystep;
   const int cz = cz0 + (int)(blockIdx.x / ncy) * czstep;
@@ -328,9 +351,81 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
       for (int a = 0; a < 3; ++a) { pf.p[a] = s.r[a][p]; pf.p[3 + a] = s.v[a][p]; }
     }
   };
+  // ---- gathering form.  Addresses: 32-bit byte offsets from two wave-uniform bases per array -- the old-order arrays from
+  // kGatherWindow slots below the pencil's first slot (a record's old index is within that window of its new one: k_index
+  // checks it), the new-order arrays from the pencil's first slot -- so that one shifted index serves the six arrays of a
+  // record (64-bit address arithmetic per array cost 24 vector instructions per pass).
+  using UniformIntsG = const __attribute__((address_space(4))) int*;
+  const long pn0 = GA ? (long)((UniformIntsG)(s.cell_start + pencil0))[0] : 0;
+  const long gb = pn0 > kGatherWindow ? pn0 - kGatherWindow : 0;
+  const char* rb[6];
+  char* wb[6];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    rb[a] = reinterpret_cast<const char*>(s.r[a] + gb); rb[3 + a] = reinterpret_cast<const char*>(s.v[a] + gb);
+    wb[a] = reinterpret_cast<char*>(s.r2[a] + pn0); wb[3 + a] = reinterpret_cast<char*>(s.v2[a] + pn0);
+  }
+  // (the pencils of the box's first and last z-plane also receive the particles that crossed the periodic boundary, whose
+  // old index is an array length away: they take plain 64-bit addresses -- 2 of nz planes)
+  // (k_index has checked |old - new| < 2^27 for these pencils; with fewer than 2^27 particles in the pencil every offset from
+  // `gb` stays below 2^29 slots = 2^32 bytes)
+  const long pencil_pop = GA ? (long)((UniformIntsG)(s.cell_start + pencil0))[g.nx] - pn0 : 0;
+  const bool near_only = cz > 0 && cz < g.nzl - 1 && pencil_pop < (1L << 27);
+  if (GA && pencil_pop >= (1L << 29) && threadIdx.x == 0) atomicOr(gerr, 1); // the sorted copy's 32-bit offsets: host falls back
+  auto gather = [&](int srcidx, double (&rec)[6]) {
+    if (near_only) {
+      const unsigned off8 = (unsigned)((long)srcidx - gb) << 3;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) rec[a] = *reinterpret_cast<const double*>(rb[a] + (size_t)off8);
+    }
+    else {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { rec[a] = s.r[a][srcidx]; rec[3 + a] = s.v[a][srcidx]; }
+    }
+  };
+  // two cells ahead: the cell's range and the source indices of its first 2 kCP slots (the index -> record chain of one
+  // cell ahead was 2.6 ms of the assembly)
+  auto prefetch_idx = [&](int i, PrefetchIdx& pi) {
+    pi.start = 0; pi.cnt = 0; pi.src = 0; pi.srcx = 0;
+    if (i >= g.nx) return;
+    const int cxu = __builtin_amdgcn_readfirstlane(cell_x(i));
+    UniformIntsG cs = (UniformIntsG)(s.cell_start + pencil0);
+    pi.start = cs[cxu];
+    pi.cnt = cs[cxu + 1] - pi.start;
+    if (lane < min(kCP, pi.cnt)) pi.src = s.src[(long)pi.start + lane];
+    if (lane < min(kCP, pi.cnt - kCP)) pi.srcx = s.src[(long)pi.start + kCP + lane];
+  };
+  auto prefetch_rec = [&](int i, const PrefetchIdx& pi, Prefetch& pf) {
+    pf.start = pi.start; pf.cnt = pi.cnt; pf.b = 0.0; pf.srcx = pi.srcx;
+    if (i >= g.nx) return;
+    pf.b = brow ? brow[g.wx(cell_x(i) + box)] : 0.0;
+    if (lane < min(kCP, pf.cnt)) gather(FILL_GA_NOCHAIN ? pf.start + lane : pi.src, pf.p);
+  };
+  // a record that has just arrived from the old order is moved, wrapped (k_scatter's arithmetic, bit for bit) and written
+  // to its slot d of the new order.  (Wrapping only in the cells on the box's boundary is wrong: a particle that moves
+  // several cells in a step lands further inside.)
+  auto settle = [&](double (&cur)[6], int drel) {
+    cur[0] += cur[3] * step;
+    cur[1] += cur[4] * step;
+    cur[2] += cur[5] * step;
+    cur[0] = bound_periodic(cur[0], g.Lx);
+    cur[1] = bound_periodic(cur[1], g.Ly);
+    cur[2] = bound_periodic(cur[2], g.Lz);
+    const unsigned off8 = (unsigned)drel << 3;
+#if FILL_GA_EXP != 1
+#pragma unroll
+    for (int a = 0; a < 6; ++a) *reinterpret_cast<double*>(wb[a] + (size_t)off8) = cur[a];
+#endif
+  };
 
   Prefetch pf;
-  prefetch_cell(wave, pf);
+  PrefetchIdx pi;
+  if (GA) {
+    prefetch_idx(wave, pi);
+    prefetch_rec(wave, pi, pf);
+    prefetch_idx(wave + kW, pi);
+  }
+  else prefetch_cell(wave, pf);
 #if FILL_DRAIN
   __builtin_amdgcn_s_waitcnt(0x0F70);
 #endif
@@ -362,6 +457,9 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
       double cur[6];
 #pragma unroll
       for (int a = 0; a < 6; ++a) cur[a] = pf.p[a];
+      const int srcx_cur = pf.srcx;
+      if (GA && lane < min(kCP, cnt)) settle(cur, (int)((long)start - pn0) + lane);
+      int fresh = -1; // GA: slot (relative to the cell's first) of a record this lane requested during the last pass
       // particles.cpp:107-115: the factors that do not depend on the particle
       const double fb = (0.5 * dt) * q / m;
       const double qw = q * mpw;                          // iq  = q * mpw / (1 + b^2)
@@ -381,6 +479,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
         real = false;
 #endif
         wave_sync(); // the previous pass's operand reads (and the neighbourhood store) are done
+        if (GA && fresh >= 0) { settle(cur, (int)((long)start - pn0) + fresh); fresh = -1; }
         // CIC weights and the half-cell octant first: the octant decides the particle's stage slot
         const W1T<P2> w(g, cur[0], cur[1], cur[2]); // lanes without a particle: garbage in, masked by oct = 8
         const int ox = w.is[0] - w.in[0] + 1, oy = w.is[1] - w.in[1] + 1, oz = w.is[2] - w.in[2] + 1;
@@ -473,7 +572,18 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
           const unsigned long long fm = ~km;
           const int fr = __builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
           const bool get = !keep && fr < take;
-          if (get) {
+          if (GA) {
+            // the second pass's source indices came with the cell (srcx: slot kCP + lane); the lane that takes slot
+            // handed + fr fetches the index from lane handed + fr - kCP (every lane takes part in the shuffle)
+            const int q = handed + fr - kCP;
+            const int sv = __shfl(srcx_cur, q & 63, 64);
+            if (get) {
+              fresh = handed + fr;
+              const int srcidx = FILL_GA_NOCHAIN ? start + handed + fr : (q >= 0 && q < kCP ? sv : s.src[(long)start + handed + fr]);
+              gather(srcidx, cur);
+            }
+          }
+          else if (get) {
             const long p = (long)start + handed + fr;
 #pragma unroll
             for (int a = 0; a < 3; ++a) { cur[a] = s.r[a][p]; cur[3 + a] = s.v[a][p]; }
@@ -592,7 +702,11 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     // re-use of the pass loop's load registers with waits BEHIND the requests below)
     __builtin_amdgcn_s_waitcnt(0x0F70);
 #endif
-    prefetch_cell(i + kW, pf);
+    if (GA) {
+      prefetch_rec(i + kW, pi, pf);   // its indices were requested a chunk ago
+      prefetch_idx(i + 2 * kW, pi);
+    }
+    else prefetch_cell(i + kW, pf);
 
     // ---- the finished columns of this chunk leave by read-modify-write: request their current values NOW, so
     // that the HBM latency runs under the merge below (addresses depend only on the chunk, not on the data)
@@ -1543,17 +1657,23 @@ void ecsim_fill_variant(const xpic_ctx* c, int* p2, int* fx, int* ws)
 
 int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, double* matL, bool first_sort, bool post_ghost_rows)
 {
+  if (s.deferred && s.n == 0) XPIC_CALL(sort_materialize(c, s));
   if (s.n == 0) return 0;
   const GridDev& g = c->g;
   int p2, fxi, wsi;
   ecsim_fill_variant(c, &p2, &fxi, &wsi);
   const bool ws = wsi != 0;
+  // a deferred re-binning is resolved here: the classic kernel gathers the old-order records through s.d.src, moves and
+  // wraps them and writes the sorted copy on its way (the periodic wrap it applies is the deferral's only form); the
+  // warp-specialised body has no gathering form: scatter first
+  if (s.deferred && (ws || !s.def_wrap)) XPIC_CALL(sort_materialize(c, s));
+  const bool ga = s.deferred;
   // y is periodic inside the slab; z is periodic only when the slab is the whole box: with z-neighbours the rows
   // below plane 0 / above plane nzl-1 are ghost rows of this rank alone, so plain residues mod per_z suffice
   int per_y, per_z;
   colour_periods(g, (ws ? 1 : 2) * c->num_cus, &per_y, &per_z); // workgroup slots of the chip: the 8-wave kernel owns a CU
   const int ncol_y = per_y + g.ny % per_y, ncol_z = g.G == 0 ? per_z + g.nzl % per_z : per_z;
-  if (ws) XPIC_HIP(hipMemsetAsync(c->fill_err, 0, sizeof(int), c->stream));
+  if (ws || ga) XPIC_HIP(hipMemsetAsync(c->fill_err, 0, sizeof(int), c->stream));
   // Launch sequence of the z colours.  On a slab the colours of the first and the last plane go first: their pencils are
   // the only ones that write the two ghost row planes of matL, which the neighbours are waiting for -- with
   // `post_ghost_rows` (the last species) the exchange is posted right behind them and travels beside the other colours.
@@ -1591,15 +1711,24 @@ int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, d
           per_y, per_z, first_sort ? 1 : 0, c->fill_err, zord);
         continue;
       }
-      auto kern = g.pow2 ? (fx ? k_ecsim_fill<true, true> : k_ecsim_fill<true, false>)
-                         : (fx ? k_ecsim_fill<false, true> : k_ecsim_fill<false, false>);
+      auto kern = ga ? (g.pow2 ? (fx ? k_ecsim_fill<true, true, true> : k_ecsim_fill<true, false, true>)
+                               : (fx ? k_ecsim_fill<false, true, true> : k_ecsim_fill<false, false, true>))
+                     : (g.pow2 ? (fx ? k_ecsim_fill<true, true, false> : k_ecsim_fill<true, false, false>)
+                               : (fx ? k_ecsim_fill<false, true, false> : k_ecsim_fill<false, false, false>));
       hipLaunchKernelGGL(kern, dim3((unsigned)(ncy * ncz)), dim3(kThreads), 0, c->stream, g, s.d, B,
         currI_sort, matL, dtab, c->ltab, c->ltab + kLines, s.par.q, s.par.m,
         s.par.n / (double)s.par.Np, cy0, cys, ncy, cz0, czs, pos * ncol_y + a, ncol_y, per_y, per_z, first_sort && !alias ? 1 : 0,
-        alias ? 1 : 0, zord);
+        alias ? 1 : 0, zord, s.def_step, c->fill_err);
     }
   }
   if (post_ghost_rows && nseq <= nboundary) XPIC_CALL(matL_ghost_rows_post(c)); // (a slab whose every colour is a boundary colour)
+  if (ga) {
+    sort_deferred_done(s); // every cell's records are in r2 / v2 now: they become the sort
+    int* herr = (int*)(c->red_host + 60);
+    XPIC_HIP(hipMemcpyAsync(herr, c->fill_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    XPIC_HIP(hipStreamSynchronize(c->stream));
+    XPIC_CHECK(*herr == 0, "an x-pencil holds more than 2^29 particles: run this configuration with xpic_set_fused_rebin(ctx, 0)");
+  }
   XPIC_HIP(hipGetLastError());
   if (ws) {
     // the pipeline's bounded waits: a wave that gave up has left the matrix incomplete -- fail the assembly loudly

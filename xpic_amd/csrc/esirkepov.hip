@@ -877,6 +877,7 @@ extern "C" int xpic_debug_esk_stamps(double* out, int reset)
 
 int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double* B, double* J, double* pred_w_host)
 {
+  XPIC_CALL(sort_materialize(c, s));
   s.prebinned = false;
   if (pred_w_host) *pred_w_host = 0.0;
   // rank-uniform checks first: every slab fails them alike, BEFORE anyone enters the collective below (a slab that

@@ -1,6 +1,9 @@
 // particles.hip -- particle-side kernels: SoA storage, move + periodic wrap + cell binning, the
 // out-of-place counting sort that replaces the reference's per-cell std::list splicing, the CIC
 // gather + Boris velocity update, reductions over particles, the synthetic loader.
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
 #include "device_common.h"
 
@@ -174,6 +177,25 @@ __global__ void __launch_bounds__(kBlock) k_scatter(GridDev g, SortDev s, int64_
   }
   s.r2[0][d] = x; s.r2[1][d] = y; s.r2[2][d] = z;
   s.v2[0][d] = vx; s.v2[1][d] = vy; s.v2[2][d] = vz;
+}
+
+// deferred scatter: instead of moving the records, note for every slot of the new order where its record sits in the old
+// (flag: set when a record's old index is not within `window` slots of its new one in a pencil that addresses its records
+// with 32-bit offsets -- every pencil but those of the first and the last z-plane, which also receive what crossed the
+// periodic boundary from the other end of the array; the host then scatters as before)
+__global__ void __launch_bounds__(kBlock) k_index(SortDev s, int64_t n, long plane_cells, int nzl, long window, int* flag)
+{
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n) return;
+  const int c = s.cell[p];
+  if (c < 0) return;
+  const int64_t d = (int64_t)s.cell_start[c] + s.rank[p];
+  s.src[d] = (int)p;
+  const int64_t far = d > p ? d - p : p - d;
+  if (far >= window) {
+    const long cz = c / plane_cells;
+    if (cz > 0 && cz < nzl - 1) atomicOr(flag, 1);
+  }
 }
 
 // ---- exclusive scan of the per-cell counts (3 small kernels; N ints, negligible next to particles) ----
@@ -675,6 +697,8 @@ int sort_alloc(xpic_ctx* c, Sort& s, int64_t cap)
   }
   XPIC_HIP(hipMalloc(&s.d.cell, sizeof(int) * cap));
   XPIC_HIP(hipMalloc(&s.d.rank, sizeof(int) * cap));
+  s.d.src = nullptr;
+  if (c->scheme == XPIC_ECSIM) XPIC_HIP(hipMalloc(&s.d.src, sizeof(int) * (cap + 1))); // deferred scatter of the ecsim step
   XPIC_HIP(hipMalloc(&s.d.cell_count, sizeof(int) * (c->ncell + 1)));
   // + kCellStartPad: the pencil kernels read a fixed number of entries ahead of the cell they are at (never used past
   // the pencil's end, but the reads must land in the allocation)
@@ -701,7 +725,7 @@ void sort_free(Sort& s)
   for (int a = 0; a < 3; ++a) {
     (void)hipFree(s.d.r[a]); (void)hipFree(s.d.v[a]); (void)hipFree(s.d.r2[a]); (void)hipFree(s.d.v2[a]);
   }
-  (void)hipFree(s.d.cell); (void)hipFree(s.d.rank); (void)hipFree(s.d.cell_count); (void)hipFree(s.d.cell_start);
+  (void)hipFree(s.d.cell); (void)hipFree(s.d.rank); (void)hipFree(s.d.src); (void)hipFree(s.d.cell_count); (void)hipFree(s.d.cell_start);
   (void)hipFree(s.J); (void)hipFree(s.currI); (void)hipFree(s.currJe); (void)hipFree(s.rho);
   (void)hipFree(s.mig_send[0]); (void)hipFree(s.mig_send[1]); (void)hipFree(s.mig_recv);
   (void)hipFree(s.mig_cell); (void)hipFree(s.mig_rank); (void)hipFree(s.mig_count);
@@ -722,8 +746,46 @@ static Migr make_migr(xpic_ctx* c, Sort& s)
   return mg;
 }
 
-int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap)
+static int launch_scatter(xpic_ctx* c, Sort& s, int64_t n_old, double step, bool wrap)
 {
+  Timed t(c, "scatter");
+  const bool move = step != 0.0;
+  const unsigned nb = (unsigned)(8 * ((pgrid(n_old) + 7) / 8)); // 8 XCD runs of equal length
+#define LAUNCH(M, W) hipLaunchKernelGGL((k_scatter<M, W>), dim3(nb), dim3(kBlock), 0, c->stream, c->g, s.d, n_old, step)
+  if (move && wrap) LAUNCH(true, true);
+  else if (move) LAUNCH(true, false);
+  else if (wrap) LAUNCH(false, true);
+  else LAUNCH(false, false);
+#undef LAUNCH
+  XPIC_HIP(hipGetLastError());
+  return 0;
+}
+
+// a deferred re-binning whose assembly never came (or was not the gathering kind): do the scatter now
+int sort_materialize(xpic_ctx* c, Sort& s)
+{
+  if (!s.deferred) return 0;
+  s.deferred = false;
+  if (s.def_n_old > 0) XPIC_CALL(launch_scatter(c, s, s.def_n_old, s.def_step, s.def_wrap));
+  for (int a = 0; a < 3; ++a) {
+    std::swap(s.d.r[a], s.d.r2[a]);
+    std::swap(s.d.v[a], s.d.v2[a]);
+  }
+  return 0;
+}
+
+void sort_deferred_done(Sort& s)
+{
+  s.deferred = false;
+  for (int a = 0; a < 3; ++a) {
+    std::swap(s.d.r[a], s.d.r2[a]);
+    std::swap(s.d.v[a], s.d.v2[a]);
+  }
+}
+
+int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap, bool defer)
+{
+  XPIC_CALL(sort_materialize(c, s));
   const bool move = step != 0.0;
   const bool mig = c->comm.kind != 0;
   // keys, ranks, counts (and the migration send buffers) of exactly this move may already be there (ecsim_second_push)
@@ -811,17 +873,30 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap)
       "a particle received from a neighbouring z-slab does not lie in this slab", "", ""};
     XPIC_CALL(agree(bad, what));
   }
-  if (s.n > 0) {
-    Timed t(c, "scatter");
-    const unsigned nb = (unsigned)(8 * ((pgrid(s.n) + 7) / 8)); // 8 XCD runs of equal length
-#define LAUNCH(M, W) hipLaunchKernelGGL((k_scatter<M, W>), dim3(nb), dim3(kBlock), 0, c->stream, c->g, s.d, s.n, step)
-    if (move && wrap) LAUNCH(true, true);
-    else if (move) LAUNCH(true, false);
-    else if (wrap) LAUNCH(false, true);
-    else LAUNCH(false, false);
-#undef LAUNCH
-    XPIC_HIP(hipGetLastError());
+  // Deferred (the ecsim step on a single slab): the records stay where they are; slot d of the new order learns its
+  // source, and the mass-matrix assembly -- which reads every particle anyway -- moves, wraps and writes it (ecsim.hip).
+  if (defer && !mig && s.n > 0 && s.d.src) {
+    int* flag = s.d.src + s.cap; // one word behind the index
+    {
+      Timed t(c, "index");
+      XPIC_HIP(hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+      hipLaunchKernelGGL(k_index, dim3(pgrid(s.n)), dim3(kBlock), 0, c->stream, s.d, s.n, (long)c->g.plane, c->g.nzl, 1L << 27, flag);
+      XPIC_HIP(hipGetLastError());
+    }
+    int* hflag = (int*)(c->red_host + 61);
+    XPIC_HIP(hipMemcpyAsync(hflag, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    XPIC_HIP(hipStreamSynchronize(c->stream));
+    s.deferred = true; s.def_step = step; s.def_wrap = wrap; s.def_n_old = s.n;
+    s.n = total;
+    if (*hflag != 0) {
+      if (getenv("XPIC_DEBUG_INDEX")) fprintf(stderr, "k_index flag %d (n %ld total %d)\n", *hflag, (long)s.def_n_old, total);
+      // a record lies further from its slot than the gathering assembly's offsets reach: scatter now (s.n is the new count;
+      // the scatter walks the old one)
+      return sort_materialize(c, s);
+    }
+    return 0;
   }
+  if (s.n > 0) XPIC_CALL(launch_scatter(c, s, s.n, step, wrap));
   if (n_in > 0) {
     hipLaunchKernelGGL(k_scatter_incoming, dim3(pgrid(n_in)), dim3(kBlock), 0, c->stream, s.d, s.mig_recv, n_in, s.mig_cell, s.mig_rank);
     XPIC_HIP(hipGetLastError());
@@ -835,7 +910,9 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap)
 }
 
 int sort_append_host(xpic_ctx* c, Sort& s, int64_t n, const double* pts6, int64_t* added)
-{  s.prebinned = false;
+{
+  XPIC_CALL(sort_materialize(c, s)); // (a deferred re-binning whose assembly has not run)
+  s.prebinned = false;
 
   XPIC_CHECK(s.n + n <= s.cap, "sort capacity exceeded in add_particles");
   const int64_t before = s.n;
@@ -857,6 +934,7 @@ int sort_append_host(xpic_ctx* c, Sort& s, int64_t n, const double* pts6, int64_
 
 int sort_download(xpic_ctx* c, Sort& s, double* pts6, int32_t* cell_of_out)
 {
+  XPIC_CALL(sort_materialize(c, s)); // (a deferred re-binning whose assembly has not run)
   if (s.n == 0) return 0;
   double* tmp = nullptr;
   int* tc = nullptr;
@@ -874,6 +952,7 @@ int sort_download(xpic_ctx* c, Sort& s, double* pts6, int32_t* cell_of_out)
 
 int sort_fill_synthetic(xpic_ctx* c, Sort& s, int ppc, double vth, uint64_t seed, bool regular)
 {
+  XPIC_CALL(sort_materialize(c, s)); // (a deferred re-binning whose assembly has not run)
   s.prebinned = false;
   const int64_t n = (int64_t)c->ncell * ppc;
   XPIC_CHECK(n <= s.cap, "sort capacity exceeded in fill_synthetic");
@@ -897,6 +976,7 @@ int sort_fill_synthetic(xpic_ctx* c, Sort& s, int ppc, double vth, uint64_t seed
 // step = dt consumes it if nothing touched the species in between)
 int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B, bool prebin)
 {
+  XPIC_CALL(sort_materialize(c, s)); // (a deferred re-binning whose assembly has not run)
   s.prebinned = false;
   if (s.n == 0) return 0;
   Timed t(c, "second_push");
@@ -928,6 +1008,7 @@ int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B, bo
 
 int charge_density(xpic_ctx* c, Sort& s, double* rho_vec)
 {
+  XPIC_CALL(sort_materialize(c, s)); // (a deferred re-binning whose assembly has not run)
   XPIC_HIP(hipMemsetAsync(rho_vec, 0, sizeof(double) * c->nvec, c->stream));
   if (s.n > 0) {
     hipLaunchKernelGGL(k_charge_density, dim3(pgrid(s.n)), dim3(kBlock), 0, c->stream, c->g, s.d, s.n,
@@ -939,6 +1020,7 @@ int charge_density(xpic_ctx* c, Sort& s, double* rho_vec)
 
 int moment_density(xpic_ctx* c, Sort& s, double* vec)
 {
+  XPIC_CALL(sort_materialize(c, s)); // (a deferred re-binning whose assembly has not run)
   XPIC_HIP(hipMemsetAsync(vec, 0, sizeof(double) * c->nvec, c->stream));
   if (s.n > 0) {
     hipLaunchKernelGGL(k_moment_density, dim3(pgrid(s.n)), dim3(kBlock), 0, c->stream, c->g, s.d, s.n,
@@ -950,6 +1032,7 @@ int moment_density(xpic_ctx* c, Sort& s, double* vec)
 
 int kinetic_sums_host(xpic_ctx* c, Sort& s, double* out5)
 {
+  XPIC_CALL(sort_materialize(c, s)); // (a deferred re-binning whose assembly has not run)
   for (int i = 0; i < 5; ++i) out5[i] = 0;
   out5[4] = (double)s.n;
   if (s.n == 0) return 0;
@@ -974,6 +1057,7 @@ int kinetic_sums_global(xpic_ctx* c, Sort& s, double* out5)
 // out6 = {Px, Py, Pz, QEx, QEy, QEz} of one sort, summed over the slabs (E must have its ghost planes filled)
 int momentum_sums_global(xpic_ctx* c, Sort& s, const double* E, double* out6)
 {
+  XPIC_CALL(sort_materialize(c, s)); // (a deferred re-binning whose assembly has not run)
   for (int i = 0; i < 6; ++i) out6[i] = 0;
   if (s.n > 0) {
     int nblocks = (int)pgrid(s.n, 4);
@@ -990,7 +1074,9 @@ int momentum_sums_global(xpic_ctx* c, Sort& s, const double* E, double* out6)
 }
 
 int sort_move(xpic_ctx* c, Sort& s, double step)
-{  s.prebinned = false;
+{
+  XPIC_CALL(sort_materialize(c, s)); // (a deferred re-binning whose assembly has not run)
+  s.prebinned = false;
 
   if (s.n == 0) return 0;
   Timed t(c, "move");
@@ -1000,7 +1086,9 @@ int sort_move(xpic_ctx* c, Sort& s, double step)
 }
 
 int scale_velocities(xpic_ctx* c, Sort& s, double lambda)
-{  s.prebinned = false;
+{
+  XPIC_CALL(sort_materialize(c, s)); // (a deferred re-binning whose assembly has not run)
+  s.prebinned = false;
 
   if (s.n == 0) return 0;
   hipLaunchKernelGGL(k_scale_v, dim3(pgrid(s.n)), dim3(kBlock), 0, c->stream, s.d, s.n, lambda);
