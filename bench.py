@@ -51,7 +51,7 @@ def parse_args(argv=None):
                     help="skip the device copy probe (1 GiB device-to-device copies: the achievable copy rate of THIS box, "
                          "SURVEY 8(d); on by default, outside the timed region)")
     ap.add_argument("--plain-gmres", action="store_true", help="unpreconditioned GMRES(30), as the CPU oracle runs")
-    ap.add_argument("--fused-rebin", type=int, default=None, choices=[0, 1],
+    ap.add_argument("--fused-rebin", type=int, default=None, choices=[0, 1, 2],
                     help="ecsim: 1 the re-binning's scatter deferred into the assembly's particle loads, 0 scatter first (default: the library's)")
     ap.add_argument("--fill-kernel", type=int, default=None, choices=[0, 1],
                     help="mass-matrix assembly: 1 warp-specialised kernel, 0 the classic 4-wave kernel (default: the library's)")

@@ -183,7 +183,9 @@ int xpic_set_fill_kernel(xpic_ctx* ctx, int kind);
 /* The ecsim step's first_push + update_cells (ecsim/simulation.cpp:174-189) re-bins the particles; on = 1 (default)
  * defers the scatter pass of that re-binning into the assembly that follows: the assembly reads every particle anyway,
  * so it gathers the records through a source index, applies the move and the periodic wrap and writes the sorted copy on
- * its way.  Same particles, same order, same arithmetic as on = 0 (scatter first).  Single slab, classic assembly kernel. */
+ * its way; on = 2: the assembly only reads through the index and ecsim's second_push -- which is bound by memory anyway --
+ * moves the records and writes the sorted copy with the new velocities.  Same particles, same cells, same arithmetic as
+ * on = 0 (scatter first).  Single slab, classic assembly kernel. */
 int xpic_set_fused_rebin(xpic_ctx* ctx, int on);
 int xpic_get_fill_variant(xpic_ctx* ctx, int* out3);
 /* MatMult on a z-slab with neighbours: on = 1 posts the ghost exchange of the operand (VecScatterBegin), applies

@@ -185,8 +185,9 @@ def test_both_assembly_kernels_match_the_oracle(oracle, grid):
         assert np.abs(Lo - g.matL()).max() <= 1e-12 * np.abs(Lo).max(), kind
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @BOTH_GRIDS
-def test_deferred_scatter_equals_scatter_first(oracle, grid):
+def test_deferred_scatter_equals_scatter_first(oracle, grid, mode):
     """xpic_set_fused_rebin: the ecsim step's re-binning leaves its scatter to the assembly (records gathered through a
     source index, moved, wrapped and written sorted on the way) -- the same particles in the same cells with the same
     position bits as the scatter-first step, over several steps with particles crossing cells and the periodic boundary, heavy and empty
@@ -201,7 +202,7 @@ def test_deferred_scatter_equals_scatter_first(oracle, grid):
     heavy = np.hstack([(np.array([3, 2, 1]) + rng.random((150, 3))) * np.array(d), rng.normal(0, 0.35, (150, 3))])
     for sim in (o, g, h):
         assert sim.add_particles(0, heavy) == 150
-    g.set_fused_rebin(1)
+    g.set_fused_rebin(mode)  # 1: the assembly writes the sorted copy, 2: the second push does
     h.set_fused_rebin(0)
     for sim in (o, g, h):
         sim.set_tolerances(1e-12, 1e-50, 400)

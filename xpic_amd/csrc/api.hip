@@ -174,7 +174,7 @@ static int ecsim_final_update(xpic_ctx* c)
 static int step_ecsim(xpic_ctx* c, int* its)
 {
   // first_push + update_cells :174-189 (the scatter of the re-binning deferred into the assembly's particle loads)
-  for (auto& s : c->sorts) XPIC_CALL(sort_rebin(c, s, c->g.dt, true, c->fused_rebin));
+  for (auto& s : c->sorts) XPIC_CALL(sort_rebin(c, s, c->g.dt, true, c->fused_rebin != 0));
   XPIC_CALL(ecsim_fill_current(c));
   XPIC_CALL(advance_fields(c, XPIC_OP_MATA_GMRES, c->field[XPIC_CURRI], c->field[XPIC_EP], its)); // :191-210
   XPIC_CALL(halo_fill(c, c->field[XPIC_EP]));
@@ -703,7 +703,8 @@ int xpic_set_preconditioner(xpic_ctx* ctx, int kind, int degree)
 int xpic_set_fused_rebin(xpic_ctx* ctx, int on)
 {
   CTX_CHECK(ctx);
-  ctx->fused_rebin = on != 0;
+  XPIC_CHECK(on >= 0 && on <= 2, "xpic_set_fused_rebin: 0 scatter first, 1 the assembly writes the sorted copy, 2 the second push does");
+  ctx->fused_rebin = on;
   return 0;
 }
 

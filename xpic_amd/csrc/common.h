@@ -184,7 +184,8 @@ struct xpic_ctx {
   double* matL = nullptr; // [c1][nzl][ny][123][nx]
   int* ltab = nullptr;    // [1296] block entry -> packed (k, c1, o1) descriptor
   int* fill_err = nullptr; // set by k_ecsim_fill_ws when one of its bounded waits gave up
-  bool fused_rebin = XPIC_DEFAULT_FUSED_REBIN != 0; // ecsim step: the re-binning's scatter is deferred into the assembly's particle loads
+  int fused_rebin = XPIC_DEFAULT_FUSED_REBIN; // ecsim step: the re-binning's scatter is deferred -- 1: the assembly gathers, moves and writes
+                                              // the sorted copy; 2: the assembly only gathers, k_second_push writes the sorted copy; 0: scatter first
   int fill_kernel = XPIC_DEFAULT_FILL_KERNEL; // 1: warp-specialised assembly (8-wave workgroups, producer / consumer waves) where the grid allows; 0: classic
   std::vector<xpic::Sort> sorts;
   // Krylov workspace

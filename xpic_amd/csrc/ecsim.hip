@@ -38,7 +38,7 @@
 #include "lstencil.h"
 
 #ifndef FILL_EXP
-#define FILL_EXP 0 // experiments (tools/fill_exp.sh): 1 no phase 2, 6 neither phase 1 nor phase 2, 7 as 6 and no merge,
+#define FILL_EXP 0 // experiments (tools/fill_exp.sh): 11 the flush without its read-modify-write loads, 12 without loads and stores (everything else intact); 1 no phase 2, 6 neither phase 1 nor phase 2, 7 as 6 and no merge,
                    // 8 as 7 and no flush, 10 staggered workgroup starts
 #endif
 
@@ -85,6 +85,9 @@ extern "C" int xpic_debug_fill_stamps(double* out, int reset)
 // without the zero-slot compare / select, the partial step peeled: 99.2 (the octant bodies double; the instruction stream,
 // not its count, pays); FILL_DTAB32 -- the merge's offsets as 32-bit words, nine loads and no unpacking: 97.2; both: 100.5;
 // FILL_NO_READ2 -- ds_read_b64 in place of the paired ds_read2_b64 operand reads (half the LDS cycles on paper): 96.7
+#ifndef FILL_GA_NT
+#define FILL_GA_NT 0
+#endif
 #ifndef FILL_GA_EXP
 #define FILL_GA_EXP 0 // experiments (results garbage): 1 the gathering assembly without its stores
 #endif
@@ -241,7 +244,7 @@ template <bool P2, bool FX, bool GA>
 __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, SortDev s, const double* __restrict__ B,
   double* currI, double* matL, const unsigned short* __restrict__ dtab, const int* __restrict__ linetab, const int* __restrict__ cowr, double q, double m,
   double mpw, int cy0, int cystep, int ncy, int cz0, int czstep, int my_order, int ncol_y, int per_y, int per_z, int first_sort,
-  int alias_rows, unsigned long long zord, double step, int* __restrict__ gerr)
+  int alias_rows, unsigned long long zord, double step, int* __restrict__ gerr, int ga_store)
 {
   const int cy = cy0 + (int)(blockIdx.x % ncy) * cystep;
   const int cz = cz0 + (int)(blockIdx.x / ncy) * czstep;
@@ -411,10 +414,17 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     cur[0] = bound_periodic(cur[0], g.Lx);
     cur[1] = bound_periodic(cur[1], g.Ly);
     cur[2] = bound_periodic(cur[2], g.Lz);
+    if (!ga_store) return; // (xpic_set_fused_rebin 2: k_second_push writes the sorted copy)
     const unsigned off8 = (unsigned)drel << 3;
 #if FILL_GA_EXP != 1
 #pragma unroll
-    for (int a = 0; a < 6; ++a) *reinterpret_cast<double*>(wb[a] + (size_t)off8) = cur[a];
+    for (int a = 0; a < 6; ++a) {
+#if FILL_GA_NT
+      __builtin_nontemporal_store(cur[a], reinterpret_cast<double*>(wb[a] + (size_t)off8)); // read next by k_second_push, a solve later
+#else
+      *reinterpret_cast<double*>(wb[a] + (size_t)off8) = cur[a];
+#endif
+    }
 #endif
   };
 
@@ -730,7 +740,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
       ptr[mm] = lb ? (GlobalDouble*)(lb & ~(uintptr_t)1) + (long)j * (line < kMatLines ? kLBlock : kW) : nullptr;
 #pragma unroll
       for (int c = 0; c < kW; ++c) old[mm][c] = 0.0;
-      if (ptr[mm] && !fst[mm] && FILL_EXP != 8) {
+      if (ptr[mm] && !fst[mm] && FILL_EXP != 8 && FILL_EXP != 11 && FILL_EXP != 12) {
         if (vec) {
 #pragma unroll
           for (int c = 0; c < kW; c += 2) {
@@ -850,7 +860,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
         bool any = FX || fst[mm];
 #pragma unroll
         for (int c = 0; c < kW; ++c) any = any || (c < ndone && w[c] != 0.0);
-#if FILL_EXP == 8
+#if FILL_EXP == 8 || FILL_EXP == 12
         any = false;
 #endif
         if (any) {
@@ -1668,6 +1678,7 @@ int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, d
   // warp-specialised body has no gathering form: scatter first
   if (s.deferred && (ws || !s.def_wrap)) XPIC_CALL(sort_materialize(c, s));
   const bool ga = s.deferred;
+  const bool store_sorted = ga && c->fused_rebin != 2; // 2: the records stay in the old order until k_second_push moves them
   // y is periodic inside the slab; z is periodic only when the slab is the whole box: with z-neighbours the rows
   // below plane 0 / above plane nzl-1 are ghost rows of this rank alone, so plain residues mod per_z suffice
   int per_y, per_z;
@@ -1718,11 +1729,11 @@ int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, d
       hipLaunchKernelGGL(kern, dim3((unsigned)(ncy * ncz)), dim3(kThreads), 0, c->stream, g, s.d, B,
         currI_sort, matL, dtab, c->ltab, c->ltab + kLines, s.par.q, s.par.m,
         s.par.n / (double)s.par.Np, cy0, cys, ncy, cz0, czs, pos * ncol_y + a, ncol_y, per_y, per_z, first_sort && !alias ? 1 : 0,
-        alias ? 1 : 0, zord, s.def_step, c->fill_err);
+        alias ? 1 : 0, zord, s.def_step, c->fill_err, store_sorted ? 1 : 0);
     }
   }
   if (post_ghost_rows && nseq <= nboundary) XPIC_CALL(matL_ghost_rows_post(c)); // (a slab whose every colour is a boundary colour)
-  if (ga) {
+  if (store_sorted) {
     sort_deferred_done(s); // every cell's records are in r2 / v2 now: they become the sort
     int* herr = (int*)(c->red_host + 60);
     XPIC_HIP(hipMemcpyAsync(herr, c->fill_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));

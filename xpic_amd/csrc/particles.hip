@@ -292,9 +292,13 @@ constexpr int kSPPer = (kSPStrip + kSPRound - 1) / kSPRound; // strip values per
 
 using UniformIntsP = const __attribute__((address_space(4))) int*; // wave-uniform reads of cell_start: scalar loads
 
-template <bool PREBIN, bool MIG, bool P2>
+// GA: the sort's re-binning deferred its scatter and the assembly only read through the index (xpic_set_fused_rebin 2):
+// slot p of the new order finds its record at src[p] of the old; it is moved by `step` and wrapped here (k_scatter's
+// arithmetic), pushed, and written -- position and new velocity -- to r2 / v2 [p]: this kernel, which is bound by HBM
+// anyway, carries the sorted copy's stores (in the assembly they cost 9 ms: its store instructions, not their bytes).
+template <bool PREBIN, bool MIG, bool P2, bool GA>
 __global__ void __launch_bounds__(kSPRound) k_second_push(GridDev g, SortDev s, const double* __restrict__ E,
-  const double* __restrict__ B, double qm, long npencil, long chunk, Migr mg)
+  const double* __restrict__ B, double qm, long npencil, long chunk, Migr mg, double step)
 {
   // workgroup -> pencil; XCD r sweeps its own contiguous range of pencils (see k_matA)
   const long q = (long)(blockIdx.x % 8) * chunk + blockIdx.x / 8;
@@ -340,7 +344,13 @@ __global__ void __launch_bounds__(kSPRound) k_second_push(GridDev g, SortDev s, 
     return r;
   };
 
-  struct Ahead { double r[3], v[3], f[kSPPer]; };
+  struct Ahead { double r[3], v[3], f[kSPPer]; int src; };
+  // GA: the index of the round AFTER next is requested with the records of the next one (no dependent round trip)
+  auto request_src = [&](const Round& r, Ahead& pf) {
+    const long p = (long)r.P0 + threadIdx.x;
+    pf.src = 0;
+    if (GA && r.c_lo < g.nx && p < r.P1) pf.src = s.src[p];
+  };
   auto request = [&](const Round& r, Ahead& pf) {
 #pragma unroll
     for (int i = 0; i < kSPPer; ++i) {
@@ -352,14 +362,18 @@ __global__ void __launch_bounds__(kSPRound) k_second_push(GridDev g, SortDev s, 
     for (int a = 0; a < 3; ++a) { pf.r[a] = 0.0; pf.v[a] = 0.0; }
     const long p = (long)r.P0 + threadIdx.x;
     if (p < r.P1) {
+      const long sp = GA ? (long)pf.src : p;
 #pragma unroll
-      for (int a = 0; a < 3; ++a) { pf.r[a] = s.r[a][p]; pf.v[a] = s.v[a][p]; }
+      for (int a = 0; a < 3; ++a) { pf.r[a] = s.r[a][sp]; pf.v[a] = s.v[a][sp]; }
     }
   };
 
   Round nxt = compose(0, cs[0]);
   Ahead pf;
+  request_src(nxt, pf);
   request(nxt, pf);
+  Round nn = compose(nxt.c_lo + nxt.adv, nxt.P1);
+  request_src(nn, pf);
   for (int rd = 0; nxt.c_lo < g.nx; ++rd) {
     const Round cur = nxt;
     double* st = strip[rd & 1];
@@ -368,13 +382,21 @@ __global__ void __launch_bounds__(kSPRound) k_second_push(GridDev g, SortDev s, 
       const int e = threadIdx.x + i * kSPRound;
       if (e < kSPStrip) st[e] = pf.f[i];
     }
-    const double r[3] = {pf.r[0], pf.r[1], pf.r[2]};
+    double r[3] = {pf.r[0], pf.r[1], pf.r[2]};
     double v[3] = {pf.v[0], pf.v[1], pf.v[2]};
-    nxt = compose(cur.c_lo + cur.adv, cur.P1);
+    if (GA) {
+      r[0] += v[0] * step; r[1] += v[1] * step; r[2] += v[2] * step;
+      r[0] = bound_periodic(r[0], g.Lx); r[1] = bound_periodic(r[1], g.Ly); r[2] = bound_periodic(r[2], g.Lz);
+    }
+    nxt = GA ? nn : compose(cur.c_lo + cur.adv, cur.P1);
     // raw barrier that only drains LDS traffic (the requests of the next round stay in flight).  One per round: the
     // strip written here was last read two rounds ago, before the previous round's barrier.
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     request(nxt, pf);
+    if (GA) {
+      nn = compose(nxt.c_lo + nxt.adv, nxt.P1);
+      request_src(nn, pf);
+    }
 
     const long p = (long)cur.P0 + threadIdx.x;
     if (p < cur.P1) {
@@ -397,7 +419,11 @@ __global__ void __launch_bounds__(kSPRound) k_second_push(GridDev g, SortDev s, 
             Bp[2] += st[kSPoBz + (k * 3 + (oy + j)) * kSPXs + (ds + i)] * (w.wn[2][k] * w.ws[1][j] * w.ws[0][i]);
           }
       update_vEB(g.dt, qm, Ep, Bp, v);
-      s.v[0][p] = v[0]; s.v[1][p] = v[1]; s.v[2][p] = v[2];
+      if (GA) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { s.r2[a][p] = r[a]; s.v2[a][p] = v[a]; }
+      }
+      else { s.v[0][p] = v[0]; s.v[1][p] = v[1]; s.v[2][p] = v[2]; }
       if (PREBIN) {
         // the next step opens with first_push + update_cells of exactly this state: r + v dt, wrapped, binned.  Doing
         // the binning here (same expressions as k_move_bin<true, true, .>) saves that pass its 48 B per particle.
@@ -976,33 +1002,44 @@ int sort_fill_synthetic(xpic_ctx* c, Sort& s, int ppc, double vth, uint64_t seed
 // step = dt consumes it if nothing touched the species in between)
 int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B, bool prebin)
 {
-  XPIC_CALL(sort_materialize(c, s)); // (a deferred re-binning whose assembly has not run)
+  const bool mig = c->comm.kind != 0;
+  // a deferred re-binning that the assembly only read through (fused_rebin 2) is resolved HERE: gather, move, push, write
+  const bool ga = s.deferred && c->fused_rebin == 2 && !mig && s.def_wrap && s.n > 0;
+  if (!ga) XPIC_CALL(sort_materialize(c, s)); // (a deferred re-binning whose assembly has not run)
   s.prebinned = false;
   if (s.n == 0) return 0;
   Timed t(c, "second_push");
   const long npencil = (long)c->g.ny * c->g.nzl; // one workgroup per x-pencil
   const long chunk = (npencil + 7) / 8;
-  const bool mig = c->comm.kind != 0;
   Migr mg = make_migr(c, s);
   if (prebin) {
     XPIC_HIP(hipMemsetAsync(s.d.cell_count, 0, sizeof(int) * (c->ncell + 1), c->stream));
     if (mig) XPIC_HIP(hipMemsetAsync(s.mig_count, 0, sizeof(int) * 4, c->stream));
   }
-#define LAUNCH(P, G, Q) hipLaunchKernelGGL((k_second_push<P, G, Q>), dim3((unsigned)(8 * chunk)), dim3(kSPRound), 0, c->stream, \
-    c->g, s.d, E, B, s.par.q / s.par.m, npencil, chunk, mg)
-  if (c->g.pow2) { // exact reciprocal spacings: no fp64 division per position (device_common.h: scaled_position)
-    if (!prebin) LAUNCH(false, false, true);
-    else if (mig) LAUNCH(true, true, true);
-    else LAUNCH(true, false, true);
+#define LAUNCH(P, G, Q, A) hipLaunchKernelGGL((k_second_push<P, G, Q, A>), dim3((unsigned)(8 * chunk)), dim3(kSPRound), 0, c->stream, \
+    c->g, s.d, E, B, s.par.q / s.par.m, npencil, chunk, mg, s.def_step)
+  if (ga) {
+    if (c->g.pow2) { if (prebin) LAUNCH(true, false, true, true); else LAUNCH(false, false, true, true); }
+    else { if (prebin) LAUNCH(true, false, false, true); else LAUNCH(false, false, false, true); }
+  }
+  else if (c->g.pow2) { // exact reciprocal spacings: no fp64 division per position (device_common.h: scaled_position)
+    if (!prebin) LAUNCH(false, false, true, false);
+    else if (mig) LAUNCH(true, true, true, false);
+    else LAUNCH(true, false, true, false);
   }
   else {
-    if (!prebin) LAUNCH(false, false, false);
-    else if (mig) LAUNCH(true, true, false);
-    else LAUNCH(true, false, false);
+    if (!prebin) LAUNCH(false, false, false, false);
+    else if (mig) LAUNCH(true, true, false, false);
+    else LAUNCH(true, false, false, false);
   }
 #undef LAUNCH
   XPIC_HIP(hipGetLastError());
-  if (prebin) { s.prebinned = true; s.prebinned_step = c->g.dt; s.prebinned_n = s.n; }
+  if (ga) sort_deferred_done(s); // r2 / v2 hold the sorted, moved, pushed records: they become the sort
+  if (prebin) {
+    s.prebinned = true;
+    s.prebinned_step = c->g.dt;
+    s.prebinned_n = s.n;
+  }
   return 0;
 }
 
