@@ -89,7 +89,7 @@ extern "C" int xpic_debug_fill_stamps(double* out, int reset)
 #define FILL_GA_NT 0
 #endif
 #ifndef FILL_GA_EXP
-#define FILL_GA_EXP 0 // experiments (results garbage): 1 the gathering assembly without its stores
+#define FILL_GA_EXP 0 // experiments (results garbage): 1 the gathering assembly without its stores, 2 with the position's three only
 #endif
 #if FILL_GA_EXP && !defined(XPIC_EXPERIMENT)
 #error "FILL_GA_EXP is an experiment switch: build with -DXPIC_EXPERIMENT as well"
@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     const unsigned off8 = (unsigned)drel << 3;
 #if FILL_GA_EXP != 1
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
+    for (int a = 0; a < (FILL_GA_EXP == 2 ? 3 : 6); ++a) {
 #if FILL_GA_NT
       __builtin_nontemporal_store(cur[a], reinterpret_cast<double*>(wb[a] + (size_t)off8)); // read next by k_second_push, a solve later
 #else
