@@ -580,9 +580,13 @@ def rank_body(args, rank, world, local_rank, job):
         # reference fills, :149-166, + their adds + the per-particle algebra) x the particles one colour launch covers
         flop_launch = FILL_FLOP_PER_PARTICLE * count_local / launches_per_step
         tf = flop_launch / (avg_ms * 1e-3) / 1e12
-        bytes_launch = (48.0 + 2952.0 / args.ppc) * count_local / launches_per_step
+        # (with the re-binning's scatter deferred into it -- ctx fused_rebin, ecsim on one slab -- the launch also reads
+        # the 4-byte source index and writes the 48-byte sorted record of every particle)
+        fused = args.scheme == "ecsim" and world == 1 and args.fused_rebin != 0 and not ctx.fill_variant()[2]
+        bytes_launch = ((100.0 if fused else 48.0) + 2952.0 / args.ppc) * count_local / launches_per_step
         fill = {
-            "kernel": ("k_ecsim_fill_ws" if ctx.fill_variant()[2] else "k_ecsim_fill") + " (mass matrix + currI; one colour launch)",
+            "kernel": ("k_ecsim_fill_ws" if ctx.fill_variant()[2] else "k_ecsim_fill") + " (mass matrix + currI" +
+                      (" + the re-binning's gather, move and sorted copy" if fused else "") + "; one colour launch)",
             "bound": "mfma",
             "achieved": tf, "peak": FP64_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TF,
             "traffic": pmc_traffic(args.scheme, n3, "k_ecsim_fill_ws" if ctx.fill_variant()[2] else "k_ecsim_fill<") if world == 1 else None,
