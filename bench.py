@@ -460,7 +460,7 @@ def rank_body(args, rank, world, local_rank, job):
 
     if args.scheme != "basic" and args.fill_kernel is not None:
         ctx.set_fill_kernel(args.fill_kernel)
-    if args.scheme == "ecsim" and args.fused_rebin is not None:
+    if args.scheme != "basic" and args.fused_rebin is not None:
         ctx.set_fused_rebin(args.fused_rebin)
     if args.plain_gmres and args.scheme != "basic":
         ctx.set_preconditioner(0)
@@ -582,7 +582,7 @@ def rank_body(args, rank, world, local_rank, job):
         tf = flop_launch / (avg_ms * 1e-3) / 1e12
         # (with the re-binning's scatter deferred into it -- ctx fused_rebin, ecsim on one slab -- the launch also reads
         # the 4-byte source index and writes the 48-byte sorted record of every particle)
-        fused = args.scheme == "ecsim" and world == 1 and args.fused_rebin != 0 and not ctx.fill_variant()[2]
+        fused = world == 1 and args.fused_rebin != 0 and not ctx.fill_variant()[2] and (args.scheme == "ecsim" or args.fused_rebin != 2)
         bytes_launch = ((100.0 if fused else 48.0) + 2952.0 / args.ppc) * count_local / launches_per_step
         fill = {
             "kernel": ("k_ecsim_fill_ws" if ctx.fill_variant()[2] else "k_ecsim_fill") + " (mass matrix + currI" +

@@ -253,7 +253,8 @@ static int step_ecsimcorr(xpic_ctx* c, int* its)
   }
   // first_push: half move + Esirkepov, re-bin, ECSIM current + matL
   for (auto& s : c->sorts) XPIC_CALL(esirkepov_push(c, s, 1, nullptr, nullptr, s.currJe, nullptr));
-  for (auto& s : c->sorts) XPIC_CALL(sort_rebin(c, s, 0.0, true));
+  // (the assembly that follows reads every particle: the re-binning's scatter is deferred into it, as in the ecsim step)
+  for (auto& s : c->sorts) XPIC_CALL(sort_rebin(c, s, 0.0, true, c->fused_rebin == 1));
   XPIC_CALL(ecsim_fill_current(c));
   int its0 = 0, its1 = 0;
   XPIC_CALL(advance_fields(c, XPIC_OP_MATA_GMRES, c->field[XPIC_CURRI], Ep, &its0)); // KSP "predict"

@@ -724,7 +724,7 @@ int sort_alloc(xpic_ctx* c, Sort& s, int64_t cap)
   XPIC_HIP(hipMalloc(&s.d.cell, sizeof(int) * cap));
   XPIC_HIP(hipMalloc(&s.d.rank, sizeof(int) * cap));
   s.d.src = nullptr;
-  if (c->scheme == XPIC_ECSIM) XPIC_HIP(hipMalloc(&s.d.src, sizeof(int) * (cap + 1))); // deferred scatter of the ecsim step
+  if (c->scheme != XPIC_BASIC) XPIC_HIP(hipMalloc(&s.d.src, sizeof(int) * (cap + 1))); // deferred scatter of the ecsim / ecsimcorr step
   XPIC_HIP(hipMalloc(&s.d.cell_count, sizeof(int) * (c->ncell + 1)));
   // + kCellStartPad: the pencil kernels read a fixed number of entries ahead of the cell they are at (never used past
   // the pencil's end, but the reads must land in the allocation)
