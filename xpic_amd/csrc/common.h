@@ -125,6 +125,9 @@ struct SortDev {
   int* cell_count;
   int* cell_start; // [ncell+1 (+ kCellStartPad readable)] exclusive prefix of cell_count
   int* src;        // deferred scatter: source index (old order) of the particle that belongs in slot d of the new order
+  int* bucket;     // the same, written by the binning itself: bucket[cell * bucket_cap + arrival rank] (+ one flag word at the end:
+  int bucket_cap;  // a cell took more arrivals than bucket_cap); 0: no buckets
+  long ncell;
 };
 
 struct Sort {
@@ -136,7 +139,8 @@ struct Sort {
   // Deferred scatter (sort_rebin(.., defer = true)): cell_start / src describe the NEW order while r, v still hold the OLD,
   // un-moved records; the mass-matrix assembly reads them through src, applies the move and writes the sorted records into
   // r2, v2 on its way (ecsim.hip) -- the scatter pass of the re-binning is gone.  Everything else calls sort_materialize first.
-  bool deferred = false, def_wrap = false;
+  bool bucket_written = false; // the binning whose keys cell[] / rank[] hold also filled the buckets
+  bool deferred = false, def_wrap = false, def_bucket = false; // def_bucket: the assembly reads the binning's buckets, not src
   double def_step = 0;
   int64_t def_n_old = 0;
   double prebinned_step = 0;

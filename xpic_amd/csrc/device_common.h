@@ -13,6 +13,16 @@ __device__ inline double bound_periodic(double s, double L)
   return s;
 }
 
+// the same values without branches (both folds are formed, one is selected): for kernels that are bound by instruction
+// issue, where three divergent branches per particle cost more than six additions
+__device__ inline double bound_periodic_sel(double s, double L)
+{
+  const double lo = L - (0.0 - s), hi = 0.0 + (s - L);
+  double r = s > L ? hi : s;
+  r = s < 0.0 ? lo : r;
+  return r;
+}
+
 // (x / dx, y / dy, z / dz).  P2: all three spacings are powers of two (GridDev::pow2) and the hot kernels are
 // instantiated for that case with the exact multiplication by the reciprocal: the same bits at a fraction of the cost
 // of three fp64 divisions per position.

@@ -215,7 +215,7 @@ struct PrefetchIdx {
   int start, cnt;
   int src, srcx;   // source index of slot start + lane / start + kCP + lane
 };
-constexpr long kGatherWindow = 1L << 28; // a record's old index lies within this many slots of its new one (checked by k_index)
+constexpr long kGatherWindow = 1L << 28; // the 32-bit offsets of the gather reach this far below and above the pencil's first slot
 
 // B neighbourhood of cell (cx,cy,cz) = every B value a CIC gather from inside that cell can touch:
 //   Bx at (xn in cx..cx+1, ys in cy-1..cy+1, zs in cz-1..cz+1)   -> [ 0,18): (kl*3 + jl)*2 + i
@@ -244,7 +244,7 @@ template <bool P2, bool FX, bool GA>
 __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, SortDev s, const double* __restrict__ B,
   double* currI, double* matL, const unsigned short* __restrict__ dtab, const int* __restrict__ linetab, const int* __restrict__ cowr, double q, double m,
   double mpw, int cy0, int cystep, int ncy, int cz0, int czstep, int my_order, int ncol_y, int per_y, int per_z, int first_sort,
-  int alias_rows, unsigned long long zord, double step, int* __restrict__ gerr, int ga_store)
+  int alias_rows, unsigned long long zord, double step, int* __restrict__ gerr, int ga_store, int bucket_cap)
 {
   const int cy = cy0 + (int)(blockIdx.x % ncy) * cystep;
   const int cz = cz0 + (int)(blockIdx.x / ncy) * czstep;
@@ -355,8 +355,8 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     }
   };
   // ---- gathering form.  Addresses: 32-bit byte offsets from two wave-uniform bases per array -- the old-order arrays from
-  // kGatherWindow slots below the pencil's first slot (a record's old index is within that window of its new one: k_index
-  // checks it), the new-order arrays from the pencil's first slot -- so that one shifted index serves the six arrays of a
+  // kGatherWindow slots below the pencil's first slot (records further away take 64-bit addresses, lane by lane), the
+  // new-order arrays from the pencil's first slot -- so that one shifted index serves the six arrays of a
   // record (64-bit address arithmetic per array cost 24 vector instructions per pass).
   using UniformIntsG = const __attribute__((address_space(4))) int*;
   const long pn0 = GA ? (long)((UniformIntsG)(s.cell_start + pencil0))[0] : 0;
@@ -368,16 +368,14 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     rb[a] = reinterpret_cast<const char*>(s.r[a] + gb); rb[3 + a] = reinterpret_cast<const char*>(s.v[a] + gb);
     wb[a] = reinterpret_cast<char*>(s.r2[a] + pn0); wb[3 + a] = reinterpret_cast<char*>(s.v2[a] + pn0);
   }
-  // (the pencils of the box's first and last z-plane also receive the particles that crossed the periodic boundary, whose
-  // old index is an array length away: they take plain 64-bit addresses -- 2 of nz planes)
-  // (k_index has checked |old - new| < 2^27 for these pencils; with fewer than 2^27 particles in the pencil every offset from
-  // `gb` stays below 2^29 slots = 2^32 bytes)
   const long pencil_pop = GA ? (long)((UniformIntsG)(s.cell_start + pencil0))[g.nx] - pn0 : 0;
-  const bool near_only = cz > 0 && cz < g.nzl - 1 && pencil_pop < (1L << 27);
-  if (GA && pencil_pop >= (1L << 29) && threadIdx.x == 0) atomicOr(gerr, 1); // the sorted copy's 32-bit offsets: host falls back
+  if (GA && pencil_pop >= (1L << 29) && threadIdx.x == 0) atomicOr(gerr, 1); // the sorted copy's 32-bit offsets: the host fails the step
+  // A record further than 2^29 slots above `gb` (what crossed the periodic z-boundary arrives from the other end of the
+  // array; a particle that jumped dozens of planes) takes a plain 64-bit address: per lane, rare.
   auto gather = [&](int srcidx, double (&rec)[6]) {
-    if (near_only) {
-      const unsigned off8 = (unsigned)((long)srcidx - gb) << 3;
+    const unsigned long rel = (unsigned long)((long)srcidx - gb);
+    if (rel < (1ul << 29)) {
+      const unsigned off8 = (unsigned)rel << 3;
 #pragma unroll
       for (int a = 0; a < 6; ++a) rec[a] = *reinterpret_cast<const double*>(rb[a] + (size_t)off8);
     }
@@ -385,6 +383,10 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
 #pragma unroll
       for (int a = 0; a < 3; ++a) { rec[a] = s.r[a][srcidx]; rec[3 + a] = s.v[a][srcidx]; }
     }
+  };
+  // where slot i of cell cx finds its source index: the binning's bucket of the cell, or the index k_index built
+  auto idx_of = [&](int cx, int start, int i) {
+    return bucket_cap > 0 ? s.bucket[(pencil0 + cx) * bucket_cap + i] : s.src[(long)start + i];
   };
   // two cells ahead: the cell's range and the source indices of its first 2 kCP slots (the index -> record chain of one
   // cell ahead was 2.6 ms of the assembly)
@@ -395,8 +397,8 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     UniformIntsG cs = (UniformIntsG)(s.cell_start + pencil0);
     pi.start = cs[cxu];
     pi.cnt = cs[cxu + 1] - pi.start;
-    if (lane < min(kCP, pi.cnt)) pi.src = s.src[(long)pi.start + lane];
-    if (lane < min(kCP, pi.cnt - kCP)) pi.srcx = s.src[(long)pi.start + kCP + lane];
+    if (lane < min(kCP, pi.cnt)) pi.src = idx_of(cxu, pi.start, lane);
+    if (lane < min(kCP, pi.cnt - kCP)) pi.srcx = idx_of(cxu, pi.start, kCP + lane);
   };
   auto prefetch_rec = [&](int i, const PrefetchIdx& pi, Prefetch& pf) {
     pf.start = pi.start; pf.cnt = pi.cnt; pf.b = 0.0; pf.srcx = pi.srcx;
@@ -411,9 +413,9 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     cur[0] += cur[3] * step;
     cur[1] += cur[4] * step;
     cur[2] += cur[5] * step;
-    cur[0] = bound_periodic(cur[0], g.Lx);
-    cur[1] = bound_periodic(cur[1], g.Ly);
-    cur[2] = bound_periodic(cur[2], g.Lz);
+    cur[0] = bound_periodic_sel(cur[0], g.Lx);
+    cur[1] = bound_periodic_sel(cur[1], g.Ly);
+    cur[2] = bound_periodic_sel(cur[2], g.Lz);
     if (!ga_store) return; // (xpic_set_fused_rebin 2: k_second_push writes the sorted copy)
     const unsigned off8 = (unsigned)drel << 3;
 #if FILL_GA_EXP != 1
@@ -589,7 +591,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
             const int sv = __shfl(srcx_cur, q & 63, 64);
             if (get) {
               fresh = handed + fr;
-              const int srcidx = FILL_GA_NOCHAIN ? start + handed + fr : (q >= 0 && q < kCP ? sv : s.src[(long)start + handed + fr]);
+              const int srcidx = FILL_GA_NOCHAIN ? start + handed + fr : (q >= 0 && q < kCP ? sv : idx_of(cell_x(i), start, handed + fr));
               gather(srcidx, cur);
             }
           }
@@ -1729,7 +1731,7 @@ int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, d
       hipLaunchKernelGGL(kern, dim3((unsigned)(ncy * ncz)), dim3(kThreads), 0, c->stream, g, s.d, B,
         currI_sort, matL, dtab, c->ltab, c->ltab + kLines, s.par.q, s.par.m,
         s.par.n / (double)s.par.Np, cy0, cys, ncy, cz0, czs, pos * ncol_y + a, ncol_y, per_y, per_z, first_sort && !alias ? 1 : 0,
-        alias ? 1 : 0, zord, s.def_step, c->fill_err, store_sorted ? 1 : 0);
+        alias ? 1 : 0, zord, s.def_step, c->fill_err, store_sorted ? 1 : 0, ga && s.def_bucket ? s.d.bucket_cap : 0);
     }
   }
   if (post_ghost_rows && nseq <= nboundary) XPIC_CALL(matL_ghost_rows_post(c)); // (a slab whose every colour is a boundary colour)

@@ -4,6 +4,10 @@
 #include <cstdio>
 #include <cstdlib>
 
+#ifndef XPIC_BUCKET_CAP
+#define XPIC_BUCKET_CAP 128 // source indices a cell's bucket holds (deferred scatter); a fuller cell sends the step through k_index
+#endif
+
 #include "common.h"
 #include "device_common.h"
 
@@ -94,6 +98,12 @@ __device__ __forceinline__ void bin_particle(const GridDev& g, const SortDev& s,
   base = __shfl(base, my_leader, 64);
   const int rank = c >= 0 ? (solo ? solo_rank : base + rank_in) : 0;
   s.rank[p] = rank;
+  // the deferred scatter's index, written on the spot: slot `rank` of the cell's bucket (no second pass over the keys; a
+  // cell with more arrivals than the bucket holds raises the flag and the step falls back to k_index)
+  if (s.bucket_cap > 0 && c >= 0) {
+    if (rank < s.bucket_cap) s.bucket[(long)c * s.bucket_cap + rank] = (int)p;
+    else atomicOr(s.bucket + s.ncell * s.bucket_cap, 1);
+  }
 }
 
 // pass 1 of update_cells: (BorisPush::update_r) + correct_coordinates + new cell + arrival rank in it;
@@ -180,22 +190,13 @@ __global__ void __launch_bounds__(kBlock) k_scatter(GridDev g, SortDev s, int64_
 }
 
 // deferred scatter: instead of moving the records, note for every slot of the new order where its record sits in the old
-// (flag: set when a record's old index is not within `window` slots of its new one in a pencil that addresses its records
-// with 32-bit offsets -- every pencil but those of the first and the last z-plane, which also receive what crossed the
-// periodic boundary from the other end of the array; the host then scatters as before)
-__global__ void __launch_bounds__(kBlock) k_index(SortDev s, int64_t n, long plane_cells, int nzl, long window, int* flag)
+__global__ void __launch_bounds__(kBlock) k_index(SortDev s, int64_t n)
 {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= n) return;
   const int c = s.cell[p];
   if (c < 0) return;
-  const int64_t d = (int64_t)s.cell_start[c] + s.rank[p];
-  s.src[d] = (int)p;
-  const int64_t far = d > p ? d - p : p - d;
-  if (far >= window) {
-    const long cz = c / plane_cells;
-    if (cz > 0 && cz < nzl - 1) atomicOr(flag, 1);
-  }
+  s.src[(int64_t)s.cell_start[c] + s.rank[p]] = (int)p;
 }
 
 // ---- exclusive scan of the per-cell counts (3 small kernels; N ints, negligible next to particles) ----
@@ -724,7 +725,19 @@ int sort_alloc(xpic_ctx* c, Sort& s, int64_t cap)
   XPIC_HIP(hipMalloc(&s.d.cell, sizeof(int) * cap));
   XPIC_HIP(hipMalloc(&s.d.rank, sizeof(int) * cap));
   s.d.src = nullptr;
-  if (c->scheme != XPIC_BASIC) XPIC_HIP(hipMalloc(&s.d.src, sizeof(int) * (cap + 1))); // deferred scatter of the ecsim / ecsimcorr step
+  s.d.bucket = nullptr; s.d.bucket_cap = 0; s.d.ncell = c->ncell;
+  if (c->scheme != XPIC_BASIC) {
+    XPIC_HIP(hipMalloc(&s.d.src, sizeof(int) * (cap + 1))); // deferred scatter of the ecsim / ecsimcorr step
+    // buckets of XPIC_BUCKET_CAP source indices per cell, on a single slab, where they cost at most as much as the particles' keys
+    // (twice the mean occupancy the capacity allows, in steps of 32, at most XPIC_BUCKET_CAP: a Poisson cell never gets there)
+    long bcap = ((2 * cap / c->ncell + 32 + 31) / 32) * 32;
+    if (bcap > XPIC_BUCKET_CAP) bcap = XPIC_BUCKET_CAP;
+    if (c->g.G == 0 && bcap > 0) {
+      XPIC_HIP(hipMalloc(&s.d.bucket, sizeof(int) * (c->ncell * bcap + 1)));
+      XPIC_HIP(hipMemsetAsync(s.d.bucket + c->ncell * bcap, 0, sizeof(int), c->stream));
+      s.d.bucket_cap = (int)bcap;
+    }
+  }
   XPIC_HIP(hipMalloc(&s.d.cell_count, sizeof(int) * (c->ncell + 1)));
   // + kCellStartPad: the pencil kernels read a fixed number of entries ahead of the cell they are at (never used past
   // the pencil's end, but the reads must land in the allocation)
@@ -751,7 +764,7 @@ void sort_free(Sort& s)
   for (int a = 0; a < 3; ++a) {
     (void)hipFree(s.d.r[a]); (void)hipFree(s.d.v[a]); (void)hipFree(s.d.r2[a]); (void)hipFree(s.d.v2[a]);
   }
-  (void)hipFree(s.d.cell); (void)hipFree(s.d.rank); (void)hipFree(s.d.src); (void)hipFree(s.d.cell_count); (void)hipFree(s.d.cell_start);
+  (void)hipFree(s.d.cell); (void)hipFree(s.d.rank); (void)hipFree(s.d.src); (void)hipFree(s.d.bucket); (void)hipFree(s.d.cell_count); (void)hipFree(s.d.cell_start);
   (void)hipFree(s.J); (void)hipFree(s.currI); (void)hipFree(s.currJe); (void)hipFree(s.rho);
   (void)hipFree(s.mig_send[0]); (void)hipFree(s.mig_send[1]); (void)hipFree(s.mig_recv);
   (void)hipFree(s.mig_cell); (void)hipFree(s.mig_rank); (void)hipFree(s.mig_count);
@@ -820,12 +833,17 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap, bool defer)
   Migr mg = make_migr(c, s);
   if (!prebinned) {
     XPIC_HIP(hipMemsetAsync(s.d.cell_count, 0, sizeof(int) * (c->ncell + 1), c->stream));
+    if (s.d.bucket_cap > 0) XPIC_HIP(hipMemsetAsync(s.d.bucket + c->ncell * s.d.bucket_cap, 0, sizeof(int), c->stream));
     if (mig) XPIC_HIP(hipMemsetAsync(s.mig_count, 0, sizeof(int) * 4, c->stream));
   }
   if (s.n > 0 && !prebinned) {
     Timed t(c, "move_bin");
     const unsigned nb = pgrid(s.n);
-#define LAUNCH(M, W, G) hipLaunchKernelGGL((k_move_bin<M, W, G>), dim3(nb), dim3(kBlock), 0, c->stream, c->g, s.d, s.n, step, mg)
+    // (the buckets are filled only for a binning that a deferred scatter will read)
+    SortDev sd = s.d;
+    s.bucket_written = defer && !mig && s.d.bucket_cap > 0 && c->fused_rebin == 1;
+    if (!s.bucket_written) sd.bucket_cap = 0;
+#define LAUNCH(M, W, G) hipLaunchKernelGGL((k_move_bin<M, W, G>), dim3(nb), dim3(kBlock), 0, c->stream, c->g, sd, s.n, step, mg)
     if (mig) {
       if (move && wrap) LAUNCH(true, true, true);
       else if (move) LAUNCH(true, false, true);
@@ -902,24 +920,22 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap, bool defer)
   // Deferred (the ecsim step on a single slab): the records stay where they are; slot d of the new order learns its
   // source, and the mass-matrix assembly -- which reads every particle anyway -- moves, wraps and writes it (ecsim.hip).
   if (defer && !mig && s.n > 0 && s.d.src) {
-    int* flag = s.d.src + s.cap; // one word behind the index
-    {
+    // the binning filled the cells' buckets (bin_particle) unless a cell overflowed its bucket: then the index is built
+    // from the keys (k_index: 12 B per particle)
+    bool use_bucket = false;
+    if (s.d.bucket_cap > 0) {
+      int* hflag = (int*)(c->red_host + 61);
+      XPIC_HIP(hipMemcpyAsync(hflag, s.d.bucket + c->ncell * s.d.bucket_cap, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      XPIC_HIP(hipStreamSynchronize(c->stream));
+      use_bucket = *hflag == 0 && s.bucket_written && c->fused_rebin == 1; // (mode 2's second push reads the index k_index builds)
+    }
+    if (!use_bucket) {
       Timed t(c, "index");
-      XPIC_HIP(hipMemsetAsync(flag, 0, sizeof(int), c->stream));
-      hipLaunchKernelGGL(k_index, dim3(pgrid(s.n)), dim3(kBlock), 0, c->stream, s.d, s.n, (long)c->g.plane, c->g.nzl, 1L << 27, flag);
+      hipLaunchKernelGGL(k_index, dim3(pgrid(s.n)), dim3(kBlock), 0, c->stream, s.d, s.n);
       XPIC_HIP(hipGetLastError());
     }
-    int* hflag = (int*)(c->red_host + 61);
-    XPIC_HIP(hipMemcpyAsync(hflag, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    XPIC_HIP(hipStreamSynchronize(c->stream));
-    s.deferred = true; s.def_step = step; s.def_wrap = wrap; s.def_n_old = s.n;
+    s.deferred = true; s.def_step = step; s.def_wrap = wrap; s.def_n_old = s.n; s.def_bucket = use_bucket;
     s.n = total;
-    if (*hflag != 0) {
-      if (getenv("XPIC_DEBUG_INDEX")) fprintf(stderr, "k_index flag %d (n %ld total %d)\n", *hflag, (long)s.def_n_old, total);
-      // a record lies further from its slot than the gathering assembly's offsets reach: scatter now (s.n is the new count;
-      // the scatter walks the old one)
-      return sort_materialize(c, s);
-    }
     return 0;
   }
   if (s.n > 0) XPIC_CALL(launch_scatter(c, s, s.n, step, wrap));
@@ -1014,10 +1030,15 @@ int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B, bo
   Migr mg = make_migr(c, s);
   if (prebin) {
     XPIC_HIP(hipMemsetAsync(s.d.cell_count, 0, sizeof(int) * (c->ncell + 1), c->stream));
+    if (s.d.bucket_cap > 0) XPIC_HIP(hipMemsetAsync(s.d.bucket + c->ncell * s.d.bucket_cap, 0, sizeof(int), c->stream));
     if (mig) XPIC_HIP(hipMemsetAsync(s.mig_count, 0, sizeof(int) * 4, c->stream));
   }
+  // (the pre-binning fills the buckets when the next step's re-binning will defer its scatter into the assembly)
+  SortDev sd = s.d;
+  const bool wbucket = prebin && !mig && s.d.bucket_cap > 0 && c->fused_rebin == 1 && c->scheme == XPIC_ECSIM;
+  if (!wbucket) sd.bucket_cap = 0;
 #define LAUNCH(P, G, Q, A) hipLaunchKernelGGL((k_second_push<P, G, Q, A>), dim3((unsigned)(8 * chunk)), dim3(kSPRound), 0, c->stream, \
-    c->g, s.d, E, B, s.par.q / s.par.m, npencil, chunk, mg, s.def_step)
+    c->g, sd, E, B, s.par.q / s.par.m, npencil, chunk, mg, s.def_step)
   if (ga) {
     if (c->g.pow2) { if (prebin) LAUNCH(true, false, true, true); else LAUNCH(false, false, true, true); }
     else { if (prebin) LAUNCH(true, false, false, true); else LAUNCH(false, false, false, true); }
@@ -1039,6 +1060,7 @@ int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B, bo
     s.prebinned = true;
     s.prebinned_step = c->g.dt;
     s.prebinned_n = s.n;
+    s.bucket_written = wbucket;
   }
   return 0;
 }
