@@ -228,6 +228,54 @@ def test_deferred_scatter_equals_scatter_first(oracle, grid, mode):
         assert np.abs(a - g.get_field(fid)).max() <= 1e-8 * np.abs(a).max()
 
 
+@pytest.mark.parametrize("case", ["overflow", "other_kernel", "unfused"])
+def test_keyless_prebinning_falls_back(oracle, case):
+    """The second push's pre-binning writes buckets and counts but no keys (cell[], rank[]) when the next re-binning will be
+    read by the gathering assembly.  Three ways the keys are needed after all, each rebuilt by a binning pass over the
+    un-moved records (particles.hip: rebuild_keys) and each compared with the scatter-first run and the oracle:
+    a cell with more arrivals than a bucket holds (k_index), another assembly kernel chosen between two steps (the plain
+    scatter resolves the deferral), the deferral switched off between two steps."""
+    import xpic_amd as X
+
+    n, d, dt = GRID_P2FX
+    sorts = [(8, 1.0, -1.0, 1.0)]
+    o, g = make_pair(oracle, "ecsim", n, d, 1.0, sorts, B0=(0.1, 0.0, 0.3), vth=0.2, ppc=9)
+    _, h = make_pair(oracle, "ecsim", n, d, 1.0, sorts, B0=(0.1, 0.0, 0.3), vth=0.2, ppc=9)
+    if case == "overflow":  # cold particles: the cell stays above the bucket capacity step after step
+        rng = np.random.default_rng(5)
+        heavy = np.hstack([(np.array([3, 2, 1]) + 0.25 + 0.5 * rng.random((300, 3))) * np.array(d), rng.normal(0, 1e-3, (300, 3))])
+        for sim in (o, g, h):
+            assert sim.add_particles(0, heavy) == 300
+    h.set_fused_rebin(0)
+    for sim in (o, g, h):
+        sim.set_tolerances(1e-12, 1e-50, 400)
+    g.profile_enable(True)
+    for t in range(4):
+        if t == 2 and case == "other_kernel":
+            g.set_fill_kernel(1)
+        if t == 2 and case == "unfused":
+            g.set_fused_rebin(0)
+        g.profile_reset()
+        assert o.step() >= 0
+        g.step()
+        h.step()
+        rebuilt = g.profile_get("move_bin")[0]
+        if t == 0:
+            assert rebuilt == 1  # the first step bins from scratch
+        elif t == 1:
+            assert rebuilt == (1 if case == "overflow" else 0), case  # the key-less pre-binning was enough, or overflowed
+        elif t == 2:
+            assert rebuilt == (0 if case == "overflow" else 1), case  # (after an overflow the pre-binnings write keys again)
+        pg, cg = canon(*g.particles(0))
+        ph, ch = canon(*h.particles(0))
+        po, co = canon(*o.particles(0))
+        assert np.array_equal(cg, ch) and np.array_equal(cg, co), t
+        assert np.abs(pg - ph).max() <= 1e-12 and np.abs(pg - po).max() <= 1e-9, t
+    for name, fid in (("E", X.E), ("B", X.B)):
+        a = o.get_field(name)
+        assert np.abs(a - g.get_field(fid)).max() <= 1e-8 * np.abs(a).max()
+
+
 def test_lstencil_layout_is_shared(oracle):
     import xpic_amd as X
     import ctypes as C

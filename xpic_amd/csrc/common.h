@@ -140,6 +140,8 @@ struct Sort {
   // un-moved records; the mass-matrix assembly reads them through src, applies the move and writes the sorted records into
   // r2, v2 on its way (ecsim.hip) -- the scatter pass of the re-binning is gone.  Everything else calls sort_materialize first.
   bool bucket_written = false; // the binning whose keys cell[] / rank[] hold also filled the buckets
+  bool keys_valid = true;      // false: that binning wrote the buckets and the counts only (particles.hip: rebuild_keys)
+  bool bucket_off = false;     // a cell overflowed its bucket once: pre-binnings write the keys again
   bool deferred = false, def_wrap = false, def_bucket = false; // def_bucket: the assembly reads the binning's buckets, not src
   double def_step = 0;
   int64_t def_n_old = 0;

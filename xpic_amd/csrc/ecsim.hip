@@ -372,16 +372,27 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
   if (GA && pencil_pop >= (1L << 29) && threadIdx.x == 0) atomicOr(gerr, 1); // the sorted copy's 32-bit offsets: the host fails the step
   // A record further than 2^29 slots above `gb` (what crossed the periodic z-boundary arrives from the other end of the
   // array; a particle that jumped dozens of planes) takes a plain 64-bit address: per lane, rare.
-  auto gather = [&](int srcidx, double (&rec)[6]) {
+  // Every lane of the wave calls it (`on`: this lane wants a record).  The far records are fetched in a branch the WHOLE
+  // wave takes or skips, complete with its wait: as the two arms of one per-lane branch the arms' loads shared their
+  // destination registers, and the compiler guarded that with s_waitcnt vmcnt(0) in front of the near arm's loads -- the
+  // memory counter being in order, a wait for the six stores of the sorted copy issued a phase 1 before (8 ms per assembly).
+  auto gather = [&](int srcidx, bool on, double (&rec)[6]) {
     const unsigned long rel = (unsigned long)((long)srcidx - gb);
-    if (rel < (1ul << 29)) {
+    const bool near = rel < (1ul << 29);
+    if (on && near) {
       const unsigned off8 = (unsigned)rel << 3;
 #pragma unroll
       for (int a = 0; a < 6; ++a) rec[a] = *reinterpret_cast<const double*>(rb[a] + (size_t)off8);
     }
-    else {
+    if (__builtin_expect(__ballot(on && !near) != 0, 0)) {
+      double far[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      if (on && !near) {
 #pragma unroll
-      for (int a = 0; a < 3; ++a) { rec[a] = s.r[a][srcidx]; rec[3 + a] = s.v[a][srcidx]; }
+        for (int a = 0; a < 3; ++a) { far[a] = s.r[a][srcidx]; far[3 + a] = s.v[a][srcidx]; }
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) rec[a] = (on && !near) ? far[a] : rec[a];
     }
   };
   // where slot i of cell cx finds its source index: the binning's bucket of the cell, or the index k_index built
@@ -404,7 +415,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     pf.start = pi.start; pf.cnt = pi.cnt; pf.b = 0.0; pf.srcx = pi.srcx;
     if (i >= g.nx) return;
     pf.b = brow ? brow[g.wx(cell_x(i) + box)] : 0.0;
-    if (lane < min(kCP, pf.cnt)) gather(FILL_GA_NOCHAIN ? pf.start + lane : pi.src, pf.p);
+    gather(FILL_GA_NOCHAIN ? pf.start + lane : pi.src, lane < min(kCP, pf.cnt), pf.p);
   };
   // a record that has just arrived from the old order is moved, wrapped (k_scatter's arithmetic, bit for bit) and written
   // to its slot d of the new order.  (Wrapping only in the cells on the box's boundary is wrong: a particle that moves
@@ -588,12 +599,20 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
             // the second pass's source indices came with the cell (srcx: slot kCP + lane); the lane that takes slot
             // handed + fr fetches the index from lane handed + fr - kCP (every lane takes part in the shuffle)
             const int q = handed + fr - kCP;
-            const int sv = __shfl(srcx_cur, q & 63, 64);
-            if (get) {
-              fresh = handed + fr;
-              const int srcidx = FILL_GA_NOCHAIN ? start + handed + fr : (q >= 0 && q < kCP ? sv : idx_of(cell_x(i), start, handed + fr));
-              gather(srcidx, cur);
+            int srcidx = __shfl(srcx_cur, q & 63, 64);
+            // a cell's third pass (slots beyond 2 kCP) reads its indices here: a branch of the whole wave that ends with
+            // its own wait (merged into the common path, the load brought a vmcnt(0) -- a wait for this pass's stores -- to
+            // every refill)
+            const bool late = get && !(q >= 0 && q < kCP);
+            if (__builtin_expect(__ballot(late) != 0, 0)) {
+              int t = 0;
+              if (late) t = idx_of(cell_x(i), start, handed + fr);
+              __builtin_amdgcn_s_waitcnt(0x0F70);
+              srcidx = late ? t : srcidx;
             }
+            if (FILL_GA_NOCHAIN) srcidx = start + handed + fr;
+            if (get) fresh = handed + fr;
+            gather(srcidx, get, cur);
           }
           else if (get) {
             const long p = (long)start + handed + fr;

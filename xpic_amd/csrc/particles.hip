@@ -69,7 +69,7 @@ __device__ __forceinline__ void bin_particle(const GridDev& g, const SortDev& s,
       c = -1;
     }
   }
-  s.cell[p] = c;
+  if (s.cell) s.cell[p] = c; // (null: the buckets alone carry this binning, see ecsim_second_push)
   // Arrival rank inside the new cell.  The input is (nearly) cell-sorted, so a wave sees a handful of distinct
   // cells: the lanes are grouped by cell with ballots, then ONE atomic instruction carries the returning add of
   // every group's first lane (one memory round trip per wave, not one per distinct cell).
@@ -97,7 +97,7 @@ __device__ __forceinline__ void bin_particle(const GridDev& g, const SortDev& s,
   if (c >= 0 && !solo && lane == my_leader) base = atomicAdd(&s.cell_count[c], gsize);
   base = __shfl(base, my_leader, 64);
   const int rank = c >= 0 ? (solo ? solo_rank : base + rank_in) : 0;
-  s.rank[p] = rank;
+  if (s.cell) s.rank[p] = rank;
   // the deferred scatter's index, written on the spot: slot `rank` of the cell's bucket (no second pass over the keys; a
   // cell with more arrivals than the bucket holds raises the flag and the step falls back to k_index)
   if (s.bucket_cap > 0 && c >= 0) {
@@ -800,12 +800,31 @@ static int launch_scatter(xpic_ctx* c, Sort& s, int64_t n_old, double step, bool
   return 0;
 }
 
+// The pre-binning of ecsim_second_push wrote buckets but no keys (cell[], rank[]: 8 B per particle that only the scatter and
+// k_index read) and one of those two is needed after all: a cell overflowed its bucket, or the deferral is resolved by the
+// plain scatter.  The records still lie un-moved in the old order, so the binning pass is simply run again (its counts equal
+// the ones cell_start was scanned from; the ranks are another valid numbering of the same cells).
+static int rebuild_keys(xpic_ctx* c, Sort& s, int64_t n_old, double step)
+{
+  Timed t(c, "move_bin");
+  XPIC_HIP(hipMemsetAsync(s.d.cell_count, 0, sizeof(int) * (c->ncell + 1), c->stream));
+  SortDev sd = s.d;
+  sd.bucket_cap = 0;
+  hipLaunchKernelGGL((k_move_bin<true, true, false>), dim3(pgrid(n_old)), dim3(kBlock), 0, c->stream, c->g, sd, n_old, step, Migr{});
+  XPIC_HIP(hipGetLastError());
+  s.keys_valid = true;
+  return 0;
+}
+
 // a deferred re-binning whose assembly never came (or was not the gathering kind): do the scatter now
 int sort_materialize(xpic_ctx* c, Sort& s)
 {
   if (!s.deferred) return 0;
   s.deferred = false;
-  if (s.def_n_old > 0) XPIC_CALL(launch_scatter(c, s, s.def_n_old, s.def_step, s.def_wrap));
+  if (s.def_n_old > 0) {
+    if (!s.keys_valid) XPIC_CALL(rebuild_keys(c, s, s.def_n_old, s.def_step));
+    XPIC_CALL(launch_scatter(c, s, s.def_n_old, s.def_step, s.def_wrap));
+  }
   for (int a = 0; a < 3; ++a) {
     std::swap(s.d.r[a], s.d.r2[a]);
     std::swap(s.d.v[a], s.d.v2[a]);
@@ -836,6 +855,7 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap, bool defer)
     if (s.d.bucket_cap > 0) XPIC_HIP(hipMemsetAsync(s.d.bucket + c->ncell * s.d.bucket_cap, 0, sizeof(int), c->stream));
     if (mig) XPIC_HIP(hipMemsetAsync(s.mig_count, 0, sizeof(int) * 4, c->stream));
   }
+  if (!prebinned) s.keys_valid = true; // (k_move_bin below writes them; an un-consumed key-less pre-binning is forgotten)
   if (s.n > 0 && !prebinned) {
     Timed t(c, "move_bin");
     const unsigned nb = pgrid(s.n);
@@ -929,6 +949,11 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap, bool defer)
       XPIC_HIP(hipStreamSynchronize(c->stream));
       use_bucket = *hflag == 0 && s.bucket_written && c->fused_rebin == 1; // (mode 2's second push reads the index k_index builds)
     }
+    if (!use_bucket && !s.keys_valid) {
+      // (a cell took more arrivals than a bucket holds: this sort's pre-binnings write the keys from now on)
+      s.bucket_off = true;
+      XPIC_CALL(rebuild_keys(c, s, s.n, step));
+    }
     if (!use_bucket) {
       Timed t(c, "index");
       hipLaunchKernelGGL(k_index, dim3(pgrid(s.n)), dim3(kBlock), 0, c->stream, s.d, s.n);
@@ -938,6 +963,7 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap, bool defer)
     s.n = total;
     return 0;
   }
+  if (s.n > 0 && !s.keys_valid) XPIC_CALL(rebuild_keys(c, s, s.n, step)); // (a key-less pre-binning that is not deferred after all)
   if (s.n > 0) XPIC_CALL(launch_scatter(c, s, s.n, step, wrap));
   if (n_in > 0) {
     hipLaunchKernelGGL(k_scatter_incoming, dim3(pgrid(n_in)), dim3(kBlock), 0, c->stream, s.d, s.mig_recv, n_in, s.mig_cell, s.mig_rank);
@@ -1037,6 +1063,10 @@ int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B, bo
   SortDev sd = s.d;
   const bool wbucket = prebin && !mig && s.d.bucket_cap > 0 && c->fused_rebin == 1 && c->scheme == XPIC_ECSIM;
   if (!wbucket) sd.bucket_cap = 0;
+  // ... and then the buckets are ALL the next re-binning reads: the keys stay unwritten (8 of the 84 B per particle), unless
+  // this sort has overflowed a bucket before or the assembly that follows is not the gathering kind
+  const bool keyless = wbucket && !s.bucket_off && c->fill_kernel == 0;
+  if (keyless) { sd.cell = nullptr; sd.rank = nullptr; }
 #define LAUNCH(P, G, Q, A) hipLaunchKernelGGL((k_second_push<P, G, Q, A>), dim3((unsigned)(8 * chunk)), dim3(kSPRound), 0, c->stream, \
     c->g, sd, E, B, s.par.q / s.par.m, npencil, chunk, mg, s.def_step)
   if (ga) {
@@ -1061,6 +1091,7 @@ int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B, bo
     s.prebinned_step = c->g.dt;
     s.prebinned_n = s.n;
     s.bucket_written = wbucket;
+    s.keys_valid = !keyless;
   }
   return 0;
 }
