@@ -202,27 +202,30 @@ def test_long_pencils_and_odd_colour_periods(oracle):
         assert np.array_equal(co, cg) and np.abs(po - pg).max() < 1e-9
 
 
+@pytest.mark.parametrize("table", ["precomposed", "overflows"])
 @pytest.mark.parametrize("scheme", ["basic", "ecsimcorr"])
-def test_esirkepov_rounds_ragged_pencils(oracle, scheme):
+def test_esirkepov_rounds_ragged_pencils(oracle, scheme, table):
     """The Esirkepov kernels pack the particles of up to 8 consecutive cells into one round of 240 (160) stage columns:
     a cell of 700 particles (several rounds of its own, the rest sharing a round with its neighbours), one of exactly
     240, runs of empty cells longer than a round's 8 cells, cells of 1..5 particles (all padding), a pencil that ends in
-    a full cell, and particles fast enough to leave the 4-node box (the cooperative slow path)."""
+    a full cell, and particles fast enough to leave the 4-node box (the cooperative slow path).  The rounds come out of the
+    table k_esk_rounds composes beforehand; `overflows` adds a cell of 8 000 particles -- more rounds than the table holds for
+    its pencil (nx + 11 = 32), so the pushes return at once and are launched again in the form that composes for itself."""
     import xpic_amd as X
 
     n, d = (21, 7, 6), (0.5, 0.4, 0.5)
     dt = 0.05 if scheme == "basic" else 0.2
     o, g = pair(oracle, scheme, n, d, dt)
     o.add_sort(10, 1.0, -1.0, 1.0)
-    g.add_sort(10, 1.0, -1.0, 1.0, capacity=20000)
+    g.add_sort(10, 1.0, -1.0, 1.0, capacity=30000)
     rng = np.random.default_rng(5)
     pts = []
-    cells = [((3, 2, 1), 700), ((4, 2, 1), 37), ((5, 2, 1), 240), ((20, 2, 1), 130), ((0, 2, 1), 3),
+    cells = ([((7, 4, 3), 8000)] if table == "overflows" else []) + [((3, 2, 1), 700), ((4, 2, 1), 37), ((5, 2, 1), 240), ((20, 2, 1), 130), ((0, 2, 1), 3),
              ((19, 6, 5), 64), ((20, 6, 5), 65), ((0, 0, 0), 1), ((11, 3, 3), 5), ((12, 3, 3), 2), ((13, 3, 3), 241)]
     for cell, cnt in cells:
         r = (np.array(cell) + rng.random((cnt, 3))) * np.array(d)
         v = rng.normal(0, 0.3, (cnt, 3))
-        v[: max(1, cnt // 16)] *= 6.0  # a few that move most of a cell in a step
+        v[: max(1, min(cnt, 1000) // 16)] *= 6.0  # a few that move most of a cell in a step
         v = np.clip(v, -0.7 * min(d) / dt, 0.7 * min(d) / dt)  # beyond ~0.8 cell the box of a move exceeds Shape::shape[]
         pts.append(np.hstack([r, v]))
     pts = np.vstack(pts)
@@ -233,9 +236,15 @@ def test_esirkepov_rounds_ragged_pencils(oracle, scheme):
         g.set_field(fid, B)
     for sim in (o, g):
         sim.set_tolerances(1e-11, 1e-50, 300)
-    for t in range(3):
+    g.profile_enable(True)
+    for t in range(3 if table == "precomposed" else 2):  # (the blob's own field throws particles further than a cell in its third step)
         assert o.step() >= 0
+        g.profile_reset()
         g.step()
+        # one launch of every push per step from the table; two (the first returned at once) when a pencil overflows it
+        for ph in (("basic_push",) if scheme == "basic" else ("corr_first_push", "corr_second_push")):
+            # (later steps: the blob has spread along its pencil and may fit)
+            assert g.profile_get(ph)[0] in ((1,) if table == "precomposed" else ((2,) if t == 0 else (1, 2))), (t, ph)
         same_fields(o, g, ["E", "B"], 1e-7)
     po, co = canon(*o.particles(0))
     pg, cg = canon(*g.particles(0))

@@ -395,7 +395,7 @@ int xpic_destroy(xpic_ctx* ctx)
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& s : ctx->sorts) sort_free(s);
   for (int f = 0; f < XPIC_NFIELDS; ++f) (void)hipFree(ctx->field[f]);
-  (void)hipFree(ctx->matL); (void)hipFree(ctx->ltab); (void)hipFree(ctx->fill_err); (void)hipFree(ctx->kry_V); (void)hipFree(ctx->kry_w);
+  (void)hipFree(ctx->matL); (void)hipFree(ctx->ltab); (void)hipFree(ctx->fill_err); (void)hipFree(ctx->kry_V); (void)hipFree(ctx->kry_w); (void)hipFree(ctx->esk_tab);
   (void)hipFree(ctx->kry_t); (void)hipFree(ctx->kry_Z); (void)hipFree(ctx->kry_p[0]); (void)hipFree(ctx->kry_p[1]); (void)hipFree(ctx->kry_p[2]);
   (void)hipFree(ctx->red_partial); (void)hipFree(ctx->red_out); (void)hipHostFree(ctx->red_host);
   (void)hipFree(ctx->scan_tmp);

@@ -197,6 +197,9 @@ struct xpic_ctx {
   // Krylov workspace
   double* kry_V = nullptr; // (m+1) vectors
   double* kry_w = nullptr;
+  unsigned* esk_tab = nullptr; // precomposed rounds of the Esirkepov pushes (esirkepov.hip: k_esk_rounds), allocated by the first push
+  size_t esk_tab_bytes = 0;
+  int esk_pre = 1;             // 0: the pushes compose their rounds themselves (XPIC_ESK_PRE=0; the fall-back of a pencil with too many rounds)
   double* kry_t = nullptr; // preconditioner scratch (fp32 copy of its input)
   double* kry_Z = nullptr; // flexible GMRES: the preconditioned basis z_j = P v_j (allocated by the first preconditioned solve)
   double* kry_p[3] = {nullptr, nullptr, nullptr}; // Chebyshev preconditioner work vectors

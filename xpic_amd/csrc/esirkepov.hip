@@ -29,6 +29,7 @@
 //     directly with fp64 atomics (slow path, same arithmetic as the reference's loop).
 //   * The boxes are merged in a circular LDS J window (11 x 4 x 4 nodes per component); the columns the march has
 //     passed leave with one fp64 atomic per node.
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -142,15 +143,89 @@ __device__ inline double lane_value(double v, int src)
 // One round of a pencil: up to kSeg segments, each the (rest of the) particles of one cell.  A cell with more particles
 // than a round holds is continued in the next round (then alone in its round's first segment).
 constexpr int kSegMax = 16;
-struct RoundTab {
+struct RoundTab { // (word order = the order tab_put's threads unpack a RoundPack into)
   int base;            // first cell of the round: the J window's column 0 is node base - 1
+  int pstart;          // first particle of the round: its particles are consecutive in the sort, thread t takes pstart + t
   int nseg, ncols, tcount;
   int adv;             // cells completed by the round: the window moves on by this many columns
   int cell[kSegMax];      // cell - base
-  int start[kSegMax];     // first particle
   int col0[kSegMax + 1];  // first stage column (multiple of 4)
   int toff[kSegMax + 1];  // first thread
 };
+constexpr int kTabWords = 6 + kSegMax + 2 * (kSegMax + 1);
+static_assert(sizeof(RoundTab) == 4 * kTabWords && kTabWords <= 64, "one lane of wave 0 per word");
+
+// The rounds of a pencil depend on cell_start alone, and composing them inside the push was a fifth of its instruction
+// stream (a scalar loop over up to 16 cells, or row shifts and ballots on 8 lanes, once per round and wave).  PRE: a small
+// kernel composes the rounds of every pencil beforehand (k_esk_rounds: one thread per pencil, the same greedy rule) into
+// 64-byte records; the push copies record r + 2 into LDS while round r runs.
+//   bytes 0-3 base, 4-7 pstart, 8 nseg, 9 ncols, 10 tcount, 11 adv, 12-19 cell[16] (4 bits each), 20-36 col0[17], 37-53 toff[17]
+constexpr int kPackDwords = 16;
+constexpr int kPackCell = 12, kPackCol0 = 20, kPackToff = 37;
+constexpr int kSentinels = 3; // records behind a pencil's last round (the push reads two records ahead)
+
+template <int SEG, int COLS>
+__global__ void __launch_bounds__(256) k_esk_rounds(GridDev g, const int* __restrict__ cell_start, unsigned* __restrict__ tabg,
+  int rcap, long npencil, int* overflow)
+{
+  const long pencil = (long)blockIdx.x * 256 + threadIdx.x;
+  if (pencil >= npencil) return;
+  const int* cs = cell_start + pencil * g.nx;
+  uint4* out = reinterpret_cast<uint4*>(tabg + pencil * (long)rcap * kPackDwords);
+  int cur = 0, cur_off = 0, sent = 0;
+  for (int r = 0; sent < kSentinels; ++r) {
+    if (r >= rcap) { atomicOr(overflow, 1); return; } // (cells of several rounds each: the push composes for itself)
+    // compose_scalar's rule (below), word for word
+    const int base = cur;
+    unsigned w[kPackDwords];
+#pragma unroll
+    for (int k = 0; k < kPackDwords; ++k) w[k] = 0u;
+    auto put = [&](int byte, unsigned v) { w[byte >> 2] |= v << ((byte & 3) * 8); };
+    int nseg = 0, cols = 0, tc = 0, pstart = 0;
+    bool open = true;
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) {
+      if (open && base + i < g.nx) {
+        const int c0 = cs[base + i] + (i == 0 ? cur_off : 0);
+        const int rem = cs[base + i + 1] - c0;
+        if (rem <= 0) { cur = base + i + 1; cur_off = 0; }
+        else {
+          const int room = COLS - cols;
+          int take = rem;
+          bool fits = true;
+          if (((rem + 3) & ~3) > room) {
+            if (nseg > 0) fits = false;
+            else take = room;
+          }
+          if (!fits) open = false;
+          else {
+            if (nseg == 0) pstart = c0;
+#pragma unroll
+            for (int k = 0; k < SEG; ++k) // (nseg as a compile-time index: no scratch)
+              if (k == nseg) {
+                w[(kPackCell + k / 2) >> 2] |= (unsigned)i << (((kPackCell + k / 2) & 3) * 8 + (k & 1) * 4);
+                put(kPackCol0 + k, (unsigned)cols);
+                put(kPackToff + k, (unsigned)tc);
+              }
+            ++nseg;
+            cols += (take + 3) & ~3;
+            tc += take;
+            if (take == rem) { cur = base + i + 1; cur_off = 0; }
+            else { cur_off = (i == 0 ? cur_off : 0) + take; cur = base + i; open = false; }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k <= SEG; ++k)
+      if (k == nseg) { put(kPackCol0 + k, (unsigned)cols); put(kPackToff + k, (unsigned)tc); }
+    w[0] = (unsigned)base; w[1] = (unsigned)pstart;
+    w[2] = (unsigned)nseg | (unsigned)cols << 8 | (unsigned)tc << 16 | (unsigned)(cur - base) << 24;
+#pragma unroll
+    for (int k = 0; k < kPackDwords / 4; ++k) out[(long)r * (kPackDwords / 4) + k] = uint4{w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]};
+    if (base >= g.nx) ++sent;
+  }
+}
 
 // what a thread requests one round ahead: its particle of the next round (and, MODE 2, its share of the cells' CIC
 // neighbourhoods)
@@ -164,11 +239,14 @@ struct Ahead {
 using UniformInts = const __attribute__((address_space(4))) int*; // wave-uniform reads of cell_start: scalar loads
 
 // P2: power-of-two spacings (exact reciprocals instead of divisions, device_common.h: scaled_position)
-template <int MODE, bool P2>
+template <int MODE, bool P2, bool PRE>
 __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkepov_push(GridDev g, SortDev s, const double* __restrict__ E,
   const double* __restrict__ B, double* __restrict__ J, double qm, double alpha, double qn_Np, double* pred_w,
-  int* bad_count)
+  int* bad_count, const unsigned* __restrict__ tabg, int rcap)
 {
+  // PRE: a pencil had more rounds than the table holds (k_esk_rounds raised the flag behind the error count): nothing is
+  // touched, the host launches the self-composing form instead
+  if (PRE && bad_count[1] != 0) return;
   // workgroup -> the x-pencil (cy, cz), marched in rounds
   constexpr int kCols = StageDim<MODE>::kCols, kPitch = StageDim<MODE>::kPitch;
   // cells per round.  MODE 0 takes up to 16: BASELINE configs[1] is two species of 16 ppc, and a round of 8 such cells
@@ -254,7 +332,7 @@ __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkep
           }
           if (!fits) open = false;
           else {
-            if (threadIdx.x == 0) { T.cell[nseg] = i; T.start[nseg] = c0; T.col0[nseg] = cols; T.toff[nseg] = tc; }
+            if (threadIdx.x == 0) { T.cell[nseg] = i; T.col0[nseg] = cols; T.toff[nseg] = tc; if (nseg == 0) T.pstart = c0; }
             ++nseg;
             cols += (take + 3) & ~3;
             tc += take;
@@ -301,7 +379,7 @@ __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkep
     if (some && ((__builtin_amdgcn_readlane(cnt, first & (kSeg - 1)) + 3) & ~3) > kCols) {
       // a cell of more than kCols particles: a full round of it, alone
       nseg = 1; ncols = kCols; tcount = kCols;
-      if (wave == 0 && lane == first) { T.cell[0] = first; T.start[0] = first_p; T.col0[0] = 0; T.toff[0] = 0; }
+      if (wave == 0 && lane == first) { T.cell[0] = first; T.pstart = first_p; T.col0[0] = 0; T.toff[0] = 0; }
       cur_off = (first == 0 ? cur_off : 0) + kCols;
       cur = base + first;
     }
@@ -314,7 +392,8 @@ __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkep
       tcount = stop > 0 ? __builtin_amdgcn_readlane(Q, (stop - 1) & (kSeg - 1)) : 0;
       if (wave == 0 && lane < stop && cnt > 0) {
         const int k = __popc(segs & ((1u << lane) - 1u));
-        T.cell[k] = lane; T.start[k] = first_p; T.col0[k] = P - pad; T.toff[k] = Q - cnt;
+        T.cell[k] = lane; T.col0[k] = P - pad; T.toff[k] = Q - cnt;
+        if (k == 0) T.pstart = first_p;
       }
       cur = min(base + stop, g.nx);
       cur_off = 0;
@@ -328,6 +407,25 @@ __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkep
     if constexpr ((ESK_LANES >> MODE) & 1) compose_lanes(T);
     else compose_scalar(T);
   };
+  // PRE: thread t < kTabWords owns word t of the table: where it sits in a 64-byte record (dword, shift, mask)
+  int twd = -1, tsh = 0;
+  unsigned tmask = 0u;
+  if (PRE && (int)threadIdx.x < kTabWords) {
+    const int t = threadIdx.x;
+    int byte, nib = 0;
+    if (t < 2) { byte = 4 * t; tmask = 0xffffffffu; }
+    else if (t < 6) { byte = 8 + (t - 2); tmask = 0xffu; }
+    else if (t < 6 + kSegMax) { byte = kPackCell + (t - 6) / 2; nib = ((t - 6) & 1) * 4; tmask = 0xfu; }
+    else if (t < 6 + kSegMax + kSegMax + 1) { byte = kPackCol0 + (t - 6 - kSegMax); tmask = 0xffu; }
+    else { byte = kPackToff + (t - 6 - kSegMax - (kSegMax + 1)); tmask = 0xffu; }
+    twd = byte >> 2;
+    tsh = t < 2 ? 0 : (byte & 3) * 8 + nib;
+  }
+  const unsigned* const tg = PRE ? tabg + (long)blockIdx.x * rcap * kPackDwords : nullptr;
+  auto tab_load = [&](int r) { return twd >= 0 ? tg[(long)r * kPackDwords + twd] : 0u; };
+  auto tab_put = [&](RoundTab& T, unsigned w) {
+    if (twd >= 0) reinterpret_cast<int*>(&T)[threadIdx.x] = (int)((w >> tsh) & tmask);
+  };
 
   auto request = [&](const RoundTab& T, Ahead<MODE>& pf) {
     pf.p = -1; pf.col = 0; pf.crel = 0; pf.seg = 0;
@@ -339,7 +437,7 @@ __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkep
 #pragma unroll
       for (int i = 1; i < kSeg; ++i) sg += (i < nseg && (int)threadIdx.x >= T.toff[i]) ? 1 : 0;
       const int k = (int)threadIdx.x - T.toff[sg];
-      pf.seg = sg; pf.p = T.start[sg] + k; pf.col = T.col0[sg] + k; pf.crel = T.cell[sg];
+      pf.seg = sg; pf.p = T.pstart + (int)threadIdx.x; pf.col = T.col0[sg] + k; pf.crel = T.cell[sg];
       // MODE 0 (the register-hungry 2nd-order gather) loads its particle when it gets there instead
       if (MODE != 0) {
 #pragma unroll
@@ -374,7 +472,12 @@ __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkep
   const double qdc[3] = {alpha * g.dx, alpha * g.dy, alpha * g.dz};
   const int kk = lane >> 4, qb = (lane >> 2) & 3, qq = lane & 3;         // phase 2: particle of the step, block, row / column
 
-  compose(tab[0]);
+  if constexpr (PRE) {
+    const unsigned w0 = tab_load(0), w1 = tab_load(1);
+    tab_put(tab[0], w0);
+    tab_put(tab[1], w1);
+  }
+  else compose(tab[0]);
   __syncthreads();
   Ahead<MODE> pf;
   request(tab[0], pf);
@@ -396,6 +499,9 @@ __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkep
     if (base >= g.nx) break;
     const int nseg = __builtin_amdgcn_readfirstlane(T.nseg), ncols = __builtin_amdgcn_readfirstlane(T.ncols);
     const int adv = __builtin_amdgcn_readfirstlane(T.adv);
+    // PRE: the record of round rd + 2 travels during this round and goes to LDS behind phase 2, into this round's table
+    unsigned tw = 0u;
+    if constexpr (PRE) tw = tab_load(rd + 2);
     // ---- this round's neighbourhoods / tile go to LDS; the next round is composed and requested
     double ft[MODE == 0 ? kFtPer : 1];
     if (MODE == 0) {
@@ -432,7 +538,7 @@ __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkep
       for (int a = 0; a < 3; ++a) { r[a] = s.r[a][p]; v[a] = s.v[a][p]; }
     }
     STAMP(1);
-    compose(tab[(rd + 1) & 1]);
+    if constexpr (!PRE) compose(tab[(rd + 1) & 1]);
     if (MODE == 0) {
 #if ESK_TILE_LATE
       __builtin_amdgcn_sched_barrier(0);
@@ -799,6 +905,8 @@ __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkep
     // the loop's end, where it copies the requested values into this round's registers)
     __builtin_amdgcn_s_waitcnt(0x0F70);
 #endif
+    // (every wave is past its last read of this round's table: the barrier above)
+    if constexpr (PRE) tab_put(tab[rd & 1], tw);
     // ---- the next round starts at cell base + adv: the window's nodes base - 1 .. base + adv - 2 are final and leave
     // with one fp64 atomic per node (other pencils add to the same nodes); their columns, zeroed, become the nodes
     // kJX further on (the window is circular, nothing moves).  The last round flushes everything (its tail wraps
@@ -904,22 +1012,56 @@ int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double
   double* scal = c->red_out;                  // [0] pred_w, [1] bad count (as int)
   XPIC_HIP(hipMemsetAsync(scal, 0, sizeof(double) * 2, c->stream));
   const char* name = mode == 0 ? "basic_push" : (mode == 1 ? "corr_first_push" : "corr_second_push");
-  {
+  // the rounds of every pencil, composed beforehand (PRE); the table is sized for one round per cell + a few
+  const int rcap = g.nx + kSentinels + 8;
+  static const bool pre_env = !(getenv("XPIC_ESK_PRE") && atoi(getenv("XPIC_ESK_PRE")) == 0);
+  bool pre = c->esk_pre != 0 && pre_env;
+  if (pre) {
+    const size_t need = (size_t)nblocks * rcap * kPackDwords * sizeof(unsigned);
+    if (c->esk_tab_bytes < need) {
+      (void)hipFree(c->esk_tab);
+      c->esk_tab = nullptr; c->esk_tab_bytes = 0;
+      if (hipMalloc(&c->esk_tab, need) == hipSuccess) c->esk_tab_bytes = need;
+      else { (void)hipGetLastError(); pre = false; } // (no room for the table: the pushes compose for themselves)
+    }
+  }
+  int* const flags = (int*)(scal + 1); // [0] particles that moved too far, [1] a pencil with more rounds than the table holds
+  auto launch = [&](bool with_table) {
     Timed t(c, name);
     dim3 grid((unsigned)nblocks), block(kThreadsB);
-#define ESK(M) (g.pow2 ? k_esirkepov_push<M, true> : k_esirkepov_push<M, false>)
-    if (mode == 0) hipLaunchKernelGGL(ESK(0), grid, block, 0, c->stream, g, s.d, E, B, J, qm, alpha, qn_Np, scal, (int*)(scal + 1));
-    else if (mode == 1) hipLaunchKernelGGL(ESK(1), grid, block, 0, c->stream, g, s.d, E, B, J, qm, alpha, qn_Np, scal, (int*)(scal + 1));
+    if (with_table) {
+      const unsigned nb = (unsigned)((nblocks + 255) / 256);
+      if (mode == 0) hipLaunchKernelGGL((k_esk_rounds<StageDim<0>::kSegM, StageDim<0>::kCols>), dim3(nb), dim3(256), 0, c->stream, g, s.d.cell_start, c->esk_tab, rcap, nblocks, flags + 1);
+      else if (mode == 1) hipLaunchKernelGGL((k_esk_rounds<StageDim<1>::kSegM, StageDim<1>::kCols>), dim3(nb), dim3(256), 0, c->stream, g, s.d.cell_start, c->esk_tab, rcap, nblocks, flags + 1);
+      else hipLaunchKernelGGL((k_esk_rounds<StageDim<2>::kSegM, StageDim<2>::kCols>), dim3(nb), dim3(256), 0, c->stream, g, s.d.cell_start, c->esk_tab, rcap, nblocks, flags + 1);
+    }
+#define ESK(M) (with_table ? (g.pow2 ? k_esirkepov_push<M, true, true> : k_esirkepov_push<M, false, true>) \
+                           : (g.pow2 ? k_esirkepov_push<M, true, false> : k_esirkepov_push<M, false, false>))
+    if (mode == 0) hipLaunchKernelGGL(ESK(0), grid, block, 0, c->stream, g, s.d, E, B, J, qm, alpha, qn_Np, scal, flags, c->esk_tab, rcap);
+    else if (mode == 1) hipLaunchKernelGGL(ESK(1), grid, block, 0, c->stream, g, s.d, E, B, J, qm, alpha, qn_Np, scal, flags, c->esk_tab, rcap);
     else {
       // per-workgroup pred_w partials go to the (idle) Krylov work vector: one double per pencil
-      hipLaunchKernelGGL(ESK(2), grid, block, 0, c->stream, g, s.d, E, B, J, qm, alpha, qn_Np, c->kry_w, (int*)(scal + 1));
+      hipLaunchKernelGGL(ESK(2), grid, block, 0, c->stream, g, s.d, E, B, J, qm, alpha, qn_Np, c->kry_w, flags, c->esk_tab, rcap);
 #undef ESK
       hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, c->stream, c->kry_w, nblocks, scal);
     }
-    XPIC_HIP(hipGetLastError());
-  }
+  };
+  launch(pre);
+  XPIC_HIP(hipGetLastError());
   XPIC_HIP(hipMemcpyAsync(c->red_host, scal, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
   XPIC_HIP(hipStreamSynchronize(c->stream));
+  if (pre) {
+    // (the flag travels with the scalars; only a raised flag -- the push then returned at once -- costs a second launch)
+    int fl[2];
+    memcpy(fl, &c->red_host[1], sizeof(fl));
+    if (fl[1] != 0) {
+      XPIC_HIP(hipMemsetAsync(scal, 0, sizeof(double) * 2, c->stream));
+      launch(false);
+      XPIC_HIP(hipGetLastError());
+      XPIC_HIP(hipMemcpyAsync(c->red_host, scal, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
+      XPIC_HIP(hipStreamSynchronize(c->stream));
+    }
+  }
   int bad;
   memcpy(&bad, &c->red_host[1], sizeof(int));
   // one collective for both scalars: MPI_Allreduce(pred_w) (ecsimcorr/particles.cpp:85) and the error count, so that
