@@ -747,7 +747,9 @@ __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkep
           for (int t = 0; t < kD; ++t) {
             run += w[1][t] - w[0][t];
             colp[(a * kD + t) * kPitch] = w[0][t];
+#if ESK_EXP != 3 // (experiment 3: a third of the stage stores dropped -- what the LDS store path costs; results garbage)
             colp[(12 + a * kD + t) * kPitch] = w[1][t];
+#endif
             colp[(24 + a * kD + t) * kPitch] = run;
           }
 #endif
