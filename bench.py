@@ -460,7 +460,7 @@ def rank_body(args, rank, world, local_rank, job):
 
     if args.scheme != "basic" and args.fill_kernel is not None:
         ctx.set_fill_kernel(args.fill_kernel)
-    if args.scheme != "basic" and args.fused_rebin is not None:
+    if args.fused_rebin is not None:
         ctx.set_fused_rebin(args.fused_rebin)
     if args.plain_gmres and args.scheme != "basic":
         ctx.set_preconditioner(0)

@@ -174,18 +174,21 @@ int xpic_set_tolerances(xpic_ctx* ctx, double rtol, double atol, int maxit);
  * Kinds 3 and 4 check their surrogate per solve (2 + the Gershgorin lower bound of <matL> must be positive) and otherwise runs
  * that solve with kind 1. */
 int xpic_set_preconditioner(xpic_ctx* ctx, int kind, int degree);
-/* The mass-matrix assembly (fill_ecsim_current) has two bodies: kind 1 (default) the warp-specialised kernel (one 8-wave
- * workgroup per CU: producer waves run the per-particle algebra and the window's read-modify-write, consumer waves the
- * matrix-core accumulation), used where nx is a multiple of 4 and no extent is below 3; kind 0 the classic 4-wave kernel
- * (all grids).  Same matrix up to the summation order of a cell's neighbours.  xpic_get_fill_variant: out3 = {power-of-two
- * spacings, full-chunk body, warp-specialised body} as the next assembly of this context will run. */
+/* The mass-matrix assembly (fill_ecsim_current) has two bodies: kind 0 (default) the classic 4-wave kernel (all grids);
+ * kind 1 the warp-specialised kernel (one 16-wave workgroup per CU: a producer wave per SIMD runs the per-particle algebra,
+ * two consumer waves the matrix-core accumulation, a flusher the window's read-modify-write), available where nx is a
+ * multiple of 4 and no extent is below 3, measured slower.  Same matrix up to the summation order of a
+ * cell's neighbours.  xpic_get_fill_variant: out3 = {power-of-two spacings, full-chunk body, warp-specialised body} as the
+ * next assembly of this context will run. */
 int xpic_set_fill_kernel(xpic_ctx* ctx, int kind);
-/* The ecsim step's first_push + update_cells (ecsim/simulation.cpp:174-189) re-bins the particles; on = 1 (default)
- * defers the scatter pass of that re-binning into the assembly that follows: the assembly reads every particle anyway,
- * so it gathers the records through a source index, applies the move and the periodic wrap and writes the sorted copy on
- * its way; on = 2: the assembly only reads through the index and ecsim's second_push -- which is bound by memory anyway --
- * moves the records and writes the sorted copy with the new velocities.  Same particles, same cells, same arithmetic as
- * on = 0 (scatter first).  Single slab, classic assembly kernel. */
+/* update_cells (src/interfaces/particles.cpp:79-116) re-bins the particles in two passes (keys, then an out-of-place
+ * scatter).  on = 1 (default) leaves the scatter to the next kernel that reads every particle anyway: in the ecsim step
+ * (ecsim/simulation.cpp:174-189) and for the first re-binning of the ecsimcorr step that is the mass-matrix assembly, in the
+ * basic step (basic/simulation.cpp:45-72) the next step's push; it gathers the records through source indices, applies the
+ * move and the periodic wrap and writes the sorted copy on its way.  on = 2 (ecsim): the assembly only reads through the
+ * index and second_push -- which is bound by memory anyway -- writes the sorted copy with the new velocities.  Same
+ * particles, same cells, same arithmetic as on = 0 (scatter first); any other reader of a sort (diagnostics, downloads,
+ * the phase entry points) resolves a pending deferral by the plain scatter.  Single slab only. */
 int xpic_set_fused_rebin(xpic_ctx* ctx, int on);
 int xpic_get_fill_variant(xpic_ctx* ctx, int* out3);
 /* MatMult on a z-slab with neighbours: on = 1 posts the ghost exchange of the operand (VecScatterBegin), applies

@@ -104,6 +104,46 @@ def test_basic_steps_match_oracle(oracle):
     assert np.abs(po - pg).max() <= 1e-12
 
 
+def test_basic_deferred_scatter_equals_scatter_first(oracle):
+    """The basic step's re-binning leaves its scatter to the next step's push (xpic_set_fused_rebin 1, the default: the
+    push gathers every record through the index k_index built, wraps it and writes the sorted copy): the same particles in
+    the same cells as the scatter-first step and the oracle, two species, particles crossing cells and the periodic
+    boundary, a heavy cell and empty ones; a diagnostic between two steps (it resolves the deferral by the plain scatter)
+    changes nothing."""
+    import xpic_amd as X
+
+    n, d, dt = GRID
+    sorts = [(6, 1.0, -1.0, 1.0), (3, 1.0, 1.0, 20.0)]
+    o, g = make_pair(oracle, "basic", n, d, 0.1, sorts, B0=(0.0, 0.3, 0.1), vth=0.3)
+    _, h = make_pair(oracle, "basic", n, d, 0.1, sorts, B0=(0.0, 0.3, 0.1), vth=0.3)
+    rng = np.random.default_rng(11)
+    heavy = np.hstack([(np.array([2, 3, 1]) + rng.random((300, 3))) * np.array(d), rng.normal(0, 0.3, (300, 3))])
+    for sim in (o, g, h):
+        assert sim.add_particles(0, heavy) == 300
+    h.set_fused_rebin(0)
+    g.profile_enable(True)
+    for t in range(4):
+        g.profile_reset()
+        for sub in range(3):  # (reading the particles below resolves a deferral: three steps in a row between two checks)
+            assert o.step() == 0
+            g.step()
+            h.step()
+            if t == 2 and sub == 1:  # ... and so does a diagnostic between two steps: by the plain scatter
+                g.energy()
+        # both species deferred their scatter in every step: an index pass each, no scatter pass but the diagnostic's
+        assert g.profile_get("index")[0] == 6 and g.profile_get("scatter")[0] == (2 if t == 2 else 0), t
+        for sp in range(2):
+            pg, cg = canon(*g.particles(sp))
+            ph, ch = canon(*h.particles(sp))
+            po, co = canon(*o.particles(sp))
+            assert np.array_equal(cg, ch) and np.array_equal(cg, co), (t, sp)
+            assert np.all(np.diff(g.particles(sp)[1]) >= 0), (t, sp)
+            assert np.abs(pg - ph).max() <= 1e-12 and np.abs(pg - po).max() <= 1e-10, (t, sp)
+        for name, fid in (("E", X.E), ("B", X.B), ("J", X.J)):
+            a, b = o.get_field(name), g.get_field(fid)
+            assert np.abs(a - b).max() <= 1e-11 * np.abs(a).max(), (t, name)
+
+
 def test_reference_golden_basic_ex1(oracle):
     """tests/basic/basic_ex1.cpp through the HIP path: 20 rows of energy.txt to every printed digit."""
     import xpic_amd as X

@@ -205,7 +205,8 @@ static int step_basic(xpic_ctx* c)
     XPIC_CALL(esirkepov_push(c, s, 0, E, B, s.J, nullptr)); // sort->push()
     XPIC_CALL(halo_add(c, s.J, 3));                         // DMLocalToGlobal(ADD) particles.cpp:50
     XPIC_CALL(vec_axpy(c, J, 1.0, s.J));                    // VecAXPY(simulation_.J, 1, J) particles.cpp:51
-    XPIC_CALL(sort_rebin(c, s, 0.0, true));                 // sort->update_cells()
+    // sort->update_cells(); the next step's push reads every particle: it gathers through the index and writes the sorted copy
+    XPIC_CALL(sort_rebin(c, s, 0.0, true, c->fused_rebin == 1 ? 2 : 0));
   }
   // push_fields :74-100
   XPIC_CALL(vec_axpy(c, B, -1.0, B0));

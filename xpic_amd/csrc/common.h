@@ -298,7 +298,9 @@ int matL_ghost_rows_finish(xpic_ctx* c);    // add the neighbours' rows into the
 // particles.hip
 int sort_alloc(xpic_ctx* c, Sort& s, int64_t cap);
 void sort_free(Sort& s);
-int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap, bool defer = false);
+// defer: 0 the scatter runs here; 1 it is left to the mass-matrix assembly (buckets of source indices where the binning
+// wrote them, else the index k_index builds); 2 it is left to the next Esirkepov push (index only)
+int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap, int defer = 0);
 int sort_materialize(xpic_ctx* c, Sort& s); // run the scatter a deferred re-binning left out (no-op otherwise)
 void sort_deferred_done(Sort& s);             // the assembly has written the sorted records: swap the buffers
 int sort_move(xpic_ctx* c, Sort& s, double step); // r += step*v in place, cells left stale // (optional move by step*v), wrap, bin, scatter

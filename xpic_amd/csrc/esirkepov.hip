@@ -232,6 +232,7 @@ __global__ void __launch_bounds__(256) k_esk_rounds(GridDev g, const int* __rest
 template <int MODE>
 struct Ahead {
   int p, col, crel, seg; // particle (-1: none), stage column, cell - base, segment
+  int idx;               // GA: where the record of slot p lies in the old order
   double r[3], v[3];
   double nb[MODE == 2 ? kNbPer : 1];
 };
@@ -239,13 +240,18 @@ struct Ahead {
 using UniformInts = const __attribute__((address_space(4))) int*; // wave-uniform reads of cell_start: scalar loads
 
 // P2: power-of-two spacings (exact reciprocals instead of divisions, device_common.h: scaled_position)
-template <int MODE, bool P2, bool PRE>
+// GA ("gather"): the re-binning in front of this push deferred its scatter (sort_rebin(.., defer = 2)): slot p of the new
+// order finds its record at src[p] of the old one, still un-wrapped; the push reads it from there, wraps it with k_scatter's
+// arithmetic and writes position AND velocity to slot p of the second buffer, which becomes the sort (the push reads
+// and writes every particle anyway: the scatter pass, 104 B per particle, is gone).  MODE 0 with the round table only.
+template <int MODE, bool P2, bool PRE, bool GA = false>
 __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkepov_push(GridDev g, SortDev s, const double* __restrict__ E,
   const double* __restrict__ B, double* __restrict__ J, double qm, double alpha, double qn_Np, double* pred_w,
   int* bad_count, const unsigned* __restrict__ tabg, int rcap)
 {
   // PRE: a pencil had more rounds than the table holds (k_esk_rounds raised the flag behind the error count): nothing is
   // touched, the host launches the self-composing form instead
+  static_assert(!GA || (MODE == 0 && PRE), "the gathering form exists for the basic push with precomposed rounds");
   if (PRE && bad_count[1] != 0) return;
   // workgroup -> the x-pencil (cy, cz), marched in rounds
   constexpr int kCols = StageDim<MODE>::kCols, kPitch = StageDim<MODE>::kPitch;
@@ -428,7 +434,7 @@ __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkep
   };
 
   auto request = [&](const RoundTab& T, Ahead<MODE>& pf) {
-    pf.p = -1; pf.col = 0; pf.crel = 0; pf.seg = 0;
+    pf.p = -1; pf.col = 0; pf.crel = 0; pf.seg = 0; pf.idx = 0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) { pf.r[a] = 0.0; pf.v[a] = 0.0; }
     const int nseg = T.nseg;
@@ -438,6 +444,7 @@ __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkep
       for (int i = 1; i < kSeg; ++i) sg += (i < nseg && (int)threadIdx.x >= T.toff[i]) ? 1 : 0;
       const int k = (int)threadIdx.x - T.toff[sg];
       pf.seg = sg; pf.p = T.pstart + (int)threadIdx.x; pf.col = T.col0[sg] + k; pf.crel = T.cell[sg];
+      if (GA) pf.idx = s.src[pf.p]; // (a round ahead of the record it addresses)
       // MODE 0 (the register-hungry 2nd-order gather) loads its particle when it gets there instead
       if (MODE != 0) {
 #pragma unroll
@@ -534,8 +541,9 @@ __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkep
     if (MODE == 0 && p >= 0) {
       // (MODE 0 cannot hold a particle a round ahead -- the 2nd-order gather takes every register -- but it can ask for
       // it here: the composition of the next round and the barrier pass under the latency)
+      const long q = GA ? (long)pf.idx : (long)p;
 #pragma unroll
-      for (int a = 0; a < 3; ++a) { r[a] = s.r[a][p]; v[a] = s.v[a][p]; }
+      for (int a = 0; a < 3; ++a) { r[a] = s.r[a][q]; v[a] = s.v[a][q]; }
     }
     STAMP(1);
     if constexpr (!PRE) compose(tab[(rd + 1) & 1]);
@@ -562,6 +570,12 @@ __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkep
     double po[3] = {0, 0, 0}, pn[3] = {0, 0, 0};
     int sst[3] = {0, 0, 0}, ssz[3] = {0, 0, 0};
     if (p >= 0) {
+      if (GA) { // correct_coordinates of the deferred re-binning (k_scatter<false, true>'s arithmetic); here, at the record's
+        // first use: directly behind the loads it made the wave sit out their whole latency at the top of every round
+        r[0] = bound_periodic_sel(r[0], g.Lx);
+        r[1] = bound_periodic_sel(r[1], g.Ly);
+        r[2] = bound_periodic_sel(r[2], g.Lz);
+      }
       const double old_r[3] = {r[0], r[1], r[2]};
       double Ep[3] = {0, 0, 0}, Bp[3] = {0, 0, 0};
 
@@ -681,8 +695,11 @@ __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkep
 #if ESK_EXP != 2
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        s.r[a][p] = r[a];
-        if (MODE != 1) s.v[a][p] = v[a];
+        if (GA) { s.r2[a][p] = r[a]; s.v2[a][p] = v[a]; }
+        else {
+          s.r[a][p] = r[a];
+          if (MODE != 1) s.v[a][p] = v[a];
+        }
       }
 #endif
 
@@ -987,7 +1004,12 @@ extern "C" int xpic_debug_esk_stamps(double* out, int reset)
 
 int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double* B, double* J, double* pred_w_host)
 {
-  XPIC_CALL(sort_materialize(c, s));
+  static const bool pre_env = !(getenv("XPIC_ESK_PRE") && atoi(getenv("XPIC_ESK_PRE")) == 0);
+  bool pre = c->esk_pre != 0 && pre_env;
+  // a re-binning that left its scatter to this push (sort_rebin(.., 2) in the basic step): the gathering form, if the round
+  // table can be used; everything else resolves the deferral by the plain scatter first
+  bool ga = pre && mode == 0 && s.deferred && !s.def_bucket && s.def_wrap && s.def_step == 0.0 && c->comm.kind == 0 && s.n > 0;
+  if (!ga) XPIC_CALL(sort_materialize(c, s));
   s.prebinned = false;
   if (pred_w_host) *pred_w_host = 0.0;
   // rank-uniform checks first: every slab fails them alike, BEFORE anyone enters the collective below (a slab that
@@ -1016,8 +1038,6 @@ int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double
   const char* name = mode == 0 ? "basic_push" : (mode == 1 ? "corr_first_push" : "corr_second_push");
   // the rounds of every pencil, composed beforehand (PRE); the table is sized for one round per cell + a few
   const int rcap = g.nx + kSentinels + 8;
-  static const bool pre_env = !(getenv("XPIC_ESK_PRE") && atoi(getenv("XPIC_ESK_PRE")) == 0);
-  bool pre = c->esk_pre != 0 && pre_env;
   if (pre) {
     const size_t need = (size_t)nblocks * rcap * kPackDwords * sizeof(unsigned);
     if (c->esk_tab_bytes < need) {
@@ -1027,6 +1047,7 @@ int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double
       else { (void)hipGetLastError(); pre = false; } // (no room for the table: the pushes compose for themselves)
     }
   }
+  if (ga && !pre) { XPIC_CALL(sort_materialize(c, s)); ga = false; }
   int* const flags = (int*)(scal + 1); // [0] particles that moved too far, [1] a pencil with more rounds than the table holds
   auto launch = [&](bool with_table) {
     Timed t(c, name);
@@ -1039,7 +1060,10 @@ int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double
     }
 #define ESK(M) (with_table ? (g.pow2 ? k_esirkepov_push<M, true, true> : k_esirkepov_push<M, false, true>) \
                            : (g.pow2 ? k_esirkepov_push<M, true, false> : k_esirkepov_push<M, false, false>))
-    if (mode == 0) hipLaunchKernelGGL(ESK(0), grid, block, 0, c->stream, g, s.d, E, B, J, qm, alpha, qn_Np, scal, flags, c->esk_tab, rcap);
+    if (mode == 0 && ga && with_table)
+      hipLaunchKernelGGL((g.pow2 ? k_esirkepov_push<0, true, true, true> : k_esirkepov_push<0, false, true, true>), grid, block, 0, c->stream, g,
+        s.d, E, B, J, qm, alpha, qn_Np, scal, flags, c->esk_tab, rcap);
+    else if (mode == 0) hipLaunchKernelGGL(ESK(0), grid, block, 0, c->stream, g, s.d, E, B, J, qm, alpha, qn_Np, scal, flags, c->esk_tab, rcap);
     else if (mode == 1) hipLaunchKernelGGL(ESK(1), grid, block, 0, c->stream, g, s.d, E, B, J, qm, alpha, qn_Np, scal, flags, c->esk_tab, rcap);
     else {
       // per-workgroup pred_w partials go to the (idle) Krylov work vector: one double per pencil
@@ -1057,6 +1081,7 @@ int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double
     int fl[2];
     memcpy(fl, &c->red_host[1], sizeof(fl));
     if (fl[1] != 0) {
+      if (ga) { XPIC_CALL(sort_materialize(c, s)); ga = false; } // (the gathering push returned before touching anything)
       XPIC_HIP(hipMemsetAsync(scal, 0, sizeof(double) * 2, c->stream));
       launch(false);
       XPIC_HIP(hipGetLastError());
@@ -1064,6 +1089,7 @@ int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double
       XPIC_HIP(hipStreamSynchronize(c->stream));
     }
   }
+  if (ga) sort_deferred_done(s); // r2 / v2 hold the sorted, wrapped, pushed records: they become the sort
   int bad;
   memcpy(&bad, &c->red_host[1], sizeof(int));
   // one collective for both scalars: MPI_Allreduce(pred_w) (ecsimcorr/particles.cpp:85) and the error count, so that

@@ -726,8 +726,8 @@ int sort_alloc(xpic_ctx* c, Sort& s, int64_t cap)
   XPIC_HIP(hipMalloc(&s.d.rank, sizeof(int) * cap));
   s.d.src = nullptr;
   s.d.bucket = nullptr; s.d.bucket_cap = 0; s.d.ncell = c->ncell;
+  XPIC_HIP(hipMalloc(&s.d.src, sizeof(int) * (cap + 1))); // deferred scatter (into the assembly, or into the next Esirkepov push)
   if (c->scheme != XPIC_BASIC) {
-    XPIC_HIP(hipMalloc(&s.d.src, sizeof(int) * (cap + 1))); // deferred scatter of the ecsim / ecsimcorr step
     // buckets of XPIC_BUCKET_CAP source indices per cell, on a single slab, where they cost at most as much as the particles' keys
     // (twice the mean occupancy the capacity allows, in steps of 32, at most XPIC_BUCKET_CAP: a Poisson cell never gets there)
     long bcap = ((2 * cap / c->ncell + 32 + 31) / 32) * 32;
@@ -841,7 +841,7 @@ void sort_deferred_done(Sort& s)
   }
 }
 
-int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap, bool defer)
+int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap, int defer)
 {
   XPIC_CALL(sort_materialize(c, s));
   const bool move = step != 0.0;
@@ -861,7 +861,7 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap, bool defer)
     const unsigned nb = pgrid(s.n);
     // (the buckets are filled only for a binning that a deferred scatter will read)
     SortDev sd = s.d;
-    s.bucket_written = defer && !mig && s.d.bucket_cap > 0 && c->fused_rebin == 1;
+    s.bucket_written = defer == 1 && !mig && s.d.bucket_cap > 0 && c->fused_rebin == 1;
     if (!s.bucket_written) sd.bucket_cap = 0;
 #define LAUNCH(M, W, G) hipLaunchKernelGGL((k_move_bin<M, W, G>), dim3(nb), dim3(kBlock), 0, c->stream, c->g, sd, s.n, step, mg)
     if (mig) {
@@ -947,7 +947,7 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap, bool defer)
       int* hflag = (int*)(c->red_host + 61);
       XPIC_HIP(hipMemcpyAsync(hflag, s.d.bucket + c->ncell * s.d.bucket_cap, sizeof(int), hipMemcpyDeviceToHost, c->stream));
       XPIC_HIP(hipStreamSynchronize(c->stream));
-      use_bucket = *hflag == 0 && s.bucket_written && c->fused_rebin == 1; // (mode 2's second push reads the index k_index builds)
+      use_bucket = defer == 1 && *hflag == 0 && s.bucket_written && c->fused_rebin == 1; // (mode 2's second push reads the index k_index builds)
     }
     if (!use_bucket && !s.keys_valid) {
       // (a cell took more arrivals than a bucket holds: this sort's pre-binnings write the keys from now on)
