@@ -575,3 +575,15 @@ def test_headline_size_properties():
     e2 = g.energy()
     assert e2[4] == e1[4] or abs(e2[4] - e1[4]) <= 1e-13 * e1[4]  # same particles, maybe another summation order
     g.close()
+    # the same two steps with the re-binning's scatter as a pass of its own (the default step defers it into the assembly,
+    # gathering through the binning's buckets): field and kinetic energies are sums over every node and every particle
+    h = X.Context("ecsim", n, (0.5, 0.5, 0.5), 1.0)
+    sh = h.add_sort(64, 1.0, -1.0, 1.0, capacity=int(64 * N * 1.02))
+    h.fill_synthetic(sh, 64, 0.014, seed=11)
+    h.set_fused_rebin(0)
+    assert [h.step() for _ in range(2)] == its
+    eh = h.energy()
+    assert h.count(sh) == 64 * N
+    for k in (0, 1, 4):
+        assert abs(eh[k] - e1[k]) <= 1e-9 * abs(e1[k]), (k, eh[k], e1[k])
+    h.close()
