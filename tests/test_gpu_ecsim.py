@@ -167,7 +167,7 @@ def test_fill_current_and_matL(oracle, B0, grid):
 
 @BOTH_GRIDS
 def test_both_assembly_kernels_match_the_oracle(oracle, grid):
-    """The warp-specialised assembly (the default where nx % 4 == 0: the body bench.py times) and the classic kernel on
+    """The warp-specialised assembly (xpic_set_fill_kernel 1, where nx % 4 == 0) and the classic kernel (the default) on
     the same particles: currI and matL within 1e-12 of the oracle for both, B != 0, two species."""
     import xpic_amd as X
 

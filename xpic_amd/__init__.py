@@ -317,11 +317,11 @@ class Context:
         return tuple(int(v) for v in o)
 
     def set_fill_kernel(self, kind):
-        """0: classic 4-wave assembly kernel; 1 (default): warp-specialised 8-wave kernel where the grid allows"""
+        """0 (default): classic 4-wave assembly kernel; 1: warp-specialised 16-wave kernel where the grid allows (measured slower)"""
         self._ck(self.L.xpic_set_fill_kernel(self.h, int(kind)))
 
     def set_fused_rebin(self, on):
-        """ecsim step: 1 (default) the re-binning's scatter is deferred into the assembly's particle loads, 0 scatter first"""
+        """1 (default): a re-binning's scatter is left to the next kernel that reads every particle (the assembly in ecsim / ecsimcorr, the next push in basic); 2: to ecsim's second push; 0: scatter first"""
         self._ck(self.L.xpic_set_fused_rebin(self.h, int(on)))
 
     def fill_variant(self):
