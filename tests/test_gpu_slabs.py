@@ -82,10 +82,17 @@ def build(force):
 a, b, c = build(True), build(False), build(True)
 a.set_overlap(3)      # operator halos posted beside the interior rows AND the matL ghost rows beside the interior colours
 c.set_overlap(0)      # every exchange first, then one launch over all planes
+c.set_fused_rebin(0)  # ... and the first re-binning's scatter as a pass of its own (a and b leave it to the assembly)
+a.profile_enable(True); c.profile_enable(True)
 for t in range(3):
     ia, ib, ic = a.step(), b.step(), c.step()
     assert abs(ia - ib) <= 2, (ia, ib)
     assert abs(ia - ic) <= 1, (ia, ic)
+# per step: the slab that defers runs the index pass (what the neighbours sent stays in the receive buffer and is gathered
+# from there) and ONE scatter (the second re-binning), the other one two scatters
+assert a.profile_get("index")[0] == 3 and a.profile_get("scatter")[0] == 3, (a.profile_get("index"), a.profile_get("scatter"))
+assert c.profile_get("index")[0] == 0 and c.profile_get("scatter")[0] == 6
+assert a.profile_get("migrate")[0] == 6  # particles do cross the slab's (own) boundary in both re-binnings
 for f in (X.E, X.B):
     fa, fb, fc = a.get_field(f), b.get_field(f), c.get_field(f)
     assert np.abs(fa - fb).max() <= 1e-8 * np.abs(fb).max()

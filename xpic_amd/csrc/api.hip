@@ -206,7 +206,7 @@ static int step_basic(xpic_ctx* c)
     XPIC_CALL(halo_add(c, s.J, 3));                         // DMLocalToGlobal(ADD) particles.cpp:50
     XPIC_CALL(vec_axpy(c, J, 1.0, s.J));                    // VecAXPY(simulation_.J, 1, J) particles.cpp:51
     // sort->update_cells(); the next step's push reads every particle: it gathers through the index and writes the sorted copy
-    XPIC_CALL(sort_rebin(c, s, 0.0, true, c->fused_rebin == 1 ? 2 : 0));
+    XPIC_CALL(sort_rebin(c, s, 0.0, true, c->fused_rebin == 1 && c->comm.kind == 0 ? 2 : 0));
   }
   // push_fields :74-100
   XPIC_CALL(vec_axpy(c, B, -1.0, B0));

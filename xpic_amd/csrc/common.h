@@ -128,6 +128,7 @@ struct SortDev {
   int* bucket;     // the same, written by the binning itself: bucket[cell * bucket_cap + arrival rank] (+ one flag word at the end:
   int bucket_cap;  // a cell took more arrivals than bucket_cap); 0: no buckets
   long ncell;
+  const double* inc; // z-slabs: the records received from the neighbours ({r, v} per record); a source index -1 - i means record i of it
 };
 
 struct Sort {
@@ -142,6 +143,7 @@ struct Sort {
   bool bucket_written = false; // the binning whose keys cell[] / rank[] hold also filled the buckets
   bool keys_valid = true;      // false: that binning wrote the buckets and the counts only (particles.hip: rebuild_keys)
   bool bucket_off = false;     // a cell overflowed its bucket once: pre-binnings write the keys again
+  int def_n_in = 0; // records of the deferred re-binning that came from the neighbouring slabs (they lie in mig_recv)
   bool deferred = false, def_wrap = false, def_bucket = false; // def_bucket: the assembly reads the binning's buckets, not src
   double def_step = 0;
   int64_t def_n_old = 0;

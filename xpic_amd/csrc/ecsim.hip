@@ -209,6 +209,7 @@ struct Prefetch {
   double p[6];     // x, y, z, vx, vy, vz of lane's particle of the next pass
   double b;        // lane's value of the next cell's 54-value B neighbourhood
   int srcx;        // gathering assembly: source index of slot start + kCP + lane (the second pass's records)
+  unsigned long long incm; // ... and the lanes whose record came from a neighbouring slab (already moved: no first_push for it)
 };
 // gathering assembly: what is requested TWO cells ahead -- the cell's range and the source indices of its first slots
 struct PrefetchIdx {
@@ -376,24 +377,34 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
   // wave takes or skips, complete with its wait: as the two arms of one per-lane branch the arms' loads shared their
   // destination registers, and the compiler guarded that with s_waitcnt vmcnt(0) in front of the near arm's loads -- the
   // memory counter being in order, a wait for the six stores of the sorted copy issued a phase 1 before (8 ms per assembly).
-  auto gather = [&](int srcidx, bool on, double (&rec)[6]) {
+  // z-slabs: a negative source index -1 - i is record i of what the neighbours sent (SortDev::inc, {r, v} per record, moved
+  // and wrapped by its sender); the returned mask names those lanes: settle() must not move them again.
+  auto gather = [&](int srcidx, bool on, double (&rec)[6]) -> unsigned long long {
+    const bool inc = on && srcidx < 0;
     const unsigned long rel = (unsigned long)((long)srcidx - gb);
-    const bool near = rel < (1ul << 29);
+    const bool near = !inc && rel < (1ul << 29);
     if (on && near) {
       const unsigned off8 = (unsigned)rel << 3;
 #pragma unroll
       for (int a = 0; a < 6; ++a) rec[a] = *reinterpret_cast<const double*>(rb[a] + (size_t)off8);
     }
+    const unsigned long long incm = __ballot(inc);
     if (__builtin_expect(__ballot(on && !near) != 0, 0)) {
       double far[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-      if (on && !near) {
+      if (on && !near && !inc) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) { far[a] = s.r[a][srcidx]; far[3 + a] = s.v[a][srcidx]; }
+      }
+      if (inc) {
+        const double* q = s.inc + 6L * (-1 - srcidx);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) far[a] = q[a];
       }
       __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll
       for (int a = 0; a < 6; ++a) rec[a] = (on && !near) ? far[a] : rec[a];
     }
+    return incm;
   };
   // where slot i of cell cx finds its source index: the binning's bucket of the cell, or the index k_index built
   auto idx_of = [&](int cx, int start, int i) {
@@ -412,18 +423,20 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     if (lane < min(kCP, pi.cnt - kCP)) pi.srcx = idx_of(cxu, pi.start, kCP + lane);
   };
   auto prefetch_rec = [&](int i, const PrefetchIdx& pi, Prefetch& pf) {
-    pf.start = pi.start; pf.cnt = pi.cnt; pf.b = 0.0; pf.srcx = pi.srcx;
+    pf.start = pi.start; pf.cnt = pi.cnt; pf.b = 0.0; pf.srcx = pi.srcx; pf.incm = 0ull;
     if (i >= g.nx) return;
     pf.b = brow ? brow[g.wx(cell_x(i) + box)] : 0.0;
-    gather(FILL_GA_NOCHAIN ? pf.start + lane : pi.src, lane < min(kCP, pf.cnt), pf.p);
+    pf.incm = gather(FILL_GA_NOCHAIN ? pf.start + lane : pi.src, lane < min(kCP, pf.cnt), pf.p);
   };
   // a record that has just arrived from the old order is moved, wrapped (k_scatter's arithmetic, bit for bit) and written
   // to its slot d of the new order.  (Wrapping only in the cells on the box's boundary is wrong: a particle that moves
   // several cells in a step lands further inside.)
-  auto settle = [&](double (&cur)[6], int drel) {
-    cur[0] += cur[3] * step;
-    cur[1] += cur[4] * step;
-    cur[2] += cur[5] * step;
+  auto settle = [&](double (&cur)[6], int drel, unsigned long long incm) {
+    double st = step;
+    if (__builtin_expect(incm != 0ull, 0)) st = ((incm >> lane) & 1ull) ? 0.0 : step; // (x + v * 0 = x: the sender moved it)
+    cur[0] += cur[3] * st;
+    cur[1] += cur[4] * st;
+    cur[2] += cur[5] * st;
     cur[0] = bound_periodic_sel(cur[0], g.Lx);
     cur[1] = bound_periodic_sel(cur[1], g.Ly);
     cur[2] = bound_periodic_sel(cur[2], g.Lz);
@@ -481,7 +494,8 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
 #pragma unroll
       for (int a = 0; a < 6; ++a) cur[a] = pf.p[a];
       const int srcx_cur = pf.srcx;
-      if (GA && lane < min(kCP, cnt)) settle(cur, (int)((long)start - pn0) + lane);
+      if (GA && lane < min(kCP, cnt)) settle(cur, (int)((long)start - pn0) + lane, pf.incm);
+      unsigned long long fresh_incm = 0ull;
       int fresh = -1; // GA: slot (relative to the cell's first) of a record this lane requested during the last pass
       // particles.cpp:107-115: the factors that do not depend on the particle
       const double fb = (0.5 * dt) * q / m;
@@ -502,7 +516,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
         real = false;
 #endif
         wave_sync(); // the previous pass's operand reads (and the neighbourhood store) are done
-        if (GA && fresh >= 0) { settle(cur, (int)((long)start - pn0) + fresh); fresh = -1; }
+        if (GA && fresh >= 0) { settle(cur, (int)((long)start - pn0) + fresh, fresh_incm); fresh = -1; }
         // CIC weights and the half-cell octant first: the octant decides the particle's stage slot
         const W1T<P2> w(g, cur[0], cur[1], cur[2]); // lanes without a particle: garbage in, masked by oct = 8
         const int ox = w.is[0] - w.in[0] + 1, oy = w.is[1] - w.in[1] + 1, oz = w.is[2] - w.in[2] + 1;
@@ -612,7 +626,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
             }
             if (FILL_GA_NOCHAIN) srcidx = start + handed + fr;
             if (get) fresh = handed + fr;
-            gather(srcidx, get, cur);
+            fresh_incm = gather(srcidx, get, cur);
           }
           else if (get) {
             const long p = (long)start + handed + fr;

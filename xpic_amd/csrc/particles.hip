@@ -199,6 +199,16 @@ __global__ void __launch_bounds__(kBlock) k_index(SortDev s, int64_t n)
   s.src[(int64_t)s.cell_start[c] + s.rank[p]] = (int)p;
 }
 
+// ... and the records that arrived from the neighbouring slabs stay in the receive buffer: slot <- -1 - (record number)
+__global__ void __launch_bounds__(kBlock) k_index_incoming(SortDev s, int n, const int* __restrict__ inc_cell, const int* __restrict__ inc_rank)
+{
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int c = inc_cell[i];
+  if (c < 0) return;
+  s.src[(int64_t)s.cell_start[c] + inc_rank[i]] = -1 - i;
+}
+
 // ---- exclusive scan of the per-cell counts (3 small kernels; N ints, negligible next to particles) ----
 constexpr int kScanItems = 8; // per thread
 constexpr int kScanTile = kBlock * kScanItems;
@@ -724,7 +734,7 @@ int sort_alloc(xpic_ctx* c, Sort& s, int64_t cap)
   }
   XPIC_HIP(hipMalloc(&s.d.cell, sizeof(int) * cap));
   XPIC_HIP(hipMalloc(&s.d.rank, sizeof(int) * cap));
-  s.d.src = nullptr;
+  s.d.src = nullptr; s.d.inc = nullptr;
   s.d.bucket = nullptr; s.d.bucket_cap = 0; s.d.ncell = c->ncell;
   XPIC_HIP(hipMalloc(&s.d.src, sizeof(int) * (cap + 1))); // deferred scatter (into the assembly, or into the next Esirkepov push)
   if (c->scheme != XPIC_BASIC) {
@@ -751,6 +761,7 @@ int sort_alloc(xpic_ctx* c, Sort& s, int64_t cap)
     XPIC_HIP(hipMalloc(&s.mig_send[0], sizeof(double) * 6 * mc));
     XPIC_HIP(hipMalloc(&s.mig_send[1], sizeof(double) * 6 * mc));
     XPIC_HIP(hipMalloc(&s.mig_recv, sizeof(double) * 6 * mc));
+    s.d.inc = s.mig_recv;
     XPIC_HIP(hipMalloc(&s.mig_cell, sizeof(int) * mc));
     XPIC_HIP(hipMalloc(&s.mig_rank, sizeof(int) * mc));
     XPIC_HIP(hipMalloc(&s.mig_count, sizeof(int) * 8));
@@ -824,6 +835,10 @@ int sort_materialize(xpic_ctx* c, Sort& s)
   if (s.def_n_old > 0) {
     if (!s.keys_valid) XPIC_CALL(rebuild_keys(c, s, s.def_n_old, s.def_step));
     XPIC_CALL(launch_scatter(c, s, s.def_n_old, s.def_step, s.def_wrap));
+  }
+  if (s.def_n_in > 0) {
+    hipLaunchKernelGGL(k_scatter_incoming, dim3(pgrid(s.def_n_in)), dim3(kBlock), 0, c->stream, s.d, s.mig_recv, s.def_n_in, s.mig_cell, s.mig_rank);
+    XPIC_HIP(hipGetLastError());
   }
   for (int a = 0; a < 3; ++a) {
     std::swap(s.d.r[a], s.d.r2[a]);
@@ -939,7 +954,9 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap, int defer)
   }
   // Deferred (the ecsim step on a single slab): the records stay where they are; slot d of the new order learns its
   // source, and the mass-matrix assembly -- which reads every particle anyway -- moves, wraps and writes it (ecsim.hip).
-  if (defer && !mig && s.n > 0 && s.d.src) {
+  // On z-slabs too (the assembly only: defer == 1): what the neighbours sent stays in the receive buffer and gets the source
+  // indices -1 - i; no buckets there.
+  if (defer && (!mig || defer == 1) && (s.n > 0 || n_in > 0) && s.d.src) {
     // the binning filled the cells' buckets (bin_particle) unless a cell overflowed its bucket: then the index is built
     // from the keys (k_index: 12 B per particle)
     bool use_bucket = false;
@@ -956,10 +973,11 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap, int defer)
     }
     if (!use_bucket) {
       Timed t(c, "index");
-      hipLaunchKernelGGL(k_index, dim3(pgrid(s.n)), dim3(kBlock), 0, c->stream, s.d, s.n);
+      if (s.n > 0) hipLaunchKernelGGL(k_index, dim3(pgrid(s.n)), dim3(kBlock), 0, c->stream, s.d, s.n);
+      if (n_in > 0) hipLaunchKernelGGL(k_index_incoming, dim3(pgrid(n_in)), dim3(kBlock), 0, c->stream, s.d, n_in, s.mig_cell, s.mig_rank);
       XPIC_HIP(hipGetLastError());
     }
-    s.deferred = true; s.def_step = step; s.def_wrap = wrap; s.def_n_old = s.n; s.def_bucket = use_bucket;
+    s.deferred = true; s.def_step = step; s.def_wrap = wrap; s.def_n_old = s.n; s.def_bucket = use_bucket; s.def_n_in = n_in;
     s.n = total;
     return 0;
   }
