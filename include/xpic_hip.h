@@ -188,7 +188,9 @@ int xpic_set_fill_kernel(xpic_ctx* ctx, int kind);
  * move and the periodic wrap and writes the sorted copy on its way.  on = 2 (ecsim): the assembly only reads through the
  * index and second_push -- which is bound by memory anyway -- writes the sorted copy with the new velocities.  Same
  * particles, same cells, same arithmetic as on = 0 (scatter first); any other reader of a sort (diagnostics, downloads,
- * the phase entry points) resolves a pending deferral by the plain scatter.  Single slab only. */
+ * the phase entry points) resolves a pending deferral by the plain scatter.  On z-slabs the assembly's form is used as well
+ * (records received from the neighbours are gathered out of the receive buffer); the basic step and on = 2 defer on a single
+ * slab only. */
 int xpic_set_fused_rebin(xpic_ctx* ctx, int on);
 int xpic_get_fill_variant(xpic_ctx* ctx, int* out3);
 /* MatMult on a z-slab with neighbours: on = 1 posts the ghost exchange of the operand (VecScatterBegin), applies
