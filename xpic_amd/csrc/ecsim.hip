@@ -388,8 +388,9 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
 #pragma unroll
       for (int a = 0; a < 6; ++a) rec[a] = *reinterpret_cast<const double*>(rb[a] + (size_t)off8);
     }
-    const unsigned long long incm = __ballot(inc);
+    unsigned long long incm = 0ull;
     if (__builtin_expect(__ballot(on && !near) != 0, 0)) {
+      incm = __ballot(inc);
       double far[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       if (on && !near && !inc) {
 #pragma unroll
@@ -437,9 +438,14 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     cur[0] += cur[3] * st;
     cur[1] += cur[4] * st;
     cur[2] += cur[5] * st;
-    cur[0] = bound_periodic_sel(cur[0], g.Lx);
-    cur[1] = bound_periodic_sel(cur[1], g.Ly);
-    cur[2] = bound_periodic_sel(cur[2], g.Lz);
+    // (the fold leaves a coordinate inside [0, L] as it is: the thirty instructions are skipped where no lane of the pass
+    // left the box -- all but the cells next to its faces, and not only those: a fast particle lands further inside)
+    const bool out = cur[0] < 0.0 || cur[0] > g.Lx || cur[1] < 0.0 || cur[1] > g.Ly || cur[2] < 0.0 || cur[2] > g.Lz;
+    if (__builtin_expect(__ballot(out) != 0, 0)) {
+      cur[0] = bound_periodic_sel(cur[0], g.Lx);
+      cur[1] = bound_periodic_sel(cur[1], g.Ly);
+      cur[2] = bound_periodic_sel(cur[2], g.Lz);
+    }
     if (!ga_store) return; // (xpic_set_fused_rebin 2: k_second_push writes the sorted copy)
     const unsigned off8 = (unsigned)drel << 3;
 #if FILL_GA_EXP != 1

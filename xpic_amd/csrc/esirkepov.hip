@@ -572,9 +572,13 @@ __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkep
     if (p >= 0) {
       if (GA) { // correct_coordinates of the deferred re-binning (k_scatter<false, true>'s arithmetic); here, at the record's
         // first use: directly behind the loads it made the wave sit out their whole latency at the top of every round
-        r[0] = bound_periodic_sel(r[0], g.Lx);
-        r[1] = bound_periodic_sel(r[1], g.Ly);
-        r[2] = bound_periodic_sel(r[2], g.Lz);
+        // (the fold leaves a coordinate inside [0, L] as it is: skipped where no lane of the wave left the box)
+        const bool out = r[0] < 0.0 || r[0] > g.Lx || r[1] < 0.0 || r[1] > g.Ly || r[2] < 0.0 || r[2] > g.Lz;
+        if (__builtin_expect(__ballot(out) != 0, 0)) {
+          r[0] = bound_periodic_sel(r[0], g.Lx);
+          r[1] = bound_periodic_sel(r[1], g.Ly);
+          r[2] = bound_periodic_sel(r[2], g.Lz);
+        }
       }
       const double old_r[3] = {r[0], r[1], r[2]};
       double Ep[3] = {0, 0, 0}, Bp[3] = {0, 0, 0};
