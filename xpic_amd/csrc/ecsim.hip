@@ -362,6 +362,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
   using UniformIntsG = const __attribute__((address_space(4))) int*;
   const long pn0 = GA ? (long)((UniformIntsG)(s.cell_start + pencil0))[0] : 0;
   const long gb = pn0 > kGatherWindow ? pn0 - kGatherWindow : 0;
+  const unsigned gb32 = (unsigned)gb;
   const char* rb[6];
   char* wb[6];
 #pragma unroll
@@ -369,6 +370,9 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     rb[a] = reinterpret_cast<const char*>(s.r[a] + gb); rb[3 + a] = reinterpret_cast<const char*>(s.v[a] + gb);
     wb[a] = reinterpret_cast<char*>(s.r2[a] + pn0); wb[3 + a] = reinterpret_cast<char*>(s.v2[a] + pn0);
   }
+  // (ONE base per buffer + the pitch between its arrays, the other bases formed by scalar additions where they are used, was
+  // measured: 32 of the kernel's 145 v_readlane -- scalar registers spilled into vector lanes -- go, as many scalar additions
+  // come, the wave cycles stay)
   const long pencil_pop = GA ? (long)((UniformIntsG)(s.cell_start + pencil0))[g.nx] - pn0 : 0;
   if (GA && pencil_pop >= (1L << 29) && threadIdx.x == 0) atomicOr(gerr, 1); // the sorted copy's 32-bit offsets: the host fails the step
   // A record further than 2^29 slots above `gb` (what crossed the periodic z-boundary arrives from the other end of the
@@ -380,16 +384,21 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
   // z-slabs: a negative source index -1 - i is record i of what the neighbours sent (SortDev::inc, {r, v} per record, moved
   // and wrapped by its sender); the returned mask names those lanes: settle() must not move them again.
   auto gather = [&](int srcidx, bool on, double (&rec)[6]) -> unsigned long long {
-    const bool inc = on && srcidx < 0;
-    const unsigned long rel = (unsigned long)((long)srcidx - gb);
-    const bool near = !inc && rel < (1ul << 29);
+    // 32-bit arithmetic modulo 2^32: gb and every source index lie in [0, 2^31), so an index below gb, and the negative
+    // index of a received record, wrap to 2^31 or more -- not near.  The offset is made opaque: knowing its range the
+    // compiler widened it and added it to each of the six bases with 64-bit vector arithmetic (7 instructions per gather)
+    // instead of handing the 32-bit register to the load as its offset from a scalar base.
+    const unsigned rel = (unsigned)srcidx - gb32;
+    const bool near = rel < (1u << 29);
     if (on && near) {
-      const unsigned off8 = (unsigned)rel << 3;
+      unsigned off8 = rel << 3;
+      asm volatile("" : "+v"(off8));
 #pragma unroll
       for (int a = 0; a < 6; ++a) rec[a] = *reinterpret_cast<const double*>(rb[a] + (size_t)off8);
     }
     unsigned long long incm = 0ull;
     if (__builtin_expect(__ballot(on && !near) != 0, 0)) {
+      const bool inc = on && srcidx < 0;
       incm = __ballot(inc);
       double far[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       if (on && !near && !inc) {
@@ -432,32 +441,39 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
   // a record that has just arrived from the old order is moved, wrapped (k_scatter's arithmetic, bit for bit) and written
   // to its slot d of the new order.  (Wrapping only in the cells on the box's boundary is wrong: a particle that moves
   // several cells in a step lands further inside.)
-  auto settle = [&](double (&cur)[6], int drel, unsigned long long incm) {
-    double st = step;
-    if (__builtin_expect(incm != 0ull, 0)) st = ((incm >> lane) & 1ull) ? 0.0 : step; // (x + v * 0 = x: the sender moved it)
+  // Every lane runs it (`fresh`: the lane's record has just arrived): a lane whose record is older, or came from a
+  // neighbouring slab, moves by v * 0 = nothing, and the fold leaves what lies inside the box as it is -- as a branch around
+  // the whole thing the compiler merged the two versions of the record with 22 register moves per pass, and the `||` of the
+  // six range tests became five nested branches.
+  auto settle = [&](double (&cur)[6], int drel, bool fresh, unsigned long long incm) {
+    bool mv = fresh;
+    if (__builtin_expect(incm != 0ull, 0)) mv = fresh & !((incm >> lane) & 1ull); // (the sender moved it)
+    const double st = mv ? step : 0.0;
     cur[0] += cur[3] * st;
     cur[1] += cur[4] * st;
     cur[2] += cur[5] * st;
-    // (the fold leaves a coordinate inside [0, L] as it is: the thirty instructions are skipped where no lane of the pass
-    // left the box -- all but the cells next to its faces, and not only those: a fast particle lands further inside)
-    const bool out = cur[0] < 0.0 || cur[0] > g.Lx || cur[1] < 0.0 || cur[1] > g.Ly || cur[2] < 0.0 || cur[2] > g.Lz;
+    // (the fold's thirty instructions are skipped where no lane of the pass left the box -- all but the cells next to its
+    // faces, and not only those: a fast particle lands further inside)
+    const bool out = fresh & ((cur[0] < 0.0) | (cur[0] > g.Lx) | (cur[1] < 0.0) | (cur[1] > g.Ly) | (cur[2] < 0.0) | (cur[2] > g.Lz));
     if (__builtin_expect(__ballot(out) != 0, 0)) {
       cur[0] = bound_periodic_sel(cur[0], g.Lx);
       cur[1] = bound_periodic_sel(cur[1], g.Ly);
       cur[2] = bound_periodic_sel(cur[2], g.Lz);
     }
     if (!ga_store) return; // (xpic_set_fused_rebin 2: k_second_push writes the sorted copy)
-    const unsigned off8 = (unsigned)drel << 3;
+    if (fresh) {
+      const unsigned off8 = (unsigned)drel << 3;
 #if FILL_GA_EXP != 1
 #pragma unroll
-    for (int a = 0; a < (FILL_GA_EXP == 2 ? 3 : 6); ++a) {
+      for (int a = 0; a < (FILL_GA_EXP == 2 ? 3 : 6); ++a) {
 #if FILL_GA_NT
-      __builtin_nontemporal_store(cur[a], reinterpret_cast<double*>(wb[a] + (size_t)off8)); // read next by k_second_push, a solve later
+        __builtin_nontemporal_store(cur[a], reinterpret_cast<double*>(wb[a] + (size_t)off8)); // read next by k_second_push, a solve later
 #else
-      *reinterpret_cast<double*>(wb[a] + (size_t)off8) = cur[a];
+        *reinterpret_cast<double*>(wb[a] + (size_t)off8) = cur[a];
+#endif
+      }
 #endif
     }
-#endif
   };
 
   Prefetch pf;
@@ -500,7 +516,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
 #pragma unroll
       for (int a = 0; a < 6; ++a) cur[a] = pf.p[a];
       const int srcx_cur = pf.srcx;
-      if (GA && lane < min(kCP, cnt)) settle(cur, (int)((long)start - pn0) + lane, pf.incm);
+      if (GA) settle(cur, (int)((long)start - pn0) + lane, lane < min(kCP, cnt), pf.incm);
       unsigned long long fresh_incm = 0ull;
       int fresh = -1; // GA: slot (relative to the cell's first) of a record this lane requested during the last pass
       // particles.cpp:107-115: the factors that do not depend on the particle
@@ -522,7 +538,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
         real = false;
 #endif
         wave_sync(); // the previous pass's operand reads (and the neighbourhood store) are done
-        if (GA && fresh >= 0) { settle(cur, (int)((long)start - pn0) + fresh, fresh_incm); fresh = -1; }
+        if (GA && __ballot(fresh >= 0) != 0) { settle(cur, (int)((long)start - pn0) + fresh, fresh >= 0, fresh_incm); fresh = -1; }
         // CIC weights and the half-cell octant first: the octant decides the particle's stage slot
         const W1T<P2> w(g, cur[0], cur[1], cur[2]); // lanes without a particle: garbage in, masked by oct = 8
         const int ox = w.is[0] - w.in[0] + 1, oy = w.is[1] - w.in[1] + 1, oz = w.is[2] - w.in[2] + 1;
