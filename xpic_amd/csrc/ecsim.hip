@@ -547,19 +547,22 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
         int ocnt[8], ooff[8], slot = 0;
         bool keep = false; // this lane's particle waits for the next pass
         {
-          int run = 0;
+          // (rank and size of the lane's own octant leave the loop as lane values and `keep` is formed behind it: assigned
+          // inside the predicated block, the flag was carried as a lane mask through five scalar instructions per octant)
+          int run = 0, rk_own = 0, full_own = 0;
 #pragma unroll
           for (int o = 0; o < 8; ++o) {
             const unsigned long long mk = __ballot(oct == o);
             ocnt[o] = __popcll(mk);
             ooff[o] = run;
             if (oct == o) {
-              const int rk = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-              slot = run + rk;
-              keep = !lastpass && rk >= (ocnt[o] & ~3);
+              rk_own = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+              slot = run + rk_own;
+              full_own = ocnt[o] & ~3;
             }
             run += ocnt[o];
           }
+          keep = !lastpass && oct < 8 && rk_own >= full_own;
         }
         if (real) {
           // (shifting the odd-ranked particles of an octant by 16 bytes inside their slot, so that the two particles whose
