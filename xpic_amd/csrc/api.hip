@@ -385,6 +385,9 @@ int xpic_create(const xpic_geometry* geom, int scheme, xpic_ctx** out)
     XPIC_HIP(hipMemsetAsync(c->fill_err, 0, sizeof(int), c->stream));
     XPIC_CALL(ensure_flexible_workspace(c));
   }
+  // the round table of the Esirkepov pushes is sized with the context too (a push finds it there; without room for it the
+  // pushes compose their rounds themselves, on this rank alone: no collective depends on it)
+  if (scheme != XPIC_ECSIM && g.nx >= 6 && g.ny >= 6 && g.nzl >= 6) esk_table_alloc(c);
   XPIC_HIP(hipStreamSynchronize(c->stream));
   *out = c;
   return 0;

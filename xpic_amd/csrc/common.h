@@ -324,6 +324,7 @@ void ecsim_fill_variant(const xpic_ctx* c, int* p2, int* fx, int* ws);
 
 // esirkepov.hip: mode 0 basic::push, 1 ecsimcorr first_push, 2 ecsimcorr second_push
 int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double* B, double* J, double* pred_w_host);
+bool esk_table_alloc(xpic_ctx* c); // the precomposed rounds' table (esirkepov.hip): true if it is there
 
 // comm.hip
 int comm_ring(xpic_ctx* c, const void* down, size_t ndown, const void* up, size_t nup, void* from_up, size_t nfrom_up,

@@ -1006,6 +1006,21 @@ extern "C" int xpic_debug_esk_stamps(double* out, int reset)
 }
 #endif
 
+// rounds a pencil's table holds: one per cell + the records the push reads ahead + a few (cells of several rounds each)
+static int esk_rcap(const GridDev& g) { return g.nx + kSentinels + 8; }
+
+bool esk_table_alloc(xpic_ctx* c)
+{
+  const GridDev& g = c->g;
+  const size_t need = (size_t)g.ny * g.nzl * esk_rcap(g) * kPackDwords * sizeof(unsigned);
+  if (c->esk_tab_bytes >= need) return true;
+  (void)hipFree(c->esk_tab);
+  c->esk_tab = nullptr; c->esk_tab_bytes = 0;
+  if (hipMalloc(&c->esk_tab, need) != hipSuccess) { (void)hipGetLastError(); return false; }
+  c->esk_tab_bytes = need;
+  return true;
+}
+
 int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double* B, double* J, double* pred_w_host)
 {
   static const bool pre_env = !(getenv("XPIC_ESK_PRE") && atoi(getenv("XPIC_ESK_PRE")) == 0);
@@ -1041,16 +1056,8 @@ int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double
   XPIC_HIP(hipMemsetAsync(scal, 0, sizeof(double) * 2, c->stream));
   const char* name = mode == 0 ? "basic_push" : (mode == 1 ? "corr_first_push" : "corr_second_push");
   // the rounds of every pencil, composed beforehand (PRE); the table is sized for one round per cell + a few
-  const int rcap = g.nx + kSentinels + 8;
-  if (pre) {
-    const size_t need = (size_t)nblocks * rcap * kPackDwords * sizeof(unsigned);
-    if (c->esk_tab_bytes < need) {
-      (void)hipFree(c->esk_tab);
-      c->esk_tab = nullptr; c->esk_tab_bytes = 0;
-      if (hipMalloc(&c->esk_tab, need) == hipSuccess) c->esk_tab_bytes = need;
-      else { (void)hipGetLastError(); pre = false; } // (no room for the table: the pushes compose for themselves)
-    }
-  }
+  const int rcap = esk_rcap(g);
+  if (pre && !esk_table_alloc(c)) pre = false; // (no room for the table: the pushes compose for themselves)
   if (ga && !pre) { XPIC_CALL(sort_materialize(c, s)); ga = false; }
   int* const flags = (int*)(scal + 1); // [0] particles that moved too far, [1] a pencil with more rounds than the table holds
   auto launch = [&](bool with_table) {
