@@ -3,7 +3,7 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -munsafe-fp-atomics -Wall -Wno-unused-function $(EXTRA)
 CSRC := xpic_amd/csrc
-SRCS := $(CSRC)/api.hip $(CSRC)/fields.hip $(CSRC)/particles.hip $(CSRC)/ecsim.hip $(CSRC)/esirkepov.hip $(CSRC)/krylov.hip $(CSRC)/precond.hip $(CSRC)/comm.hip $(CSRC)/eccapfim.hip
+SRCS := $(CSRC)/api.hip $(CSRC)/fields.hip $(CSRC)/particles.hip $(CSRC)/ecsim.hip $(CSRC)/ecsim_ws.hip $(CSRC)/esirkepov.hip $(CSRC)/krylov.hip $(CSRC)/precond.hip $(CSRC)/comm.hip $(CSRC)/eccapfim.hip
 OBJS := $(SRCS:.hip=.o)
 HDRS := $(wildcard $(CSRC)/*.h) include/xpic_hip.h
 

@@ -193,6 +193,14 @@ int xpic_set_fill_kernel(xpic_ctx* ctx, int kind);
  * slab only. */
 int xpic_set_fused_rebin(xpic_ctx* ctx, int on);
 int xpic_get_fill_variant(xpic_ctx* ctx, int* out3);
+/* Test hooks for two size limits of the gathering assembly that no test-sized box reaches on its own (results are the same
+ * for every value; only the code path changes).  XPIC_DEBUG_GATHER_WINDOW: old-order records within `value` slots of an
+ * x-pencil's first slot are fetched by 32-bit offsets, the others -- at 256^3 x 64 what crossed the periodic z boundary --
+ * by 64-bit addresses (default and maximum 2^28).  XPIC_DEBUG_PENCIL_LIMIT: a sort with an x-pencil of `value` particles or
+ * more scatters first instead of deferring (default and maximum 2^29, the reach of the sorted copy's 32-bit offsets). */
+#define XPIC_DEBUG_GATHER_WINDOW 0
+#define XPIC_DEBUG_PENCIL_LIMIT 1
+int xpic_debug_set(xpic_ctx* ctx, int what, int64_t value);
 /* MatMult on a z-slab with neighbours: on = 1 posts the ghost exchange of the operand (VecScatterBegin), applies
  * the rows of the interior planes meanwhile and the rows of the boundary planes after it (VecScatterEnd), as PETSc's
  * MPIAIJ MatMult does (the reference's KSPSolve, src/impls/ecsim/simulation.cpp:266); on = 0 exchanges first. Same result.

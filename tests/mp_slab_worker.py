@@ -2,7 +2,11 @@
 through gloo (xpic_comm_init_callbacks).  Every rank runs the same seeded problem; rank 0 also runs it on a
 single-slab context AND on the CPU oracle (whole box) and checks that the decomposed run reproduces both: fields,
 particle totals and the per-cell occupancy of the whole box (update_cells_mpi, src/interfaces/particles.cpp:118-248).
-usage: mp_slab_worker.py <scheme> [planes per slab]"""
+usage: mp_slab_worker.py <scheme> [planes per slab]
+environment: XPIC_SLAB_GATHER_WINDOW=<slots> -- the gathering assembly reaches only that far by 32-bit offsets (the far
+arm and the receive-buffer arm of its gather then meet the oracle); XPIC_SLAB_CONFINE=1 -- the LAST species lives in the
+middle of slab 0 only and is cold, so the other slabs hold no particle of it (the matL ghost-row exchange must still be
+posted at the same place of every rank's message sequence)"""
 import os
 import sys
 
@@ -25,10 +29,14 @@ def problem(scheme, n, d, seed):
     N = n[0] * n[1] * n[2]
     L = np.array(n) * np.array(d)
     parts = []
-    for _ in SORTS:
+    for i, _ in enumerate(SORTS):
         pts = np.empty((8 * N, 6))
         pts[:, :3] = rng.random((8 * N, 3)) * L
         pts[:, 3:] = rng.normal(0, vth, (8 * N, 3))
+        if CONFINE and i == len(SORTS) - 1:
+            pts = pts[: N]
+            pts[:, 2] = (0.3 + 0.4 * rng.random(N)) * CONFINE * d[2]  # CONFINE = planes of slab 0
+            pts[:, 3:] *= 0.02
         parts.append(pts)
     shape = (n[2], n[1], n[0], 3)
     E = rng.normal(0, 0.02, shape)
@@ -37,6 +45,7 @@ def problem(scheme, n, d, seed):
     return parts, E, B, B0
 
 
+CONFINE = 0  # planes of slab 0 (set by main() from XPIC_SLAB_CONFINE)
 RCCL = os.environ.get("XPIC_SLAB_TRANSPORT") == "rccl"  # one GPU per rank, RCCL over xGMI (needs >= nranks devices)
 
 
@@ -52,6 +61,8 @@ def build(scheme, n, d, dt, rank, nranks, seed):
     for fid, F in ((X.E, E), (X.B, B), (X.B0, B0)):
         ctx.set_field(fid, F[z0:z0 + nzl])
     ctx.set_tolerances(1e-12, 1e-50, 400)
+    if os.environ.get("XPIC_SLAB_GATHER_WINDOW"):
+        ctx.debug_set(X.DEBUG_GATHER_WINDOW, int(os.environ["XPIC_SLAB_GATHER_WINDOW"]))
     return ctx
 
 
@@ -81,8 +92,11 @@ def gather_field(ctx, fid, nranks):
 def main():
     scheme = sys.argv[1]
     nzl = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+    global CONFINE
     dist.init_process_group("gloo")
     rank, nranks = dist.get_rank(), dist.get_world_size()
+    if os.environ.get("XPIC_SLAB_CONFINE") == "1":
+        CONFINE = nzl
     n, d = (12, 10, nzl * nranks), (0.5, 0.4, 0.25)
     dt = 0.2 if scheme != "ecsim" else 0.8
     ctx = build(scheme, n, d, dt, rank, nranks, seed=42)
@@ -94,6 +108,8 @@ def main():
     else:
         GlooRing().attach(ctx)
     counts0 = [ctx.count(s) for s in range(2)]
+    if CONFINE:
+        assert (counts0[1] > 0) == (rank == 0), counts0  # the last species lives on slab 0 alone
     nsteps = 3
     its = [ctx.step() for _ in range(nsteps)]
     en = ctx.energy()
@@ -116,6 +132,8 @@ def main():
         print("particles before/after", tot0, tot1, "single-slab", [ref.count(s) for s in range(2)], flush=True)
         ok &= tot1 == [ref.count(s) for s in range(2)]
         ok &= any(c[1] != c[0] for c in allc)  # particles did migrate between the slabs
+        if CONFINE:
+            ok &= all(c[1][1] == 0 for c in allc[1:])  # ... but the confined species stayed where it was
         for name, fid in (("E", X.E), ("B", X.B)):
             a = ref.get_field(fid)
             err = np.abs(a - fields[name]).max() / np.abs(a).max()

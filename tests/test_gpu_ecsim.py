@@ -185,13 +185,18 @@ def test_both_assembly_kernels_match_the_oracle(oracle, grid):
         assert np.abs(Lo - g.matL()).max() <= 1e-12 * np.abs(Lo).max(), kind
 
 
+@pytest.mark.parametrize("window", [None, 150], ids=["window-2^28", "window-150"])
 @pytest.mark.parametrize("mode", [1, 2])
 @BOTH_GRIDS
-def test_deferred_scatter_equals_scatter_first(oracle, grid, mode):
+def test_deferred_scatter_equals_scatter_first(oracle, grid, mode, window):
     """xpic_set_fused_rebin: the ecsim step's re-binning leaves its scatter to the assembly (records gathered through a
     source index, moved, wrapped and written sorted on the way) -- the same particles in the same cells with the same
     position bits as the scatter-first step, over several steps with particles crossing cells and the periodic boundary, heavy and empty
-    cells, two species; and both equal the oracle."""
+    cells, two species; and both equal the oracle.
+    window-150: the gather reaches old-order records within 2^28 slots of its pencil by 32-bit offsets and takes 64-bit
+    addresses beyond (ecsim.hip: the `far` arm) -- at 256^3 x 64 what crossed the periodic z boundary, in a test box
+    nothing.  With the window cut to 150 slots (an x-pencil here holds ~ 110 records, a z-plane ~ 1100) every wave mixes
+    the two arms, and the far arm meets the oracle bit for bit."""
     import xpic_amd as X
 
     n, d, dt = grid
@@ -203,6 +208,8 @@ def test_deferred_scatter_equals_scatter_first(oracle, grid, mode):
     for sim in (o, g, h):
         assert sim.add_particles(0, heavy) == 150
     g.set_fused_rebin(mode)  # 1: the assembly writes the sorted copy, 2: the second push does
+    if window:
+        g.debug_set(X.DEBUG_GATHER_WINDOW, window)
     h.set_fused_rebin(0)
     for sim in (o, g, h):
         sim.set_tolerances(1e-12, 1e-50, 400)
@@ -228,13 +235,14 @@ def test_deferred_scatter_equals_scatter_first(oracle, grid, mode):
         assert np.abs(a - g.get_field(fid)).max() <= 1e-8 * np.abs(a).max()
 
 
-@pytest.mark.parametrize("case", ["overflow", "other_kernel", "unfused"])
+@pytest.mark.parametrize("case", ["overflow", "other_kernel", "unfused", "long_pencil"])
 def test_keyless_prebinning_falls_back(oracle, case):
     """The second push's pre-binning writes buckets and counts but no keys (cell[], rank[]) when the next re-binning will be
     read by the gathering assembly.  Three ways the keys are needed after all, each rebuilt by a binning pass over the
     un-moved records (particles.hip: rebuild_keys) and each compared with the scatter-first run and the oracle:
     a cell with more arrivals than a bucket holds (k_index), another assembly kernel chosen between two steps (the plain
-    scatter resolves the deferral), the deferral switched off between two steps."""
+    scatter resolves the deferral), the deferral switched off between two steps, an x-pencil at the limit of the sorted
+    copy's 32-bit offsets (2^29 particles in production, 100 here through xpic_debug_set: the sort scatters first)."""
     import xpic_amd as X
 
     n, d, dt = GRID_P2FX
@@ -255,11 +263,15 @@ def test_keyless_prebinning_falls_back(oracle, case):
             g.set_fill_kernel(1)
         if t == 2 and case == "unfused":
             g.set_fused_rebin(0)
+        if t == 2 and case == "long_pencil":
+            g.debug_set(X.DEBUG_PENCIL_LIMIT, 100)  # (an x-pencil of this box holds 12 x 9 = 108)
         g.profile_reset()
         assert o.step() >= 0
         g.step()
         h.step()
         rebuilt = g.profile_get("move_bin")[0]
+        if case == "long_pencil":
+            assert g.profile_get("scatter")[0] == (1 if t >= 2 else 0), t  # scattered first from the limit on
         if t == 0:
             assert rebuilt == 1  # the first step bins from scratch
         elif t == 1:

@@ -21,13 +21,35 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                                               ("ecsimcorr", 2, 32), ("ecsimcorr", 2, 64), ("ecsim", 2, 32),
                                               ("ecsim", 4, 6), ("ecsimcorr", 4, 6)])
 def test_slabs_reproduce_single_slab_and_oracle(scheme, world, nzl):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    run_slabs(scheme, world, nzl)
+
+
+def run_slabs(scheme, world, nzl, **extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", **extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(29700 + world), os.path.join(ROOT, "tests", "mp_slab_worker.py"), scheme,
            str(nzl)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
     assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-4000:]
     assert out.stdout.count(" ok") == world
+
+
+def test_slabs_with_a_short_gather_window():
+    """The gathering assembly fetches old-order records near its pencil by 32-bit offsets and the others -- at 256^3 x 64
+    what crossed the periodic z boundary -- by 64-bit addresses, lane by lane; on slabs a third arm reads what the
+    neighbours sent out of the receive buffer.  No test-sized slab has a record beyond the production window of 2^28 slots:
+    with a window of 150 slots (xpic_debug_set) every wave of the assembly mixes the three arms, and the run must still
+    equal the single-slab run and the oracle (per-cell occupancy exactly, fields 1e-8)."""
+    run_slabs("ecsim", 2, 12, XPIC_SLAB_GATHER_WINDOW="150")
+
+
+@pytest.mark.parametrize("scheme,world", [("ecsim", 2), ("ecsimcorr", 3)])
+def test_slabs_with_a_species_on_one_slab_only(scheme, world):
+    """Point-to-point messages are matched per peer in issue order, so every rank must post the matL ghost-row exchange
+    at the same place of its message sequence: behind the boundary colours of the LAST species of the list, whether or
+    not this slab holds a particle of it (round 4 posted behind the last species WITH particles: a slab without them
+    sent its ghost rows where its neighbour expected a current halo).  The last species lives in the middle of slab 0."""
+    run_slabs(scheme, world, 12, XPIC_SLAB_CONFINE="1")
 
 
 @pytest.mark.parametrize("overlap", [0, 3])

@@ -27,7 +27,7 @@ SYMBOLS = [
     "xpic_matL_apply", "xpic_matA_apply", "xpic_matL_get", "xpic_lstencil_decode", "xpic_ecsim_first_push",
     "xpic_update_cells", "xpic_ecsim_fill_current", "xpic_ecsim_second_push", "xpic_basic_push",
     "xpic_ecsimcorr_first_push", "xpic_ecsimcorr_second_push", "xpic_ecsimcorr_final_update",
-    "xpic_calculate_energy", "xpic_ecsimcorr_scalars", "xpic_solve", "xpic_set_tolerances", "xpic_set_preconditioner", "xpic_set_overlap", "xpic_comm_stats", "xpic_set_fill_kernel", "xpic_set_fused_rebin", "xpic_get_fill_variant", "xpic_step",
+    "xpic_calculate_energy", "xpic_ecsimcorr_scalars", "xpic_solve", "xpic_set_tolerances", "xpic_set_preconditioner", "xpic_set_overlap", "xpic_comm_stats", "xpic_set_fill_kernel", "xpic_set_fused_rebin", "xpic_get_fill_variant", "xpic_debug_set", "xpic_step",
     "xpic_energy", "xpic_momentum", "xpic_charge_density", "xpic_moment_density", "xpic_cell_traversal", "xpic_implicit_esirkepov_interpolate",
     "xpic_implicit_esirkepov_decompose", "xpic_charge_collect", "xpic_charge_columns", "xpic_comm_rccl_unique_id", "xpic_comm_init_rccl", "xpic_comm_init_callbacks", "xpic_comm_size",
     "xpic_profile_enable", "xpic_profile_reset", "xpic_profile_get", "xpic_probe_copy_bandwidth",
@@ -57,6 +57,7 @@ class Geometry(C.Structure):
                 ("rank", C.c_int32), ("nranks", C.c_int32), ("device", C.c_int32), ("self_ring", C.c_int32)]
 
 
+DEBUG_GATHER_WINDOW, DEBUG_PENCIL_LIMIT = 0, 1  # include/xpic_hip.h: xpic_debug_set
 VERSION_EXPERIMENT_BIT = 0x40000000  # include/xpic_hip.h: XPIC_VERSION_EXPERIMENT_BIT
 
 
@@ -329,6 +330,10 @@ class Context:
         o = (C.c_int * 3)()
         self._ck(self.L.xpic_get_fill_variant(self.h, o))
         return bool(o[0]), bool(o[1]), bool(o[2])
+
+    def debug_set(self, what, value):
+        """test hooks (include/xpic_hip.h): DEBUG_GATHER_WINDOW, DEBUG_PENCIL_LIMIT"""
+        self._ck(self.L.xpic_debug_set(self.h, int(what), C.c_int64(int(value))))
 
     def set_overlap(self, on):
         self._ck(self.L.xpic_set_overlap(self.h, int(on)))  # bit 0: operator halos, bit 1: matL ghost rows

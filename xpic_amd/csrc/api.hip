@@ -142,13 +142,15 @@ static int ecsim_fill_current(xpic_ctx* c)
     }
   }
   XPIC_CALL(vec_set(c, c->field[XPIC_CURRI], 0.0));
+  XPIC_HIP(hipMemsetAsync(c->fill_err, 0, sizeof(int), c->stream));
   bool first_sort = first_touch;
   XPIC_CALL(halo_fill(c, c->field[XPIC_B], 1)); // DMGlobalToLocal(B) :474
-  // the last species with particles completes the ghost rows of matL: its assembly posts their exchange behind its
-  // boundary colours (fields.hip: matL_ghost_rows_post), the neighbours' rows are added when every launch is done
-  int last = -1;
-  for (size_t i = 0; i < c->sorts.size(); ++i)
-    if (c->sorts[i].n > 0) last = (int)i;
+  // the LAST species completes the ghost rows of matL: its assembly posts their exchange behind its boundary colours
+  // (fields.hip: matL_ghost_rows_post), the neighbours' rows are added when every launch is done.  "Last" is the last of
+  // the list, not the last with particles on this slab: point-to-point messages are matched per peer in issue order, so
+  // the post must sit at the same place of the message sequence on every rank (a slab without particles of that species
+  // posts from ecsim_fill_sort's empty-species return)
+  const int last = (int)c->sorts.size() - 1;
   for (size_t i = 0; i < c->sorts.size(); ++i) {
     Sort& s = c->sorts[i];
     XPIC_HIP(hipMemsetAsync(s.currI, 0, sizeof(double) * c->nvec, c->stream));
@@ -157,8 +159,8 @@ static int ecsim_fill_current(xpic_ctx* c)
     XPIC_CALL(halo_add(c, s.currI, 1));                          // DMLocalToGlobal(ADD) particles.cpp:56
     XPIC_CALL(vec_axpy(c, c->field[XPIC_CURRI], 1.0, s.currI)); // particles.cpp:57
   }
-  XPIC_CALL(matL_ghost_rows_finish(c)); // (posts first when no species had particles: the cleared rows travel)
-  return 0;
+  XPIC_CALL(matL_ghost_rows_finish(c)); // (posts first when there is no species at all: the cleared rows travel)
+  return ecsim_fill_check(c);
 }
 
 // ecsim::Simulation::final_update (src/impls/ecsim/simulation.cpp:241-253)
@@ -290,7 +292,7 @@ const char* xpic_last_error(void) { return g_error.c_str(); }
 int xpic_version(void)
 {
   // bit 30: some object of this library was built with -DXPIC_EXPERIMENT (ablation switches, in-kernel timers)
-  const bool exp = XPIC_TU_EXPERIMENT || experiment_ecsim() || experiment_esirkepov();
+  const bool exp = XPIC_TU_EXPERIMENT || experiment_ecsim() || experiment_ecsim_ws() || experiment_esirkepov();
   return XPIC_VERSION | (exp ? XPIC_VERSION_EXPERIMENT_BIT : 0);
 }
 
@@ -718,6 +720,24 @@ int xpic_set_fill_kernel(xpic_ctx* ctx, int kind)
   CTX_CHECK(ctx);
   XPIC_CHECK(kind == 0 || kind == 1, "unknown assembly kernel (0 classic, 1 warp-specialised)");
   ctx->fill_kernel = kind;
+  return 0;
+}
+
+int xpic_debug_set(xpic_ctx* ctx, int what, int64_t value)
+{
+  CTX_CHECK(ctx);
+  switch (what) {
+    case XPIC_DEBUG_GATHER_WINDOW:
+      XPIC_CHECK(value >= 1 && value <= (1 << 28), "gather window: 1 .. 2^28 slots");
+      ctx->gather_window = (int)value;
+      return 0;
+    case XPIC_DEBUG_PENCIL_LIMIT:
+      XPIC_CHECK(value >= 1 && value <= (1 << 29), "pencil limit: 1 .. 2^29 particles");
+      ctx->pencil_limit = (int)value;
+      return 0;
+    default:
+      XPIC_CHECK(false, "xpic_debug_set: unknown knob");
+  }
   return 0;
 }
 

@@ -10,12 +10,20 @@
 
 #include "../../include/xpic_hip.h"
 
-// Experiment builds.  The kernels carry ablation switches and in-kernel timers (FILL_EXP, FILL_STAMPS, ESK_EXP, ESK_STAMPS:
-// some of them produce wrong physics by design).  They are honoured ONLY under -DXPIC_EXPERIMENT, and an object built that
-// way says so through xpic_version() (bit 30 set), which tests/test_abi.py and xpic_amd/__init__.py refuse: a stray
-// EXTRA=-DFILL_EXP=1 no longer builds a library that loads and passes the ABI test.
-#if !defined(XPIC_EXPERIMENT) && ((defined(FILL_EXP) && FILL_EXP != 0) || defined(FILL_STAMPS) || (defined(ESK_EXP) && ESK_EXP != 0) || defined(ESK_STAMPS))
-#error "FILL_EXP / FILL_STAMPS / ESK_EXP / ESK_STAMPS are experiment switches: build with -DXPIC_EXPERIMENT as well"
+// Experiment builds.  The kernels carry ablation switches, in-kernel timers and tunables (some of the switches produce
+// wrong physics by design; every tunable changes generated code that no test has seen).  A value for any of them on the
+// command line is honoured ONLY under -DXPIC_EXPERIMENT, and an object built that way says so through xpic_version()
+// (bit 30 set), which tests/test_abi.py and xpic_amd/__init__.py refuse: a stray EXTRA=-DFILL_KCP=48 does not build a
+// library that loads and passes the ABI test.  This header comes first in every translation unit, before the sources
+// give the tunables their defaults, so "defined here" means "defined on the command line".
+#if !defined(XPIC_EXPERIMENT) && (defined(FILL_EXP) || defined(FILL_STAMPS) || defined(FILL_GA_EXP) || defined(FILL_GA_NOCHAIN) || \
+  defined(FILL_KCP) || defined(FILL_OCC) || defined(FILL_PITCH) || defined(FILL_WPITCH) || defined(FILL_WS_KCP) || \
+  defined(FILL_WS_PRIO_C) || defined(FILL_WS_PRIO_P) || defined(FILL_WS_PRIO_F) || defined(ESK_EXP) || defined(ESK_STAMPS) || \
+  defined(ESK_BOX_GENERIC) || defined(ESK_PIPE) || defined(ESK_LANES) || defined(ESK_COLS1) || defined(ESK_SEG0) || defined(ESK_OCC1) || \
+  defined(ESK_DRAIN0) || defined(ESK_TILE_LATE) || defined(XPIC_CHEB_MIN_ZC) || defined(BAR_SCHED_SCALED) || defined(BAR_SCHED_GROUP) || \
+  defined(XPIC_MAX_PER_Z) || defined(XPIC_SLAB_FIRST_TOUCH) || defined(XPIC_CHEB_M_BOUND) || defined(XPIC_BUCKET_CAP) || \
+  defined(XPIC_DEFAULT_FUSED_REBIN) || defined(XPIC_DEFAULT_PRECOND) || defined(XPIC_DEFAULT_FILL_KERNEL))
+#error "a build switch of the kernels was set on the command line: that is an experiment build, add -DXPIC_EXPERIMENT"
 #endif
 #ifdef XPIC_EXPERIMENT
 #define XPIC_TU_EXPERIMENT 1
@@ -38,6 +46,7 @@ namespace xpic {
 void set_error(const std::string& msg);
 // 1 when the translation unit was built with -DXPIC_EXPERIMENT (one per kernel file that has experiment switches)
 int experiment_ecsim();
+int experiment_ecsim_ws();
 int experiment_esirkepov();
 
 #define XPIC_HIP(call)                                                                         \
@@ -194,6 +203,8 @@ struct xpic_ctx {
   int* fill_err = nullptr; // set by k_ecsim_fill_ws when one of its bounded waits gave up
   int fused_rebin = XPIC_DEFAULT_FUSED_REBIN; // ecsim step: the re-binning's scatter is deferred -- 1: the assembly gathers, moves and writes
                                               // the sorted copy; 2: the assembly only gathers, k_second_push writes the sorted copy; 0: scatter first
+  int gather_window = 1 << 28;  // slots the gathering assembly reaches by 32-bit offsets around a pencil's first slot (xpic_debug_set)
+  int pencil_limit = 1 << 29;   // x-pencils of this many particles or more are scattered first (the sorted copy's 32-bit offsets)
   int fill_kernel = XPIC_DEFAULT_FILL_KERNEL; // 1: warp-specialised assembly (8-wave workgroups, producer / consumer waves) where the grid allows; 0: classic
   std::vector<xpic::Sort> sorts;
   // Krylov workspace
@@ -319,6 +330,7 @@ int momentum_sums_global(xpic_ctx* c, Sort& s, const double* E, double* out6);
 
 // ecsim.hip
 int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, double* matL, bool first_sort, bool post_ghost_rows);
+int ecsim_fill_check(xpic_ctx* c); // the assembly's device-side error word, agreed on by all slabs (once per assembly)
 int build_ltab(xpic_ctx* c);
 void ecsim_fill_variant(const xpic_ctx* c, int* p2, int* fx, int* ws);
 

@@ -27,20 +27,12 @@
 // matrix-pipe cycles multiplied structural zeros.
 #include <algorithm>
 #include <array>
-#include <cstdint>
 #include <map>
 #include <type_traits>
 #include <utility>
 #include <vector>
 
-#include "common.h"
-#include "device_common.h"
-#include "lstencil.h"
-
-#ifndef FILL_EXP
-#define FILL_EXP 0 // experiments (tools/fill_exp.sh): 11 the flush without its read-modify-write loads, 12 without loads and stores (everything else intact); 1 no phase 2, 6 neither phase 1 nor phase 2, 7 as 6 and no merge,
-                   // 8 as 7 and no flush, 10 staggered workgroup starts
-#endif
+#include "ecsim_fill.h"
 
 #ifdef FILL_STAMPS
 // in-kernel section timers (experiment build only): s_memtime deltas of wave 0 summed per section over all workgroups
@@ -66,174 +58,22 @@ extern "C" int xpic_debug_fill_stamps(double* out, int reset)
 #define STAMP(k)
 #endif
 
-// wave priority (s_setprio) of phase 2, phase 1 and the chunk's tail.  Raising phase 2 alone -- the wave that has matrix
-// instructions to issue goes first against the other workgroup's wave on its SIMD -- is worth 1.3 % (97.5 -> 96.0 / 96.3 ms;
-// phase 2 = 2 / 3: 96.3-96.6; also the tail = 1 or 2: 97.2-97.8; phase 1 alone: 97.2; the tail alone: 97.7)
-#ifndef FILL_PRIO
-#define FILL_PRIO 1
-#endif
-#ifndef FILL_PRIO1
-#define FILL_PRIO1 0
-#endif
-#ifndef FILL_PRIOT
-#define FILL_PRIOT 0
-#endif
-#ifndef FILL_NO_READ2
-#define FILL_NO_READ2 0
-#endif
-// round 4, measured and left off (256^3 x 64, per assembly, A/B/A/B in one call: 96.1 as is): FILL_PEEL -- full K steps
-// without the zero-slot compare / select, the partial step peeled: 99.2 (the octant bodies double; the instruction stream,
-// not its count, pays); FILL_DTAB32 -- the merge's offsets as 32-bit words, nine loads and no unpacking: 97.2; both: 100.5;
-// FILL_NO_READ2 -- ds_read_b64 in place of the paired ds_read2_b64 operand reads (half the LDS cycles on paper): 96.7
-#ifndef FILL_GA_NT
-#define FILL_GA_NT 0
-#endif
-#ifndef FILL_GA_EXP
-#define FILL_GA_EXP 0 // experiments (results garbage): 1 the gathering assembly without its stores, 2 with the position's three only
-#endif
-#if FILL_GA_EXP && !defined(XPIC_EXPERIMENT)
-#error "FILL_GA_EXP is an experiment switch: build with -DXPIC_EXPERIMENT as well"
-#endif
-#ifndef FILL_GA_NOCHAIN
-#define FILL_GA_NOCHAIN 0 // experiment (results garbage): the gathering assembly without its index indirection -- what the stores and the move cost alone
-#endif
-#if FILL_GA_NOCHAIN && !defined(XPIC_EXPERIMENT)
-#error "FILL_GA_NOCHAIN is an experiment switch: build with -DXPIC_EXPERIMENT as well"
-#endif
-#ifndef FILL_PEEL
-#define FILL_PEEL 0
-#endif
-#ifndef FILL_DTAB32
-#define FILL_DTAB32 0
-#endif
-#ifndef FILL_DRAIN
-#define FILL_DRAIN 3 // explicit waits for global reads where they cost nothing (see the comment in front of the flush)
-#endif
 namespace xpic {
 
 int experiment_ecsim() { return XPIC_TU_EXPERIMENT; }
 
+using namespace fill;
+
 namespace {
 
-constexpr int kW = 4;             // waves per workgroup = cells per chunk
-#ifndef FILL_KCP
-#define FILL_KCP 64
-#endif
-#ifndef FILL_OCC
-#define FILL_OCC 2
-#endif
-constexpr int kCP = FILL_KCP;      // particles staged per pass and wave: one pass for a cell of up to 64 (53 % of Poisson(64) cells)
-// One stage slot = one particle: 24 weights [c][i][h] (i: the 2 x 2 nodes transverse to the component's staggered axis,
-// h: lower / upper node along it), 9 A_p*matB, 3 I_p.  Pitch 38 doubles = 76 dwords: the 16-byte stores of 8
-// consecutive slots fall in 8 distinct bank quads (76 l mod 32 = 0,12,24,4,16,28,8,20) and the operand reads of the
-// two particles that share an LDS cycle are 12 banks apart (pitch 42 measured the same).  With pitch 38 and without the
-// LDS copies of two small tables (FILL_LEAN_LDS) four waves x 64 slots + the rest are 79 856 bytes: two workgroups per
-// CU.  Per assembly at 256^3 x 64: 48 slots 125.4 ms, 56 slots 123.9, 64 slots 121.7.
-#ifndef FILL_PITCH
-#define FILL_PITCH 38
-#endif
-constexpr int kPitch = FILL_PITCH;
-constexpr int kOffAB = 24; // [24, 33): A_p*matB row-major, [33, 36): I_p
-constexpr int kStage = kCP * kPitch;
-constexpr int kAcc = 36;          // accumulators per lane: 30 matL (component pair x octant bits of the pair) + 6 currI
-typedef double mfma_acc __attribute__((ext_vector_type(4)));
-typedef double dpair __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(1))) double GlobalDouble; // matL / currI are global memory: a pointer rebuilt from an
-// integer is 'flat' to the compiler, and flat loads also count in lgkmcnt -- the LDS-only barriers then wait for HBM
-typedef __attribute__((address_space(1))) dpair GlobalPair;
-typedef __attribute__((address_space(3))) const char* LdsBytes; // LDS addresses are 32 bits: say so where address arithmetic is hot
-typedef __attribute__((address_space(3))) double LdsDouble;
-typedef __attribute__((address_space(3))) dpair LdsDouble2;
-constexpr int kMatLines = 816;    // distinct (c1, row dy, row dz, k) streams one pencil can touch
-constexpr int kCurLines = 16;     // (c, dy, dz) streams of currI
-constexpr int kLines = kMatLines + kCurLines;
-constexpr int kThreads = kW * 64;
-constexpr int kSlots = kW + 2;    // window columns: kW finished + 2 carried
-#ifndef FILL_WPITCH
-#define FILL_WPITCH 7
-#endif
-// doubles between two window lines (>= kSlots).  The merge's 36 ds_add_f64 per lane hit lines that lie multiples of 8 apart:
-// with the natural pitch of 6 doubles those share their banks (line * 12 dwords mod 32 has period 8), an odd pitch cycles
-// through all 16 bank pairs.  Per assembly: pitch 6 106.6 ms, 7 101.5, 9 102.8, 8 138.3 (the seed and the flush give up
-// their 16-byte window accesses for it).
-constexpr int kWP = FILL_WPITCH;
-static_assert(kWP >= kSlots, "window pitch");
-constexpr int kOwn = (kLines + kThreads - 1) / kThreads; // window lines owned by a thread (init, flush, carry)
-#ifndef FILL_LEAN_LDS
-#define FILL_LEAN_LDS 1 // 1: the per-lane window offsets and the cell_start row are read from global memory (five 16-byte
-                        // loads per chunk, scalar loads) instead of LDS copies: the 6.6 KB are what lets a wave stage 64 particles
-#endif
-constexpr int kDtabPitch = 40;     // ushorts per lane of the transposed offset table (FILL_LEAN_LDS)
-constexpr int kMaxNxLds = FILL_LEAN_LDS ? 0 : 512; // pencils up to this length keep their cell_start row in LDS
-
-// accumulator of the block (c1, c2) for a particle of octant o = ox | oy << 1 | oz << 2: the rows depend on the
-// octant bit of axis c1 only, the columns on that of axis c2
-__host__ __device__ constexpr int acc_main(int c1, int c2, int o)
-{
-  const int o1 = (o >> c1) & 1, o2 = (o >> c2) & 1;
-  if (c1 == c2) return c1 * 2 + o1;
-  const int pair = c1 * 2 + (c2 > c1 ? c2 - 1 : c2);
-  return 6 + pair * 4 + o1 * 2 + o2;
-}
-// currI: instruction 1 holds the X and Y rows (bits ox, oy), instruction 2 the Z rows (bit oz)
-__host__ __device__ constexpr int acc_cur1(int o) { return 30 + (o & 1) * 2 + ((o >> 1) & 1); }
-__host__ __device__ constexpr int acc_cur2(int o) { return 34 + ((o >> 2) & 1); }
-// row of the cell block (numbering of lstencil.h: block_node_offset) of node i of group g of component c; g = octant
-// bit + h is the node slot along the component's own axis
-__host__ __device__ constexpr int row_of(int c, int g, int i)
-{
-  if (c == 0) return i * 3 + g;                                  // i = k * 2 + j
-  if (c == 1) return 12 + ((i >> 1) * 3 + g) * 2 + (i & 1);      // i = k * 2 + ix
-  return 24 + (g * 2 + (i >> 1)) * 2 + (i & 1);                  // i = j * 2 + ix
-}
-
-static_assert(kLines * kWP <= kW * kStage, "the merge window must fit in the (dead) staging area");
-
-__device__ inline void wave_sync()
-{
-  // the stage of a wave is private to it and a wave's LDS operations complete in order: draining the LDS
-  // counter orders its writes before its reads.  No workgroup barrier, and (unlike a fence) no wait on
-  // the global prefetches in flight.
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-}
-
-// raw workgroup barrier that only drains LDS traffic: global prefetches stay in flight across it
-__device__ inline void lds_barrier()
-{
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-struct Prefetch {
-  int start, cnt;  // cell_start of the cell this wave handles next
-  double p[6];     // x, y, z, vx, vy, vz of lane's particle of the next pass
-  double b;        // lane's value of the next cell's 54-value B neighbourhood
-  int srcx;        // gathering assembly: source index of slot start + kCP + lane (the second pass's records)
-  unsigned long long incm; // ... and the lanes whose record came from a neighbouring slab (already moved: no first_push for it)
-};
 // gathering assembly: what is requested TWO cells ahead -- the cell's range and the source indices of its first slots
 struct PrefetchIdx {
   int start, cnt;
   int src, srcx;   // source index of slot start + lane / start + kCP + lane
 };
-constexpr long kGatherWindow = 1L << 28; // the 32-bit offsets of the gather reach this far below and above the pencil's first slot
-
-// B neighbourhood of cell (cx,cy,cz) = every B value a CIC gather from inside that cell can touch:
-//   Bx at (xn in cx..cx+1, ys in cy-1..cy+1, zs in cz-1..cz+1)   -> [ 0,18): (kl*3 + jl)*2 + i
-//   By at (xs in cx-1..cx+1, yn in cy..cy+1, zs in cz-1..cz+1)   -> [18,36): (kl*2 + j)*3 + il
-//   Bz at (xs in cx-1..cx+1, ys in cy-1..cy+1, zn in cz..cz+1)   -> [36,54): (k*3 + jl)*3 + il
-// lane's entry of the table: the row of B it lies in (fixed for a pencil) and its x offset from the cell
-__device__ inline const double* bnb_row(const GridDev& g, const double* __restrict__ B, int lane, int cy, int cz, int* ox_out)
-{
-  *ox_out = 0;
-  if (lane >= 54) return nullptr;
-  int c, ox, oy, oz;
-  if (lane < 18) { c = 0; ox = lane % 2; oy = (lane / 2) % 3 - 1; oz = lane / 6 - 1; }
-  else if (lane < 36) { const int l = lane - 18; c = 1; ox = l % 3 - 1; oy = (l / 3) % 2; oz = l / 6 - 1; }
-  else { const int l = lane - 36; c = 2; ox = l % 3 - 1; oy = (l / 3) % 3 - 1; oz = l / 9; }
-  *ox_out = ox;
-  return B + c * g.cstride + g.node(0, g.wy(cy + oy), g.wz(cz + oz));
-}
+// (the 32-bit offsets of the gather reach `gwin` slots below and above the pencil's first slot: 2^28 in production -- the
+// widest a 32-bit byte offset allows -- and a few hundred in the parity tests of the far arm of the gather:
+// xpic_debug_set(ctx, XPIC_DEBUG_GATHER_WINDOW, n))
 
 // P2: power-of-two spacings (exact reciprocals, device_common.h); FX: nx is a multiple of the chunk width, so every
 // chunk is full and its flush is the aligned 32-byte form (the partial-chunk code paths compile away)
@@ -245,15 +85,13 @@ template <bool P2, bool FX, bool GA>
 __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, SortDev s, const double* __restrict__ B,
   double* currI, double* matL, const unsigned short* __restrict__ dtab, const int* __restrict__ linetab, const int* __restrict__ cowr, double q, double m,
   double mpw, int cy0, int cystep, int ncy, int cz0, int czstep, int my_order, int ncol_y, int per_y, int per_z, int first_sort,
-  int alias_rows, unsigned long long zord, double step, int* __restrict__ gerr, int ga_store, int bucket_cap)
+  int alias_rows, unsigned long long zord, double step, int* __restrict__ gerr, int ga_store, int bucket_cap, int gwin)
 {
   const int cy = cy0 + (int)(blockIdx.x % ncy) * cystep;
   const int cz = cz0 + (int)(blockIdx.x / ncy) * czstep;
 
   __shared__ __attribute__((aligned(16))) double sh[kW * kStage];
   __shared__ __attribute__((aligned(16))) double zslot[kPitch]; // the particle of weight zero that fills up a K = 4 step
-  __shared__ unsigned short dsc[FILL_LEAN_LDS ? 1 : kAcc * 64]; // offset (in doubles) of lane's element of accumulator e inside the merge window
-  __shared__ int cstart[kMaxNxLds + 2];
   __shared__ double bnb[kW][54];
   // the wave index is the same for all lanes: say so (readfirstlane), or the compiler treats every branch and count that
   // depends on it (active, cnt, lastpass, the K-step loops) as divergent and guards them with exec masks and VALU compares
@@ -273,14 +111,9 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
   const int offI18 = 8 * (kOffAB + 9 + (qb >> 1));       // byte offset of I_p[X] for the blocks (X, h), of I_p[Y] for (Y, h)
   const int offA8 = 8 * offA, offB8 = 8 * offB;
 
-  if (!FILL_LEAN_LDS)
-    for (int i = threadIdx.x; i < kAcc * 64; i += kThreads) dsc[i] = dtab[i];
   if (threadIdx.x < kPitch) zslot[threadIdx.x] = 0.0;
 
   const long pencil0 = ((long)cz * g.ny + cy) * g.nx;
-  const bool cs_lds = !FILL_LEAN_LDS && g.nx <= kMaxNxLds;
-  if (cs_lds)
-    for (int i = threadIdx.x; i <= g.nx; i += kThreads) cstart[i] = s.cell_start[pencil0 + i];
   // address of column 0 of the window lines this thread owns (line = thread + mm * kThreads), first-touch flag in bit 0
   uintptr_t lbase[kOwn];
 #pragma unroll
@@ -319,13 +152,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     lbase[mm] = (uintptr_t)base | (first ? 1u : 0u);
   }
 
-  // cstart is read by other threads from the first chunk on
-  __syncthreads();
-#if FILL_EXP == 10
-  // stagger: the workgroups of a launch start together and would march in step chip-wide (all compute, then all
-  // flush); spread their phases over one chunk period
-  for (int d = (int)((blockIdx.x * 2654435761u) >> 29); d > 0; --d) __builtin_amdgcn_s_sleep(78);
-#endif
+  __syncthreads(); // (the zero slot)
 
   // cells are visited in the order 1, 2, ..., nx-1, 0 so that finished columns start 64-byte aligned
   auto cell_x = [&](int i) { return (i + 1 == g.nx) ? 0 : i + 1; };
@@ -335,11 +162,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     pf.start = 0; pf.cnt = 0; pf.b = 0.0;
     if (i >= g.nx) return;
     const int cx = cell_x(i);
-    if (cs_lds) {
-      pf.start = __builtin_amdgcn_readfirstlane(cstart[cx]);
-      pf.cnt = __builtin_amdgcn_readfirstlane(cstart[cx + 1]) - pf.start;
-    }
-    else {
+    {
       // wave-uniform index: a scalar load (cell_start does not change while this kernel runs; requesting it a chunk
       // ahead of the particle loads it addresses was measured: no change)
       using UniformInts = const __attribute__((address_space(4))) int*;
@@ -356,12 +179,13 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     }
   };
   // ---- gathering form.  Addresses: 32-bit byte offsets from two wave-uniform bases per array -- the old-order arrays from
-  // kGatherWindow slots below the pencil's first slot (records further away take 64-bit addresses, lane by lane), the
+  // `gwin` slots below the pencil's first slot (records further away take 64-bit addresses, lane by lane), the
   // new-order arrays from the pencil's first slot -- so that one shifted index serves the six arrays of a
   // record (64-bit address arithmetic per array cost 24 vector instructions per pass).
   using UniformIntsG = const __attribute__((address_space(4))) int*;
   const long pn0 = GA ? (long)((UniformIntsG)(s.cell_start + pencil0))[0] : 0;
-  const long gb = pn0 > kGatherWindow ? pn0 - kGatherWindow : 0;
+  const long gb = pn0 > gwin ? pn0 - gwin : 0;
+  const unsigned near_span = 2u * (unsigned)gwin;
   const unsigned gb32 = (unsigned)gb;
   const char* rb[6];
   char* wb[6];
@@ -374,7 +198,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
   // measured: 32 of the kernel's 145 v_readlane -- scalar registers spilled into vector lanes -- go, as many scalar additions
   // come, the wave cycles stay)
   const long pencil_pop = GA ? (long)((UniformIntsG)(s.cell_start + pencil0))[g.nx] - pn0 : 0;
-  if (GA && pencil_pop >= (1L << 29) && threadIdx.x == 0) atomicOr(gerr, 1); // the sorted copy's 32-bit offsets: the host fails the step
+  if (GA && pencil_pop >= (1L << 29) && threadIdx.x == 0) atomicOr(gerr, kFillErrPencil); // the sorted copy's 32-bit offsets: the host fails the step
   // A record further than 2^29 slots above `gb` (what crossed the periodic z-boundary arrives from the other end of the
   // array; a particle that jumped dozens of planes) takes a plain 64-bit address: per lane, rare.
   // Every lane of the wave calls it (`on`: this lane wants a record).  The far records are fetched in a branch the WHOLE
@@ -389,7 +213,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     // compiler widened it and added it to each of the six bases with 64-bit vector arithmetic (7 instructions per gather)
     // instead of handing the 32-bit register to the load as its offset from a scalar base.
     const unsigned rel = (unsigned)srcidx - gb32;
-    const bool near = rel < (1u << 29);
+    const bool near = rel < near_span;
     if (on && near) {
       unsigned off8 = rel << 3;
       asm volatile("" : "+v"(off8));
@@ -466,11 +290,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
 #if FILL_GA_EXP != 1
 #pragma unroll
       for (int a = 0; a < (FILL_GA_EXP == 2 ? 3 : 6); ++a) {
-#if FILL_GA_NT
-        __builtin_nontemporal_store(cur[a], reinterpret_cast<double*>(wb[a] + (size_t)off8)); // read next by k_second_push, a solve later
-#else
-        *reinterpret_cast<double*>(wb[a] + (size_t)off8) = cur[a];
-#endif
+        *reinterpret_cast<double*>(wb[a] + (size_t)off8) = cur[a]; // (non-temporal stores: measured, no change)
       }
 #endif
     }
@@ -484,9 +304,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     prefetch_idx(wave + kW, pi);
   }
   else prefetch_cell(wave, pf);
-#if FILL_DRAIN
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-#endif
+  __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): see the comment in front of the flush
   double carry[kOwn][2];
 #pragma unroll
   for (int mm = 0; mm < kOwn; ++mm) carry[mm][0] = carry[mm][1] = 0.0;
@@ -503,9 +321,6 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
   const int nch = (g.nx + kW - 1) / kW;
   for (int j = 0; j < nch; ++j) {
     STAMP(0);
-#if FILL_PRIO || FILL_PRIO1 || FILL_PRIOT
-    __builtin_amdgcn_s_setprio(FILL_PRIO1);
-#endif
     const int i = j * kW + wave;
     const bool active = FX || i < g.nx; // full chunks: every wave has a cell
 
@@ -669,9 +484,10 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
         // operand set, the next step's ten reads issued between this step's products and its matrix instructions, also
         // across octants -- compiled as intended, 6 register moves per step, and was SLOWER: 115.1 against 108.6 ms per
         // assembly.  The other wave of the SIMD already covers the read latency; what a step costs is issue slots.)
-#if FILL_PRIO
-        __builtin_amdgcn_s_setprio(FILL_PRIO);
-#endif
+        // wave priority: of the two waves on a SIMD (one per workgroup of the CU) the one with matrix instructions to issue
+        // goes first: 97.5 -> 96.0 / 96.3 ms per assembly (priority 2 / 3: 96.3-96.6; raising phase 1 or the chunk's tail
+        // instead, or too: 97.2-97.8)
+        __builtin_amdgcn_s_setprio(1);
 #if FILL_EXP != 1 && !(FILL_EXP >= 6 && FILL_EXP <= 8)
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
@@ -687,20 +503,10 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
             const LdsDouble* spA = (const LdsDouble*)(sb + offA8);
             const LdsDouble* spB = (const LdsDouble*)(sb + offB8);
             double a[3], b[3];
-#if FILL_NO_READ2
-            // (ds_read2_b64 moves 128 B per LDS cycle, ds_read_b64 256: keep the compiler from pairing the reads of one
-            // base by hiding the second address behind an opaque copy)
-            {
-              LdsBytes sA1 = sb + offA8 + 64, sB1 = sb + offB8 + 64, sA2 = sb + offA8 + 128, sB2 = sb + offB8 + 128;
-              asm volatile("" : "+v"(sA1), "+v"(sB1), "+v"(sA2), "+v"(sB2));
-              a[0] = spA[0]; b[0] = spB[0];
-              a[1] = *(const LdsDouble*)sA1; b[1] = *(const LdsDouble*)sB1;
-              a[2] = *(const LdsDouble*)sA2; b[2] = *(const LdsDouble*)sB2;
-            }
-#else
+            // (the compiler pairs these into ds_read2_b64; unpaired ds_read_b64 -- half the LDS cycles on paper -- measured 96.7
+            // against 96.1 ms)
 #pragma unroll
             for (int c = 0; c < 3; ++c) { a[c] = spA[c * 8]; b[c] = spB[c * 8]; }
-#endif
             // the step's 9 A_p*matB per particle: the same 72 bytes for the 16 lanes of a particle (a DPP row
             // broadcast of one 8-byte read per lane was measured 6 % slower: the VALU is the scarcer resource here)
             const LdsDouble2* u = (const LdsDouble2*)(sp + kOffAB);
@@ -717,13 +523,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
             // (and the blocks 2, 3 of the second) have no target in the merge (they go to the lane's dummy double): every
             // lane passes I_p[c], read at a lane-dependent offset, and nothing has to be selected or zeroed
             const double ai1 = qb < 2 ? b[0] : b[1], ai2 = b[2];
-#if FILL_NO_READ2
-            LdsBytes sI2 = sb + 8 * (kOffAB + 11);
-            asm volatile("" : "+v"(sI2));
-            const double bi1 = *(const LdsDouble*)(sb + offI18), bi2 = *(const LdsDouble*)sI2;
-#else
             const double bi1 = *(const LdsDouble*)(sb + offI18), bi2 = sp[kOffAB + 11];
-#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c1 = 0; c1 < 3; ++c1)
@@ -734,44 +534,28 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
             acc[acc_cur1(o)] = __builtin_amdgcn_mfma_f64_4x4x4f64(ai1, bi1, acc[acc_cur1(o)], 0, 0, 0);
             acc[acc_cur2(o)] = __builtin_amdgcn_mfma_f64_4x4x4f64(ai2, bi2, acc[acc_cur2(o)], 0, 0, 0);
           };
-#if FILL_PEEL
-          // full steps read their four slots unconditionally; only a cell's last pass can end an octant on a partial step,
-          // whose missing rows read the zero slot (peeled: the compare and the select of every step were 3 of its 17
-          // vector instructions)
-          const int nfull = no >> 2;
-          for (int t = 0; t < nfull; ++t, spr += 4 * kPitch * 8) kstep(spr);
-          if (nst > nfull) kstep(spr < seg_end ? spr : (LdsBytes)(const char*)zslot);
-#else
+          // (full steps without the zero-slot compare / select, the partial step peeled, was measured: 99.2 against 96.1 ms --
+          // the octant bodies double; the instruction stream, not its count, pays)
           for (int t = 0; t < nst; ++t, spr += 4 * kPitch * 8) kstep(spr < seg_end ? spr : (LdsBytes)(const char*)zslot);
-#endif
         }
 #endif
-#if FILL_PRIO || FILL_PRIO1
-        __builtin_amdgcn_s_setprio(FILL_PRIO1);
-#endif
+        __builtin_amdgcn_s_setprio(0);
         STAMP(2);
-#if FILL_DRAIN >= 3
         // the next pass's particles are waited for HERE (they had this pass's phase 2 to arrive; on every path out of the
         // pass body, or the compiler keeps its own): left to the compiler the wait sits at the head of EVERY pass, the
         // first one of a chunk included, where -- the memory counter being in order -- it is a wait for the previous
         // chunk's flush stores
         __builtin_amdgcn_s_waitcnt(0x0F70);
-#endif
         if (lastpass) break;
         real = real_next;
       }
     }
 
     STAMP(2);
-#if FILL_PRIO || FILL_PRIO1 || FILL_PRIOT
-    __builtin_amdgcn_s_setprio(FILL_PRIOT);
-#endif
     // next chunk's cell: particle data and B neighbourhood travel while this chunk is merged and flushed
-#if FILL_DRAIN >= 2
     // (nothing is outstanding here but the previous chunk's stores: said explicitly, so that the compiler does not guard its
     // re-use of the pass loop's load registers with waits BEHIND the requests below)
     __builtin_amdgcn_s_waitcnt(0x0F70);
-#endif
     if (GA) {
       prefetch_rec(i + kW, pi, pf);   // its indices were requested a chunk ago
       prefetch_idx(i + 2 * kW, pi);
@@ -822,18 +606,9 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     unsigned wdst[kAcc]; // requested now, used after the window is seeded
 #pragma unroll
     for (int e = 0; e < kAcc; ++e) wdst[e] = 0;
-    if (FILL_LEAN_LDS && FILL_DTAB32) {
-      // the lane's 36 offsets as 32-bit words (a second copy of the table behind the 16-bit one): nine 16-byte loads and
-      // no unpacking (the shifts and masks of the packed form were ~50 vector instructions per merge)
-      const uint4* q = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned*>(dtab + 64 * kDtabPitch) + lane * kAcc);
-#pragma unroll
-      for (int k = 0; k < kAcc / 4; ++k) {
-        const uint4 w4 = q[k];
-        wdst[4 * k] = w4.x; wdst[4 * k + 1] = w4.y; wdst[4 * k + 2] = w4.z; wdst[4 * k + 3] = w4.w;
-      }
-    }
-    else if (FILL_LEAN_LDS) {
-      // the lane's 36 offsets are 72 contiguous bytes of the table (transposed on the host): five 16-byte loads
+    {
+      // the lane's 36 offsets are 72 contiguous bytes of the table (transposed on the host): five 16-byte loads (as 32-bit
+      // words, nine loads and no unpacking: 97.2 against 96.1 ms)
       const uint4* q = reinterpret_cast<const uint4*>(dtab + lane * kDtabPitch);
 #pragma unroll
       for (int k = 0; k < kDtabPitch / 8; ++k) {
@@ -843,10 +618,6 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
         for (int h = 0; h < 8; ++h)
           if (k * 8 + h < kAcc) wdst[k * 8 + h] = (w[h >> 1] >> (16 * (h & 1))) & 0xffffu; // byte offset
       }
-    }
-    else {
-#pragma unroll
-      for (int e = 0; e < kAcc; ++e) wdst[e] = dsc[e * 64 + lane];
     }
     STAMP(3);
     lds_barrier();
@@ -881,24 +652,22 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
       for (int e = 0; e < kAcc; ++e) {
         // (masking out the lanes of the six currI accumulators that have no target, instead of letting them add into their
         // dummy doubles, was measured: no difference)
-        unsafeAtomicAdd((double*)(wv + (FILL_LEAN_LDS ? wdst[e] : 8 * wdst[e])), acc[e]);
+        unsafeAtomicAdd((double*)(wv + wdst[e]), acc[e]);
         acc[e] = 0.0;
       }
     }
     lds_barrier();
     STAMP(6);
-#if FILL_DRAIN
     __builtin_amdgcn_s_waitcnt(0x0F70);
-#endif
     // (The next chunk's first use of the prefetched registers is guarded by s_waitcnt vmcnt(0): the stores of the flush
     // below sit in divergent branches, so the compiler cannot count them, and every chunk begins by waiting for its
-    // predecessor's stores.  FILL_DRAIN removes that wait step by step.  1 -- all reads declared complete here and before
+    // predecessor's stores.  Explicit waits remove that one step by step.  1 -- all reads declared complete here and before
     // the loop: 108.5 against 97.7 ms, NOT because of the stores: the compiler then guards its re-use of the pass loop's
     // load registers with vmcnt(3) .. (0) BEHIND the next chunk's requests, a full memory round trip.  2 -- also before
     // those requests: 97.9.  3 -- also at the end of every pass (the head of the pass loop otherwise keeps counted waits
     // that, the counter being in order, drain the stores after all): no vmcnt wait is left between the flush and the end
     // of the next chunk's first pass, and the assembly takes 97.4 ms (A/B/A/B in one call: 98.12, 97.47, 98.15, 97.39).
-    // The acknowledgements of the flush stores were never most of what a chunk waits for; 3 is the default.)
+    // The acknowledgements of the flush stores were never most of what a chunk waits for; all three are in.)
     // ---- stream out the finished columns (plain RMW, kW consecutive doubles per line), keep 2 in registers
 #pragma unroll
     for (int mm = 0; mm < kOwn; ++mm) {
@@ -972,571 +741,6 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
   }
 }
 
-
-// =====================================================================================================================
-// k_ecsim_fill_ws -- the same assembly with its parts on different waves (round 4).
-//
-// The kernel above runs every wave through phase 1 (VALU, lane = particle), phase 2 (matrix cores), merge and flush in
-// turn, two waves per SIMD: whether a SIMD's two waves complement each other (one feeding the matrix pipe while the other
-// issues vector / memory instructions) is left to chance, each wave issues a third of the time, and the merge window
-// aliases the stage, so a chunk's merge + flush cannot overlap the next chunk's phase 1.  Here ONE workgroup of 16 waves
-// owns the CU (all 160 KB of LDS, 128 registers per lane) and every SIMD holds one wave of each of four fixed roles, which
-// work on the same cell of a chunk of 4:
-//   * PRODUCER (waves 8..11): cell by cell, pass by pass it loads the particles, runs phase 1 and leaves the
-//     octant-compacted operands in one of the TWO stage buffers of its SIMD;
-//   * two CONSUMERS (waves 0..3: the octants with oz = 0, waves 4..7: oz = 1) run phase 2 out of the stage buffers -- two
-//     matrix-instruction streams per SIMD that cover each other's operand-read latency -- keep their part of the cell block
-//     in registers (26 of the 36 accumulators each) and merge it into the window when the cell is complete;
-//   * FLUSHER (waves 12..15): owns the window's lines; when all consumers have merged a chunk it adds the four finished
-//     columns to matL / currI (read-modify-write, the old values requested a chunk ahead: its memory counter holds nothing
-//     else), moves the two unfinished columns to the front and clears the rest.
-// The window (46.6 KB) has LDS of its own: a chunk's flush runs beside the next chunk's phases 1 and 2.  Nothing in the
-// main loop is a workgroup barrier: stage buffers change hands through sequence numbers in LDS (FULL / FREE), the window
-// through two counters (MERGED: consumer waves that merged a chunk, SEEDED: flusher waves that flushed and re-seeded it).
-// A consumer never waits for another consumer's cell, only -- a chunk later -- for the flush.  Every wait is a bounded
-// spin: a wave that waited longer than any schedule can need raises the ABORT word and leaves, the others follow, and the
-// host reports the assembly as failed instead of hanging the GPU.
-// Work per cell, colours, first touch, the window's line table and the octant accumulators are those of k_ecsim_fill:
-// the matrix it assembles is the same up to the summation order of the window's atomics.
-// =====================================================================================================================
-#ifndef FILL_WS_KCP
-#define FILL_WS_KCP 44
-#endif
-#ifndef FILL_WS_PRIO_C
-#define FILL_WS_PRIO_C 2 // s_setprio of the consumers / the producer / the flusher
-#endif
-#ifndef FILL_WS_PRIO_P
-#define FILL_WS_PRIO_P 1
-#endif
-#ifndef FILL_WS_PRIO_F
-#define FILL_WS_PRIO_F 0
-#endif
-constexpr int kWsCP = FILL_WS_KCP;            // slots of one stage buffer (two per SIMD: 4 x 2 x 44 x 304 B = 107 KB)
-constexpr int kWsStage = kWsCP * kPitch;      // doubles of one stage buffer
-constexpr int kWsThreads = 1024;
-constexpr int kWsFlush = 256;                 // flusher threads (own the window's lines)
-constexpr int kWsOwn = (kLines + kWsFlush - 1) / kWsFlush;
-constexpr unsigned kWsSpinLimit = 1u << 22;   // polls of ~100 cycles: three orders of magnitude beyond any legitimate wait
-enum { kFlFull = 0, kFlFree = 8 /* [half][w][b] */, kFlMerged = 24, kFlSeeded = 25, kFlAbort = 26, kFlCount = 28 };
-static_assert(kWsCP % 4 == 0 && kWsCP <= 64, "a stage buffer holds whole K = 4 steps of at most one wave of particles");
-static_assert(FILL_LEAN_LDS == 1, "k_ecsim_fill_ws reads the transposed per-lane offset table");
-static_assert((kLines * kWP + 64 + kW) * 8 + 8 * kWsStage * 8 + kPitch * 8 + kW * 54 * 8 + kW * 2 * 12 * 4 + kFlCount * 4 + 64 * kDtabPitch * 2 <= 160 * 1024,
-  "window + stage buffers + offset table exceed the LDS of a CU");
-
-// is accumulator e touched by the octants of half h (oz = h)?
-__host__ __device__ constexpr bool acc_in_half(int e, int h)
-{
-  for (int o = h * 4; o < h * 4 + 4; ++o) {
-    for (int c1 = 0; c1 < 3; ++c1)
-      for (int c2 = 0; c2 < 3; ++c2)
-        if (acc_main(c1, c2, o) == e) return true;
-    if (acc_cur1(o) == e || acc_cur2(o) == e) return true;
-  }
-  return false;
-}
-
-typedef __attribute__((address_space(3))) unsigned LdsWord;
-
-#ifdef FILL_STAMPS
-// section timers of the warp-specialised kernel (experiment build): 8 per role, of the role's first wave in every workgroup
-__device__ unsigned long long g_fill_ws_stamps[32];
-#define WSTAMP(k)                                                 \
-  do {                                                            \
-    const unsigned long long now_ = __builtin_readcyclecounter(); \
-    ws_acc_[k] += now_ - ws_t_;                                   \
-    ws_t_ = now_;                                                 \
-  } while (0)
-#define WSTAMP_INIT unsigned long long ws_t_ = __builtin_readcyclecounter(); unsigned long long ws_acc_[8] = {}
-#define WSTAMP_DUMP(base, cond)                                                                     \
-  do {                                                                                              \
-    if ((cond) && lane == 0)                                                                        \
-      for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_fill_ws_stamps[(base) + k_], ws_acc_[k_]);        \
-  } while (0)
-}  // namespace
-}  // namespace xpic
-extern "C" int xpic_debug_fill_ws_stamps(double* out, int reset)
-{
-  unsigned long long h[32];
-  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(xpic::g_fill_ws_stamps), sizeof(h)) != hipSuccess) return 1;
-  for (int i = 0; i < 32; ++i) out[i] = (double)h[i];
-  if (reset) {
-    unsigned long long z[32] = {};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(xpic::g_fill_ws_stamps), z, sizeof(z)) != hipSuccess) return 1;
-  }
-  return 0;
-}
-namespace xpic {
-namespace {
-#else
-#define WSTAMP(k)
-#define WSTAMP_INIT
-#define WSTAMP_DUMP(base, cond)
-#endif
-
-// LDS words that other waves of the workgroup write: always read / written by explicit DS instructions
-__device__ inline unsigned lds_peek(const unsigned* p)
-{
-  unsigned v;
-  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((const LdsWord*)p) : "memory");
-  return __builtin_amdgcn_readfirstlane(v);
-}
-// publish: everything this wave sent to the LDS before is complete (a wave's DS operations finish in order), then lane 0 writes
-__device__ inline void lds_post(unsigned* p, unsigned v, int lane)
-{
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"((LdsWord*)p), "v"(v) : "memory");
-}
-__device__ inline void lds_bump(unsigned* p, int lane)
-{
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"((LdsWord*)p), "v"(1u) : "memory");
-}
-// wait until *p has reached `target` (sequence numbers only grow); false: aborted (this wave or another one gave up)
-__device__ inline bool lds_wait(const unsigned* p, unsigned target, unsigned* flags)
-{
-  for (unsigned it = 0;; ++it) {
-    if ((int)(lds_peek(p) - target) >= 0) return true;
-    if ((it & 63u) == 63u) {
-      if (lds_peek(flags + kFlAbort)) return false;
-      if (it > kWsSpinLimit) {
-        asm volatile("ds_write_b32 %0, %1" ::"v"((LdsWord*)(flags + kFlAbort)), "v"(1u) : "memory");
-        return false;
-      }
-    }
-    __builtin_amdgcn_s_sleep(1);
-  }
-}
-
-template <int HALF, int... Es>
-__device__ __forceinline__ void ws_merge(std::integer_sequence<int, Es...>, char* wv, const uint4 (&dq)[kDtabPitch / 8], double (&acc)[kAcc])
-{
-  // (the offsets are read from their LDS table at every merge: kept in registers across the pencil they were spilled, and
-  // the merge reloaded them from scratch one by one -- 14 serialized round trips, 45 % of a consumer's time)
-  // lane's element of accumulator e goes to window byte offset(e) (16-bit entries of the transposed table) + 8 * w
-  auto one = [&](auto tag) {
-    constexpr int e = decltype(tag)::value;
-    if constexpr (acc_in_half(e, HALF)) {
-      const uint4 q4 = dq[e / 8];
-      const unsigned word = ((e % 8) >> 1) == 0 ? q4.x : ((e % 8) >> 1) == 1 ? q4.y : ((e % 8) >> 1) == 2 ? q4.z : q4.w;
-      const unsigned off = (word >> (16 * (e & 1))) & 0xffffu;
-      unsafeAtomicAdd((double*)(wv + off), acc[e]);
-      acc[e] = 0.0;
-    }
-  };
-  (one(std::integral_constant<int, Es>{}), ...);
-}
-
-template <bool P2>
-__global__ void __launch_bounds__(kWsThreads, 1) k_ecsim_fill_ws(GridDev g, SortDev s, const double* __restrict__ B,
-  double* currI, double* matL, const unsigned short* __restrict__ dtab, const int* __restrict__ linetab, const int* __restrict__ cowr, double q, double m,
-  double mpw, int cy0, int cystep, int ncy, int cz0, int czstep, int my_order, int ncol_y, int per_y, int per_z, int first_sort,
-  int* __restrict__ err, unsigned long long zord)
-{
-  const int cy = cy0 + (int)(blockIdx.x % ncy) * cystep;
-  const int cz = cz0 + (int)(blockIdx.x / ncy) * czstep;
-
-  __shared__ __attribute__((aligned(16))) double win[kLines * kWP + 64 + kW]; // + the per-lane dummy targets of the merge
-  __shared__ __attribute__((aligned(16))) double stage[kW * 2 * kWsStage];
-  __shared__ __attribute__((aligned(16))) double zslot[kPitch];
-  __shared__ double bnb[kW][54];
-  __shared__ __attribute__((aligned(16))) int hdr[kW][2][12]; // per stage buffer: the 8 octant counts, last-pass flag
-  __shared__ unsigned flags[kFlCount];
-  __shared__ __attribute__((aligned(16))) unsigned short dtl[64 * kDtabPitch]; // per-lane window offsets of the merge
-
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const double dt = g.dt;
-  for (int i = threadIdx.x; i < kLines * kWP + 64 + kW; i += kWsThreads) win[i] = 0.0;
-  for (int i = threadIdx.x; i < 64 * kDtabPitch; i += kWsThreads) dtl[i] = dtab[i];
-  if (threadIdx.x < kPitch) zslot[threadIdx.x] = 0.0;
-  if (threadIdx.x < kFlCount) flags[threadIdx.x] = 0u;
-  __syncthreads(); // the only workgroup barrier of the kernel
-  const int nch = g.nx / kW;
-  const long pencil0 = ((long)cz * g.ny + cy) * g.nx;
-  const int w = wave & 3; // the SIMD's cell of a chunk
-
-  // =================================================== consumers ====================================================
-  auto consumer = [&](auto half_tag) {
-    constexpr int HALF = decltype(half_tag)::value;
-    const int kk = lane >> 4, qb = (lane >> 2) & 3, qj = lane & 3;
-    const int offA8 = 8 * (qj * 2 + (qb >> 1)), offB8 = 8 * (qj * 2 + (qb & 1));
-    const int offI18 = 8 * (kOffAB + 9 + (qb >> 1));
-    double acc[kAcc];
-#pragma unroll
-    for (int e = 0; e < kAcc; ++e) acc[e] = 0.0;
-    __builtin_amdgcn_s_setprio(FILL_WS_PRIO_C);
-    unsigned pass = 0;
-    WSTAMP_INIT;
-    for (int j = 0; j < nch; ++j) {
-      for (;;) {
-        const int b = pass & 1;
-        if (!lds_wait(flags + kFlFull + w * 2 + b, pass + 1, flags)) { if (lane == 0) atomicOr(err, 1); return; }
-        WSTAMP(0);
-        const int4 h0 = *(const int4*)&hdr[w][b][0], h1 = *(const int4*)&hdr[w][b][4];
-        const int ocnt[8] = {__builtin_amdgcn_readfirstlane(h0.x), __builtin_amdgcn_readfirstlane(h0.y),
-          __builtin_amdgcn_readfirstlane(h0.z), __builtin_amdgcn_readfirstlane(h0.w), __builtin_amdgcn_readfirstlane(h1.x),
-          __builtin_amdgcn_readfirstlane(h1.y), __builtin_amdgcn_readfirstlane(h1.z), __builtin_amdgcn_readfirstlane(h1.w)};
-        const bool lastpass = __builtin_amdgcn_readfirstlane(hdr[w][b][8]) != 0;
-        const double* st = stage + (w * 2 + b) * kWsStage;
-        int run = HALF ? ocnt[0] + ocnt[1] + ocnt[2] + ocnt[3] : 0;
-        WSTAMP(1);
-#pragma unroll
-        for (int o = HALF * 4; o < HALF * 4 + 4; ++o) {
-          const int no = ocnt[o];
-          const double* seg = st + run * kPitch;
-          run += no;
-          const int nst = lastpass ? (no + 3) >> 2 : no >> 2;
-          LdsBytes spr = (LdsBytes)(const char*)(seg + kk * kPitch);
-          const LdsBytes seg_end = (LdsBytes)(const char*)(seg + no * kPitch);
-          for (int t = 0; t < nst; ++t, spr += 4 * kPitch * 8) {
-            const LdsBytes sb = spr < seg_end ? spr : (LdsBytes)(const char*)zslot;
-            const LdsDouble* sp = (const LdsDouble*)sb;
-            const LdsDouble* spA = (const LdsDouble*)(sb + offA8);
-            const LdsDouble* spB = (const LdsDouble*)(sb + offB8);
-            double a[3], bb[3];
-#if FILL_NO_READ2
-            {
-              LdsBytes sA1 = sb + offA8 + 64, sB1 = sb + offB8 + 64, sA2 = sb + offA8 + 128, sB2 = sb + offB8 + 128;
-              asm volatile("" : "+v"(sA1), "+v"(sB1), "+v"(sA2), "+v"(sB2));
-              a[0] = spA[0]; bb[0] = spB[0];
-              a[1] = *(const LdsDouble*)sA1; bb[1] = *(const LdsDouble*)sB1;
-              a[2] = *(const LdsDouble*)sA2; bb[2] = *(const LdsDouble*)sB2;
-            }
-#else
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { a[c] = spA[c * 8]; bb[c] = spB[c * 8]; }
-#endif
-            const LdsDouble2* u = (const LdsDouble2*)(sp + kOffAB);
-            const dpair u0 = u[0], u1 = u[1], u2 = u[2], u3 = u[3];
-            const double ab[9] = {u0.x, u0.y, u1.x, u1.y, u2.x, u2.y, u3.x, u3.y, sp[kOffAB + 8]};
-            double bm[9];
-#pragma unroll
-            for (int e = 0; e < 9; ++e) bm[e] = bb[e % 3] * ab[e];
-            const double ai1 = qb < 2 ? bb[0] : bb[1], ai2 = bb[2];
-#if FILL_NO_READ2
-            LdsBytes sI2 = sb + 8 * (kOffAB + 11);
-            asm volatile("" : "+v"(sI2));
-            const double bi1 = *(const LdsDouble*)(sb + offI18), bi2 = *(const LdsDouble*)sI2;
-#else
-            const double bi1 = *(const LdsDouble*)(sb + offI18), bi2 = sp[kOffAB + 11];
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c1 = 0; c1 < 3; ++c1)
-#pragma unroll
-              for (int c2 = 0; c2 < 3; ++c2)
-                acc[acc_main(c1, c2, o)] =
-                  __builtin_amdgcn_mfma_f64_4x4x4f64(a[c1], bm[c1 * 3 + c2], acc[acc_main(c1, c2, o)], 0, 0, 0);
-            acc[acc_cur1(o)] = __builtin_amdgcn_mfma_f64_4x4x4f64(ai1, bi1, acc[acc_cur1(o)], 0, 0, 0);
-            acc[acc_cur2(o)] = __builtin_amdgcn_mfma_f64_4x4x4f64(ai2, bi2, acc[acc_cur2(o)], 0, 0, 0);
-          }
-        }
-        WSTAMP(2);
-        lds_post(flags + kFlFree + (HALF * kW + w) * 2 + b, pass + 1, lane); // every operand read of this buffer has returned
-        WSTAMP(3);
-        ++pass;
-        if (lastpass) break;
-      }
-      // ---- merge this half of the cell block into the window
-      if (!lds_wait(flags + kFlSeeded, (unsigned)(kW * j), flags)) { if (lane == 0) atomicOr(err, 1); return; } // re-seeded after chunk j - 1
-      WSTAMP(5);
-      uint4 dq[kDtabPitch / 8]; // the lane's window offsets of its accumulator elements: 36 16-bit entries
-      {
-        const uint4* dp = reinterpret_cast<const uint4*>(dtl + lane * kDtabPitch);
-#pragma unroll
-        for (int k = 0; k < kDtabPitch / 8; ++k) dq[k] = dp[k];
-      }
-      ws_merge<HALF>(std::make_integer_sequence<int, kAcc>{}, (char*)(win + w), dq, acc);
-      lds_bump(flags + kFlMerged, lane);
-      WSTAMP(6);
-    }
-    WSTAMP_DUMP(HALF * 8, w == 0);
-  };
-  if (wave < kW) { consumer(std::integral_constant<int, 0>{}); return; }
-  if (wave < 2 * kW) { consumer(std::integral_constant<int, 1>{}); return; }
-
-  if (wave >= 3 * kW) {
-    // ================================================= flusher ======================================================
-    __builtin_amdgcn_s_setprio(FILL_WS_PRIO_F);
-    const int t = threadIdx.x - 3 * kW * 64;
-    // window lines this thread owns (line = t + mm * kWsFlush): address of their column 0, first-touch flag in bit 0
-    uintptr_t lbase[kWsOwn];
-#pragma unroll
-    for (int mm = 0; mm < kWsOwn; ++mm) {
-      const int line = t + mm * kWsFlush;
-      lbase[mm] = 0;
-      if (line >= kLines) continue;
-      const int ld = linetab[line];
-      const int ry = g.wy(cy + ((ld >> 2) & 3) - 1);
-      const int rz = cz + ((ld >> 4) & 3) - 1;
-      const int rzw = g.G == 0 ? (rz < 0 ? rz + g.nzl : (rz >= g.nzl ? rz - g.nzl : rz)) : rz + 1;
-      double* base = line < kMatLines
-        ? matL + g.lindex(ld & 3, rzw, ry, 0, ld >> 6)
-        : currI + (ld & 3) * g.cstride + g.node(0, ry, g.wz(rz));
-      bool first = first_sort && line < kMatLines; // no co-writer of this line runs in an earlier launch: store, do not add
-      if (first) {
-        const int bodyy = g.ny - g.ny % per_y, bodyz = g.nzl - g.nzl % per_z;
-        for (int e = 0; e < 8 && first; ++e) {
-          const int cw = cowr[line * 8 + e];
-          if (cw == 0x7fffffff) break;
-          const int oy = (cw & 0xff) - 8, oz = ((cw >> 8) & 0xff) - 8;
-          int py = cy + oy, pz = cz + oz;
-          py = py < 0 ? py + g.ny : (py >= g.ny ? py - g.ny : py);
-          if (g.G == 0) pz = pz < 0 ? pz + g.nzl : (pz >= g.nzl ? pz - g.nzl : pz);
-          else if (pz < 0 || pz >= g.nzl) continue;
-          const int ca = py < bodyy ? py % per_y : per_y + (py - bodyy);
-          const int cb = g.G == 0 ? (pz < bodyz ? pz % per_z : per_z + (pz - bodyz)) : pz % per_z;
-          if ((int)((zord >> (4 * cb)) & 15u) * ncol_y + ca < my_order) first = false; // zord: launch position of z colour cb
-        }
-      }
-      lbase[mm] = (uintptr_t)base | (first ? 1u : 0u);
-    }
-    // old[] = the current values of the next chunk's finished columns, requested a chunk ahead (the addresses depend on
-    // the chunk alone; these loads and the flush's stores are all this wave has in its memory counter)
-    double old[kWsOwn][kW];
-    auto request_old = [&](int jc) {
-#pragma unroll
-      for (int mm = 0; mm < kWsOwn; ++mm) {
-        const int line = t + mm * kWsFlush;
-#pragma unroll
-        for (int c = 0; c < kW; ++c) old[mm][c] = 0.0;
-        const uintptr_t lb = lbase[mm];
-        if (!lb || (lb & 1) || jc >= nch) continue;
-        const GlobalDouble* ptr = (const GlobalDouble*)(lb & ~(uintptr_t)1) + (long)jc * (line < kMatLines ? kLBlock : kW);
-#pragma unroll
-        for (int c = 0; c < kW; c += 2) {
-          const dpair v = *(const GlobalPair*)(ptr + c);
-          old[mm][c] = v.x; old[mm][c + 1] = v.y;
-        }
-      }
-    };
-    request_old(0);
-    WSTAMP_INIT;
-    for (int jc = 0; jc < nch; ++jc) {
-      if (!lds_wait(flags + kFlMerged, (unsigned)(2 * kW * (jc + 1)), flags)) { if (lane == 0) atomicOr(err, 1); return; }
-      WSTAMP(0);
-      // add the window's four finished columns, store, move the two unfinished columns to the front, clear the rest
-#pragma unroll
-      for (int mm = 0; mm < kWsOwn; ++mm) {
-        const int line = t + mm * kWsFlush;
-        const uintptr_t lb = lbase[mm];
-        if (!lb) continue;
-        double* wl = win + line * kWP;
-        double wv[kSlots];
-#pragma unroll
-        for (int c = 0; c < kSlots; ++c) wv[c] = wl[c];
-        GlobalDouble* ptr = (GlobalDouble*)(lb & ~(uintptr_t)1) + (long)jc * (line < kMatLines ? kLBlock : kW);
-#pragma unroll
-        for (int c = 0; c < kW; c += 2)
-          *(GlobalPair*)(ptr + c) = dpair{old[mm][c] + wv[c], old[mm][c + 1] + wv[c + 1]};
-        wl[0] = wv[kW]; wl[1] = wv[kW + 1];
-#pragma unroll
-        for (int c = 2; c < kSlots; ++c) wl[c] = 0.0;
-      }
-      lds_bump(flags + kFlSeeded, lane);
-      WSTAMP(1);
-      request_old(jc + 1);
-      WSTAMP(2);
-    }
-    // ---- the two columns left over are x = nx, nx + 1 = 0, 1 (periodic): columns this thread has already written,
-    // added with atomics (2 of nx columns)
-#pragma unroll
-    for (int mm = 0; mm < kWsOwn; ++mm) {
-      const int line = t + mm * kWsFlush;
-      if (line < kLines && lbase[mm]) {
-        double* base = (double*)(lbase[mm] & ~(uintptr_t)1);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const double v = win[line * kWP + c];
-          if (v != 0.0) unsafeAtomicAdd(base + g.wx(c), v);
-        }
-      }
-    }
-    WSTAMP(3);
-    WSTAMP_DUMP(24, w == 0);
-    return;
-  }
-
-  // ================================================= producer =======================================================
-  __builtin_amdgcn_s_setprio(FILL_WS_PRIO_P);
-  auto cell_x = [&](int i) { return (i + 1 == g.nx) ? 0 : i + 1; };
-  int box;
-  const double* const brow = bnb_row(g, B, lane, cy, cz, &box);
-  Prefetch pf;
-  auto prefetch_cell = [&](int i) {
-    pf.start = 0; pf.cnt = 0; pf.b = 0.0;
-    if (i >= g.nx) return;
-    const int cx = cell_x(i);
-    using UniformInts = const __attribute__((address_space(4))) int*;
-    UniformInts cs = (UniformInts)(s.cell_start + pencil0);
-    const int cxu = __builtin_amdgcn_readfirstlane(cx);
-    pf.start = cs[cxu];
-    pf.cnt = cs[cxu + 1] - pf.start;
-    pf.b = brow ? brow[g.wx(cx + box)] : 0.0;
-    if (lane < min(kWsCP, pf.cnt)) {
-      const long p = (long)pf.start + lane;
-#pragma unroll
-      for (int a = 0; a < 3; ++a) { pf.p[a] = s.r[a][p]; pf.p[3 + a] = s.v[a][p]; }
-    }
-  };
-  prefetch_cell(w);
-
-  const double fb = (0.5 * dt) * q / m;
-  const double qw = q * mpw;
-  const double Aq = 0.5 * dt * dt * mpw * q * q / m;
-  unsigned pass = 0;
-  WSTAMP_INIT;
-  for (int j = 0; j < nch; ++j) {
-    const int i = j * kW + w;
-    // the particles requested a cell ago are waited for HERE, before the next request goes out: left to the compiler the
-    // wait sits at their first use, behind the new request, and -- the memory counter being in order -- covers that too
-    // (a full HBM round trip at the head of every cell: 20 % of the producer's time)
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    const int start = pf.start, cnt = pf.cnt;
-    if (lane < 54) bnb[w][lane] = pf.b;
-    double cur[6];
-#pragma unroll
-    for (int a = 0; a < 6; ++a) cur[a] = pf.p[a];
-    asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5])); // copies made before the request below
-    prefetch_cell(i + kW); // the next cell's first particles travel during this cell's passes
-    int handed = min(kWsCP, cnt);
-    bool real = lane < handed;
-    WSTAMP(2);
-    for (;;) {
-      const bool lastpass = handed >= cnt;
-      const int b = pass & 1;
-      // both consumers have finished with the buffer's previous content (pass - 2)
-      if (pass >= 2) {
-        if (!lds_wait(flags + kFlFree + w * 2 + b, pass - 1, flags) ||
-            !lds_wait(flags + kFlFree + (kW + w) * 2 + b, pass - 1, flags)) { if (lane == 0) atomicOr(err, 1); return; }
-      }
-      WSTAMP(0);
-      double* st = stage + (w * 2 + b) * kWsStage;
-      wave_sync();
-      const W1T<P2> wt(g, cur[0], cur[1], cur[2]);
-      const int ox = wt.is[0] - wt.in[0] + 1, oy = wt.is[1] - wt.in[1] + 1, oz = wt.is[2] - wt.in[2] + 1;
-      const int oct = real ? (ox | (oy << 1) | (oz << 2)) : 8;
-      int ocnt[8], slot = 0;
-      bool keep = false;
-      {
-        int run = 0;
-#pragma unroll
-        for (int o = 0; o < 8; ++o) {
-          const unsigned long long mk = __ballot(oct == o);
-          ocnt[o] = __popcll(mk);
-          if (oct == o) {
-            const int rk = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-            slot = run + rk;
-            keep = !lastpass && rk >= (ocnt[o] & ~3);
-          }
-          run += ocnt[o];
-        }
-      }
-      // next pass of this cell: the free lanes take the next particles.  Requested NOW, as soon as the lanes that keep
-      // their particle are known, so that the loads travel under the rest of this pass (requested at the end of the pass
-      // they were a full HBM round trip at the head of the next one)
-      // (straight into the lanes' own registers: the position is dead behind the weights above, the velocity is copied first)
-      bool real_next = false;
-      double v[3] = {cur[3], cur[4], cur[5]};
-      asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
-      if (!lastpass) {
-        const unsigned long long km = __ballot(keep);
-        const int take = min(cnt - handed, kWsCP - (int)__popcll(km));
-        const unsigned long long fm = ~km;
-        const int fr = __builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
-        const bool get = !keep && fr < take;
-        if (get) {
-          const long p = (long)start + handed + fr;
-#pragma unroll
-          for (int a = 0; a < 3; ++a) { cur[a] = s.r[a][p]; cur[3 + a] = s.v[a][p]; }
-        }
-        real_next = keep || get;
-        handed += take;
-      }
-      if (real) {
-        double2* dst = (double2*)(st + slot * kPitch);
-        const double* nb = bnb[w];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int bb = 0; bb < 2; ++bb) {
-            const double tx = wt.wn[2][a] * wt.wn[1][bb];
-            dst[0 + a * 2 + bb] = double2{tx * wt.ws[0][0], tx * wt.ws[0][1]};
-            dst[4 + a * 2 + bb] = double2{wt.wn[2][a] * wt.ws[1][0] * wt.wn[0][bb], wt.wn[2][a] * wt.ws[1][1] * wt.wn[0][bb]};
-            dst[8 + a * 2 + bb] = double2{wt.ws[2][0] * wt.wn[1][a] * wt.wn[0][bb], wt.ws[2][1] * wt.wn[1][a] * wt.wn[0][bb]};
-          }
-        // interpolate_B_s1 out of the cell's LDS neighbourhood, component by component (8 values in flight at a time: the
-        // producer has 128 registers and time to spare; all 24 at once were spilled), same product and sum order per component
-        double Bp[3] = {0.0, 0.0, 0.0};
-        {
-          double nv[8];
-#pragma unroll
-          for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-              for (int ii = 0; ii < 2; ++ii) nv[(k * 2 + jj) * 2 + ii] = nb[((oz + k) * 3 + (oy + jj)) * 2 + ii];
-#pragma unroll
-          for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-              for (int ii = 0; ii < 2; ++ii) Bp[0] += nv[(k * 2 + jj) * 2 + ii] * (wt.ws[2][k] * wt.ws[1][jj] * wt.wn[0][ii]);
-          asm volatile("" ::: "memory");
-#pragma unroll
-          for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-              for (int ii = 0; ii < 2; ++ii) nv[(k * 2 + jj) * 2 + ii] = nb[18 + ((oz + k) * 2 + jj) * 3 + (ox + ii)];
-#pragma unroll
-          for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-              for (int ii = 0; ii < 2; ++ii) Bp[1] += nv[(k * 2 + jj) * 2 + ii] * (wt.ws[2][k] * wt.wn[1][jj] * wt.ws[0][ii]);
-          asm volatile("" ::: "memory");
-#pragma unroll
-          for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-              for (int ii = 0; ii < 2; ++ii) nv[(k * 2 + jj) * 2 + ii] = nb[36 + (k * 3 + (oy + jj)) * 3 + (ox + ii)];
-#pragma unroll
-          for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-              for (int ii = 0; ii < 2; ++ii) Bp[2] += nv[(k * 2 + jj) * 2 + ii] * (wt.wn[2][k] * wt.ws[1][jj] * wt.ws[0][ii]);
-        }
-        const double bx = Bp[0] * fb, by = Bp[1] * fb, bz = Bp[2] * fb;
-        const double b2 = bx * bx + by * by + bz * bz;
-        const double vb = v[0] * bx + v[1] * by + v[2] * bz;
-        const double cxv = +(v[1] * bz - v[2] * by), cyv = -(v[0] * bz - v[2] * bx), czv = +(v[0] * by - v[1] * bx);
-        const double rb = 1.0 / (1. + b2);
-        const double iq = qw * rb;
-        const double A_p = Aq * rb;
-        dst[12] = double2{A_p * (1.0 + bx * bx), A_p * (+bz + bx * by)};
-        dst[13] = double2{A_p * (-by + bx * bz), A_p * (-bz + by * bx)};
-        dst[14] = double2{A_p * (1.0 + by * by), A_p * (+bx + by * bz)};
-        dst[15] = double2{A_p * (+by + bz * bx), A_p * (-bx + bz * by)};
-        dst[16] = double2{A_p * (1.0 + bz * bz), iq * (v[0] + cxv + vb * bx)};
-        dst[17] = double2{iq * (v[1] + cyv + vb * by), iq * (v[2] + czv + vb * bz)};
-      }
-      WSTAMP(3);
-      if (lane == 0) {
-        *(int4*)&hdr[w][b][0] = int4{ocnt[0], ocnt[1], ocnt[2], ocnt[3]};
-        *(int4*)&hdr[w][b][4] = int4{ocnt[4], ocnt[5], ocnt[6], ocnt[7]};
-        hdr[w][b][8] = lastpass ? 1 : 0;
-      }
-      lds_post(flags + kFlFull + w * 2 + b, pass + 1, lane); // operands and header are in place
-      WSTAMP(4);
-      ++pass;
-      if (lastpass) break;
-      real = real_next;
-    }
-  }
-  WSTAMP_DUMP(16, w == 0);
-}
 
 }  // namespace
 
@@ -1643,19 +847,11 @@ int build_ltab(xpic_ctx* c)
       for (int c2 = 0; c2 < 3; ++c2) seen[acc_main(c1, c2, o)] = 1;
   }
   static_assert((kLines * kWP + 64) <= kW * kStage, "the dummy doubles must lie inside the stage area");
-  if (FILL_LEAN_LDS) { // [lane][kDtabPitch] instead of [e][64], and BYTE offsets (one add per atomic in the kernel)
+  { // [lane][kDtabPitch] instead of [e][64], and BYTE offsets (one add per atomic in the kernel)
     static_assert((kLines * kWP + 64 + kW) * 8 <= 0xffff, "window byte offsets must fit 16 bits");
     std::vector<unsigned short> t(64 * kDtabPitch, 0);
     for (int e = 0; e < kAcc; ++e)
       for (int lane = 0; lane < 64; ++lane) t[lane * kDtabPitch + e] = (unsigned short)(8 * dtab[e * 64 + lane]);
-    // the same offsets as 32-bit words, [lane][kAcc], behind the 16-bit table (FILL_DTAB32)
-    t.resize(64 * kDtabPitch + 2 * 64 * kAcc, 0);
-    for (int lane = 0; lane < 64; ++lane)
-      for (int e = 0; e < kAcc; ++e) {
-        const unsigned v = 8u * dtab[e * 64 + lane];
-        t[64 * kDtabPitch + 2 * (lane * kAcc + e)] = (unsigned short)(v & 0xffffu);
-        t[64 * kDtabPitch + 2 * (lane * kAcc + e) + 1] = (unsigned short)(v >> 16);
-      }
     dtab.swap(t);
   }
   const size_t total = linetab.size() + cowr.size() + (dtab.size() + 1) / 2;
@@ -1728,7 +924,11 @@ void ecsim_fill_variant(const xpic_ctx* c, int* p2, int* fx, int* ws)
 int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, double* matL, bool first_sort, bool post_ghost_rows)
 {
   if (s.deferred && s.n == 0) XPIC_CALL(sort_materialize(c, s));
-  if (s.n == 0) return 0;
+  if (s.n == 0) {
+    // nothing to assemble on this slab, but the exchange it was to post is part of every rank's message sequence
+    if (post_ghost_rows) XPIC_CALL(matL_ghost_rows_post(c));
+    return 0;
+  }
   const GridDev& g = c->g;
   int p2, fxi, wsi;
   ecsim_fill_variant(c, &p2, &fxi, &wsi);
@@ -1744,7 +944,6 @@ int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, d
   int per_y, per_z;
   colour_periods(g, (ws ? 1 : 2) * c->num_cus, &per_y, &per_z); // workgroup slots of the chip: the 8-wave kernel owns a CU
   const int ncol_y = per_y + g.ny % per_y, ncol_z = g.G == 0 ? per_z + g.nzl % per_z : per_z;
-  if (ws || ga) XPIC_HIP(hipMemsetAsync(c->fill_err, 0, sizeof(int), c->stream));
   // Launch sequence of the z colours.  On a slab the colours of the first and the last plane go first: their pencils are
   // the only ones that write the two ghost row planes of matL, which the neighbours are waiting for -- with
   // `post_ghost_rows` (the last species) the exchange is posted right behind them and travels beside the other colours.
@@ -1776,10 +975,8 @@ int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, d
       const bool fx = g.nx % kW == 0 && !alias;
       const unsigned short* dtab = (const unsigned short*)(c->ltab + kLines + kLines * 8);
       if (ws) {
-        auto kern = g.pow2 ? k_ecsim_fill_ws<true> : k_ecsim_fill_ws<false>;
-        hipLaunchKernelGGL(kern, dim3((unsigned)(ncy * ncz)), dim3(kWsThreads), 0, c->stream, g, s.d, B, currI_sort, matL, dtab,
-          c->ltab, c->ltab + kLines, s.par.q, s.par.m, s.par.n / (double)s.par.Np, cy0, cys, ncy, cz0, czs, pos * ncol_y + a, ncol_y,
-          per_y, per_z, first_sort ? 1 : 0, c->fill_err, zord);
+        launch_fill_ws(c, s, (unsigned)(ncy * ncz), B, currI_sort, matL, dtab, c->ltab, c->ltab + kLines, cy0, cys, ncy, cz0, czs,
+          pos * ncol_y + a, ncol_y, per_y, per_z, first_sort ? 1 : 0, zord);
         continue;
       }
       auto kern = ga ? (g.pow2 ? (fx ? k_ecsim_fill<true, true, true> : k_ecsim_fill<true, false, true>)
@@ -1789,25 +986,29 @@ int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, d
       hipLaunchKernelGGL(kern, dim3((unsigned)(ncy * ncz)), dim3(kThreads), 0, c->stream, g, s.d, B,
         currI_sort, matL, dtab, c->ltab, c->ltab + kLines, s.par.q, s.par.m,
         s.par.n / (double)s.par.Np, cy0, cys, ncy, cz0, czs, pos * ncol_y + a, ncol_y, per_y, per_z, first_sort && !alias ? 1 : 0,
-        alias ? 1 : 0, zord, s.def_step, c->fill_err, store_sorted ? 1 : 0, ga && s.def_bucket ? s.d.bucket_cap : 0);
+        alias ? 1 : 0, zord, s.def_step, c->fill_err, store_sorted ? 1 : 0, ga && s.def_bucket ? s.d.bucket_cap : 0, c->gather_window);
     }
   }
   if (post_ghost_rows && nseq <= nboundary) XPIC_CALL(matL_ghost_rows_post(c)); // (a slab whose every colour is a boundary colour)
-  if (store_sorted) {
-    sort_deferred_done(s); // every cell's records are in r2 / v2 now: they become the sort
-    int* herr = (int*)(c->red_host + 60);
-    XPIC_HIP(hipMemcpyAsync(herr, c->fill_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    XPIC_HIP(hipStreamSynchronize(c->stream));
-    XPIC_CHECK(*herr == 0, "an x-pencil holds more than 2^29 particles: run this configuration with xpic_set_fused_rebin(ctx, 0)");
-  }
+  if (store_sorted) sort_deferred_done(s); // every cell's records are in r2 / v2 now: they become the sort
   XPIC_HIP(hipGetLastError());
-  if (ws) {
-    // the pipeline's bounded waits: a wave that gave up has left the matrix incomplete -- fail the assembly loudly
-    int* herr = (int*)(c->red_host + 60);
-    XPIC_HIP(hipMemcpyAsync(herr, c->fill_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    XPIC_HIP(hipStreamSynchronize(c->stream));
-    XPIC_CHECK(*herr == 0, "k_ecsim_fill_ws: a producer / consumer wait timed out (assembly incomplete)");
-  }
+  // (what the kernels raised in c->fill_err is read by ecsim_fill_check, once per assembly and for all slabs together)
+  return 0;
+}
+
+// The assembly's error word (ecsim_fill.h: kFillErr*), read ONCE behind all species' launches.  A rank that returned early
+// while its neighbours sit in the next exchange would hang the job (the rule of sort_rebin's agree()): the kernels only
+// raise the flag and run on, every exchange of the assembly is issued regardless, and here all slabs learn the OR of all
+// flags through one small all-reduce and leave with the same return code.
+int ecsim_fill_check(xpic_ctx* c)
+{
+  int* herr = (int*)(c->red_host + 60);
+  XPIC_HIP(hipMemcpyAsync(herr, c->fill_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  XPIC_HIP(hipStreamSynchronize(c->stream));
+  double e[2] = {(*herr & kFillErrPencil) ? 1.0 : 0.0, (*herr & kFillErrTimeout) ? 1.0 : 0.0};
+  if (c->comm.kind != 0) XPIC_CALL(comm_allreduce_sum_host(c, e, 2));
+  XPIC_CHECK(e[0] == 0.0, "an x-pencil holds 2^29 particles or more in the gathering assembly (sort_rebin should have scattered first)");
+  XPIC_CHECK(e[1] == 0.0, "k_ecsim_fill_ws: a producer / consumer wait timed out (assembly incomplete)");
   return 0;
 }
 

@@ -4,12 +4,12 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include "common.h"
+#include "device_common.h"
+
 #ifndef XPIC_BUCKET_CAP
 #define XPIC_BUCKET_CAP 128 // source indices a cell's bucket holds (deferred scatter); a fuller cell sends the step through k_index
 #endif
-
-#include "common.h"
-#include "device_common.h"
 
 namespace xpic {
 
@@ -197,6 +197,16 @@ __global__ void __launch_bounds__(kBlock) k_index(SortDev s, int64_t n)
   const int c = s.cell[p];
   if (c < 0) return;
   s.src[(int64_t)s.cell_start[c] + s.rank[p]] = (int)p;
+}
+
+// largest population of an x-pencil (the gathering assembly addresses the sorted copy by 32-bit byte offsets from the pencil's
+// first slot: ecsim.hip); only launched for sorts of 2^29 particles or more
+__global__ void __launch_bounds__(kBlock) k_max_pencil(const int* __restrict__ cell_start, int nx, long npencils, int limit, int* out)
+{
+  const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= npencils) return;
+  const int pop = cell_start[(i + 1) * nx] - cell_start[i * nx];
+  if (pop >= limit) atomicMax(out, pop);
 }
 
 // ... and the records that arrived from the neighbouring slabs stay in the receive buffer: slot <- -1 - (record number)
@@ -956,16 +966,34 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap, int defer)
   // source, and the mass-matrix assembly -- which reads every particle anyway -- moves, wraps and writes it (ecsim.hip).
   // On z-slabs too (the assembly only: defer == 1): what the neighbours sent stays in the receive buffer and gets the source
   // indices -1 - i; no buckets there.
+  // What the deferral's decisions need from the device, fetched with ONE synchronisation: the bucket-overflow flag of the
+  // binning, and -- for sorts of 2^29 particles or more only -- whether an x-pencil holds 2^29 or more: that is beyond the
+  // 32-bit offsets of the gathering assembly, and such a sort is scattered here, by this rank alone (nothing collective
+  // depends on who moves the records).
+  int* hflag = (int*)(c->red_host + 61);
+  int* hmax = (int*)(c->red_host + 62);
+  *hflag = 0; *hmax = 0;
+  if (defer && (s.n > 0 || n_in > 0) && s.d.src) {
+    bool sync = false;
+    if (defer == 1 && total >= c->pencil_limit) {
+      int* dmax = (int*)(c->red_out + 120);
+      XPIC_HIP(hipMemsetAsync(dmax, 0, sizeof(int), c->stream));
+      const long npen = c->ncell / c->g.nx;
+      hipLaunchKernelGGL(k_max_pencil, dim3(pgrid(npen)), dim3(kBlock), 0, c->stream, s.d.cell_start, c->g.nx, npen, c->pencil_limit, dmax);
+      XPIC_HIP(hipMemcpyAsync(hmax, dmax, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      sync = true;
+    }
+    if (s.d.bucket_cap > 0) {
+      XPIC_HIP(hipMemcpyAsync(hflag, s.d.bucket + c->ncell * s.d.bucket_cap, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      sync = true;
+    }
+    if (sync) XPIC_HIP(hipStreamSynchronize(c->stream));
+    if (*hmax != 0) { defer = 0; s.bucket_off = true; } // (and this sort's pre-binnings write the keys from now on)
+  }
   if (defer && (!mig || defer == 1) && (s.n > 0 || n_in > 0) && s.d.src) {
     // the binning filled the cells' buckets (bin_particle) unless a cell overflowed its bucket: then the index is built
     // from the keys (k_index: 12 B per particle)
-    bool use_bucket = false;
-    if (s.d.bucket_cap > 0) {
-      int* hflag = (int*)(c->red_host + 61);
-      XPIC_HIP(hipMemcpyAsync(hflag, s.d.bucket + c->ncell * s.d.bucket_cap, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      XPIC_HIP(hipStreamSynchronize(c->stream));
-      use_bucket = defer == 1 && *hflag == 0 && s.bucket_written && c->fused_rebin == 1; // (mode 2's second push reads the index k_index builds)
-    }
+    const bool use_bucket = s.d.bucket_cap > 0 && defer == 1 && *hflag == 0 && s.bucket_written && c->fused_rebin == 1; // (mode 2's second push reads the index k_index builds)
     if (!use_bucket && !s.keys_valid) {
       // (a cell took more arrivals than a bucket holds: this sort's pre-binnings write the keys from now on)
       s.bucket_off = true;
