@@ -41,9 +41,14 @@ def parse_args(argv=None):
     ap.add_argument("--dt", type=float, default=None, help="default 1.0 (ecsim, ecsimcorr), 0.1 (basic: explicit, CFL)")
     ap.add_argument("--vth", type=float, default=0.014)  # T = 0.1 keV electrons (tests/ecsim/ecsim_ex1.cpp:66-70)
     ap.add_argument("--b0", type=float, default=0.2)
-    ap.add_argument("--loader", default="poisson", choices=["poisson", "regular"],
+    ap.add_argument("--loader", default="poisson", choices=["poisson", "regular", "gradient", "blob"],
                     help="poisson: positions uniform over the box like CoordinateInBox (Poisson occupancy of the cells); "
-                         "regular: exactly ppc particles in every cell")
+                         "regular: exactly ppc particles in every cell; gradient: density falling 4 : 1 along x; blob: 1 %% of "
+                         "the particles in a Gaussian clump of sigma = 4 cells at the centre (cells of several hundred particles); "
+                         "the same particle total for all of them")
+    ap.add_argument("--drift", type=float, default=None,
+                    help="basic: beam momentum +-drift (m c) of the two electron species along x (default 0.2: the two-stream "
+                         "set-up of BASELINE configs[1]; 0: two thermal species)")
     ap.add_argument("--cpu-grid", type=int, default=64)   # 64^3 x ppc, as SURVEY 8(d) asks: ~20 s of oracle work
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -69,6 +74,8 @@ def parse_args(argv=None):
         args.ppc = 32 if side else 64
     if args.dt is None:
         args.dt = 0.1 if args.scheme == "basic" else 1.0
+    if args.drift is None:
+        args.drift = 0.2 if args.scheme == "basic" else 0.0
     args.n3 = tuple(args.grid_xyz) if args.grid_xyz else (args.grid,) * 3
     return args
 
@@ -211,12 +218,13 @@ def cpu_baseline(args):
     o = oracle_lib.OracleSim(args.scheme, (n, n, n), (args.dx,) * 3, args.dt)
     rng = np.random.default_rng(1)
     npart = 0
-    for (Np, dens, q, m) in species(args):
+    for i, (Np, dens, q, m) in enumerate(species(args)):
         s = o.add_sort(Np, dens, q, m)
         k = Np * n ** 3
         pts = np.empty((k, 6))
         pts[:, :3] = rng.random((k, 3)) * (n * args.dx)
         v = rng.normal(0, args.vth, (k, 3))
+        v[:, 0] += beam_drift(args, i)
         pts[:, 3:] = v / np.sqrt(1.0 + (v * v).sum(1, keepdims=True))
         o.add_particles(s, pts)
         npart += k
@@ -235,6 +243,7 @@ def cpu_baseline(args):
     ksp_s, its = o.solve_stats()
     solver = "GMRES(30), no preconditioner" if args.scheme != "basic" else "none (explicit scheme)"
     return {
+        "ms_per_solve_at_sample_grid": (ksp_s / nsteps * 1e3 / (2 if args.scheme == "ecsimcorr" else 1)) if its else None,
         "value": npart * nsteps / dt,
         "unit": "particles/s",
         "cores": threads,  # OpenMP threads actually used = the CPUs this process has (affinity mask and cgroup quota)
@@ -253,9 +262,18 @@ def cpu_baseline(args):
     }
 
 
+def beam_drift(args, k):
+    """momentum (m c, along x) of species k: +-drift for the two beams of the basic scheme's two-stream set-up"""
+    return (args.drift if k % 2 == 0 else -args.drift) if args.scheme == "basic" and args.ppc % 2 == 0 else 0.0
+
+
+LOADER_PARAM = {"gradient": (4.0,), "blob": (0.01, 4.0)}
+
+
 def species(args):
     """(Np, n, q, m) of the species the workload loads.  basic = BASELINE configs[1], the two-stream set-up: two electron
-    species of ppc / 2 each (SURVEY 8d Config 2; the reference's config surface has no drift, so both are thermal)."""
+    species of ppc / 2 each (SURVEY 8d Config 2), counter-streaming with momentum +-drift along x -- the reference's config
+    surface has no drift (simulation.tpp:24-41 never reads px): an extension of this build's loaders, see beam_drift."""
     if args.scheme == "basic" and args.ppc % 2 == 0:
         return [(args.ppc // 2, 0.5, -1.0, 1.0), (args.ppc // 2, 0.5, -1.0, 1.0)]
     return [(args.ppc, 1.0, -1.0, 1.0)]
@@ -443,8 +461,10 @@ def rank_body(args, rank, world, local_rank, job):
     sorts = []
     for k, (Np, dens, q, m) in enumerate(species(args)):
         s = ctx.add_sort(Np, dens, q, m, capacity=int(Np * N * 1.02) + 1024)
-        ctx.fill_synthetic(s, Np, args.vth, seed=1234 + rank + 7919 * k, regular=args.loader == "regular")
+        ctx.load_synthetic(s, Np, args.vth, seed=1234 + rank + 7919 * k, profile=args.loader,
+                           drift=(beam_drift(args, k), 0.0, 0.0), param=LOADER_PARAM.get(args.loader, (0.0, 0.0)))
         sorts.append(s)
+    occupancy = ctx.occupancy(sorts[0])
 
     # SetMagneticField(SetUniformField): B = B0 = (0, 0, b0)
     B = np.zeros(ctx.fshape())
@@ -508,7 +528,8 @@ def rank_body(args, rank, world, local_rank, job):
                                             "second_push", "mdot", "maxpy", "matL_zero", "scan", "index", "rot_apply",
                                             "halo", "migrate", "matL_ghost_rows", "basic_push", "corr_first_push", "precond_setup",
                                             "corr_second_push", "solve_matM", "precond", "matL_apply", "rebin",
-                                            "allreduce")}
+                                            "allreduce", "cheb_steps", "rebuild_keys", "fill_gather", "precond_fallback")}
+    COUNTERS = ("allreduce", "cheb_steps", "rebuild_keys", "fill_gather", "precond_fallback")
     count_local = sum(ctx.count(s) for s in sorts)
     count = int(job.reduce(count_local, "sum"))
     assert count == world * npart, "particles were lost in a periodic box"
@@ -520,7 +541,8 @@ def rank_body(args, rank, world, local_rank, job):
         "ecsim": f"3D ECSIM electromagnetic, {gname} cells, {args.ppc} ppc, 1 electron species, GMRES(30) on matL+matM "
                  f"rtol=atol=1e-7 (BASELINE.json configs[2])",
         "basic": f"3D explicit (basic) scheme, {gname} cells, {len(sorts)} electron species x {args.ppc // len(sorts)} ppc "
-                 f"(two-stream set-up), Boris push + Esirkepov deposit + FDTD, and CG on matM as the SPD solve "
+                 f"({'two-stream set-up: beams of momentum +-%g m c along x' % args.drift if args.drift else 'both thermal'}), "
+                 f"Boris push + Esirkepov deposit + FDTD, and CG on matM as the SPD solve "
                  f"(BASELINE.json configs[1]; side measurement)",
         "ecsimcorr": f"3D ecsimcorr charge-conserving scheme, {gname} cells, {args.ppc} ppc, two Esirkepov deposits + two "
                      f"solves per step (one GPU's share of BASELINE.json configs[4]; side measurement)",
@@ -542,8 +564,11 @@ def rank_body(args, rank, world, local_rank, job):
         "config": {
             "workload": workload,
             "grid": list(n3), "ppc": args.ppc, "species": len(sorts), "particles_per_gpu": npart, "dx": args.dx, "dt": args.dt,
-            "loader": "uniform over the box (Poisson cell occupancy, as CoordinateInBox)" if args.loader == "poisson"
-                      else "exactly ppc particles in every cell",
+            "loader": {"poisson": "uniform over the box (Poisson cell occupancy, as CoordinateInBox)",
+                       "regular": "exactly ppc particles in every cell",
+                       "gradient": "density falling linearly 4 : 1 along x (same particle total)",
+                       "blob": "1 % of the particles in a Gaussian clump of sigma = 4 cells at the centre of the box, the rest "
+                               "uniform (same particle total)"}[args.loader],
             "parallelism": "1 GPU" if world == 1 else
                            f"{world} z-slabs of {n3[2] // world} planes, RCCL halo / migration / dot all-reduce over xGMI"
                            + job.note,
@@ -558,7 +583,23 @@ def rank_body(args, rank, world, local_rank, job):
              if args.precond in (None, 3) else "matM (fp32 work vectors)" if args.precond == 1 else "matM (fp64)") +
             "; outer iterations, each = 1 matA apply + the polynomial's stencil applies"),
         "ksp_iterations_per_step": its_total / world / args.steps,
-        "phase_ms_per_step": {k: v[1] / args.steps for k, v in prof.items() if k != "allreduce"},
+        # "KSP iterations" of two methods are not one unit (an outer iteration here carries the polynomial's stencil steps, the
+        # CPU baseline's are plain GMRES iterations): the comparable figures are the time per converged solve and what it holds
+        "solve_ms_per_step": ms_solve / args.steps,
+        "solves_per_step": (prof["solve_matA"][0] + prof["solve_matM"][0]) / args.steps,
+        "ms_per_solve": ms_solve / max(1, prof["solve_matA"][0] + prof["solve_matM"][0]),
+        "matA_applies_per_step": prof["matA_apply"][0] / args.steps,
+        "stencil_steps_per_iteration": (prof["cheb_steps"][0] / (its_total / world)) if its_total else 0,
+        "phase_ms_per_step": {k: v[1] / args.steps for k, v in prof.items() if k not in COUNTERS},
+        # how the particle kernels met this load (xpic_sort_occupancy of the first species before the timed steps; the
+        # fall-backs counted inside them): a cell above 64 / 128 particles costs the assembly a second / third staging pass, a
+        # cell above the bucket capacity sends the step through the index pass, the largest x-pencil sets the duration of its
+        # colour launch
+        "occupancy": dict(occupancy, mean_pencil=npart / len(sorts) / (n3[1] * (n3[2] // world)),
+                          index_passes_per_step=prof["index"][0] / args.steps,
+                          key_rebuilds_per_step=prof["rebuild_keys"][0] / args.steps,
+                          gathering_assemblies_per_step=prof["fill_gather"][0] / args.steps,
+                          precond_fallbacks_per_step=prof["precond_fallback"][0] / args.steps),
         "allreduces_per_step": prof["allreduce"][0] / args.steps,  # reductions that are all-reduces on slabs (counted on 1 GPU too)
         "device_copy_GBps": copy_rate / 1e9 if copy_rate else None,
         # what ONE rank puts on its links per step (rank 0; every slab sends the same): point-to-point messages to the two
@@ -582,19 +623,28 @@ def rank_body(args, rank, world, local_rank, job):
         tf = flop_launch / (avg_ms * 1e-3) / 1e12
         # (with the re-binning's scatter deferred into it -- ctx fused_rebin, ecsim on one slab -- the launch also reads
         # the 4-byte source index and writes the 48-byte sorted record of every particle)
-        fused = world == 1 and args.fused_rebin != 0 and not ctx.fill_variant()[2] and (args.scheme == "ecsim" or args.fused_rebin != 2)
+        # (whether it did: the library counts its gathering assemblies -- on z-slabs too since round 4; mode 2 leaves the stores
+        # to the second push)
+        fused = prof["fill_gather"][0] > 0 and args.fused_rebin != 2
         bytes_launch = ((100.0 if fused else 48.0) + 2952.0 / args.ppc) * count_local / launches_per_step
+        gbs_fill = bytes_launch / (avg_ms * 1e-3) / 1e9
+        # the binding roof by the ridge test: flop per algorithmic byte against peak flop / peak bytes (78.6 T / 8 T = 9.8)
+        intensity, ridge = flop_launch / bytes_launch, FP64_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)
+        hbm_bound = intensity < ridge
         fill = {
             "kernel": ("k_ecsim_fill_ws" if ctx.fill_variant()[2] else "k_ecsim_fill") + " (mass matrix + currI" +
                       (" + the re-binning's gather, move and sorted copy" if fused else "") + "; one colour launch)",
-            "bound": "mfma",
-            "achieved": tf, "peak": FP64_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TF,
+            "bound": "hbm" if hbm_bound else "mfma",
+            "achieved": gbs_fill if hbm_bound else tf, "peak": HBM_PEAK_GBS if hbm_bound else FP64_PEAK_TF,
+            "unit": "GB/s" if hbm_bound else "TFLOP/s",
+            "frac": gbs_fill / HBM_PEAK_GBS if hbm_bound else tf / FP64_PEAK_TF,
+            "frac_fp64": tf / FP64_PEAK_TF, "frac_hbm": gbs_fill / HBM_PEAK_GBS,
+            "flop_per_byte": intensity, "ridge_flop_per_byte": ridge, "achieved_TFLOPs": tf, "achieved_GBps": gbs_fill,
             "traffic": pmc_traffic(args.scheme, n3, "k_ecsim_fill_ws" if ctx.fill_variant()[2] else "k_ecsim_fill<") if world == 1 else None,
             "flop_per_particle": FILL_FLOP_PER_PARTICLE, "flop_per_launch": flop_launch,
             "launches": n_fill, "launches_per_step": launches_per_step, "avg_ms": avg_ms,
             "ms_per_assembly": ms_fill / args.steps,
-            "hbm_view": {"bytes_per_launch": bytes_launch, "achieved_GBps": bytes_launch / (avg_ms * 1e-3) / 1e9,
-                         "frac_of_8TBps": bytes_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "bytes_per_launch": bytes_launch,
         }
     n_apply, ms_apply = prof["matA_apply"]
     spmv = None

@@ -96,6 +96,32 @@ int xpic_sort_clear(xpic_ctx* ctx, int sort);
  * src/commands/set_particles.cpp:19-43; the device RNG is its own, not mt19937); regular != 0: exactly ppc particles
  * in every cell.  Collective over the z-slabs like xpic_update_cells. */
 int xpic_sort_fill_synthetic(xpic_ctx* ctx, int sort, int ppc, double vth, uint64_t seed, int regular);
+/* The same with a drift and a density profile.  drift = SortParameters::px, py, pz as MaxwellianMomentum adds them
+ * (src/utils/particles_load.cpp:57-76: to the thermal momentum, before `tov`; in units of m c with m = 1).  The
+ * reference's JSON surface never reads px / py / pz (src/interfaces/simulation.tpp:24-41), so a drifting Maxwellian -- the
+ * two counter-streaming beams of BASELINE configs[1] -- is an EXTENSION of this build's loaders, not reference behaviour.
+ * profile: XPIC_LOAD_UNIFORM / XPIC_LOAD_REGULAR as above; XPIC_LOAD_GRADIENT: density falling linearly along x from
+ * profile_param[0] : 1 at x = 0 to 1 at x = Lx (same particle total); XPIC_LOAD_BLOB: the fraction profile_param[0] of
+ * the particles in a Gaussian clump of sigma = profile_param[1] cells at the centre of the slab, the rest uniform (cells
+ * of many times the mean occupancy: the bucket / third-pass / colour-balance fall-backs of the particle kernels). */
+#define XPIC_LOAD_UNIFORM 0
+#define XPIC_LOAD_REGULAR 1
+#define XPIC_LOAD_GRADIENT 2
+#define XPIC_LOAD_BLOB 3
+typedef struct xpic_load_params {
+  int32_t ppc;
+  int32_t profile;
+  double vth;
+  double drift[3];
+  double profile_param[4];
+  uint64_t seed;
+} xpic_load_params;
+int xpic_sort_load_synthetic(xpic_ctx* ctx, int sort, const xpic_load_params* params);
+/* Occupancy of the local cells (`storage[g].size()`, src/interfaces/particles.h:32, any distribution): out8 = {largest
+ * cell, cells of more than 64 particles (a second staging pass in the assembly), of more than 128 (a third), of more than
+ * a bucket of the deferred scatter holds (the step then takes the index pass), largest and smallest population of an
+ * x-pencil (one workgroup each in the particle kernels: the balance of a colour launch), empty cells, bucket capacity}. */
+int xpic_sort_occupancy(xpic_ctx* ctx, int sort, int64_t* out8);
 
 /* Vec access (DMDAVecGetArray / VecGetArray): copies in/out in the [z][y][x][3] layout, local slab */
 int xpic_field_set(xpic_ctx* ctx, int field, const double* v);

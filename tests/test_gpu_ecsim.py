@@ -599,3 +599,52 @@ def test_headline_size_properties():
     for k in (0, 1, 4):
         assert abs(eh[k] - e1[k]) <= 1e-9 * abs(e1[k]), (k, eh[k], e1[k])
     h.close()
+
+
+@pytest.mark.parametrize("profile,param", [("gradient", (4.0,)), ("blob", (0.02, 3.0))])
+def test_nonuniform_plasma_properties(profile, param):
+    """The packed layout holds any occupancy (`storage[g].size()`, src/interfaces/particles.h:32); the fast paths of the
+    particle kernels were tuned on a uniform plasma.  128^3 x 64 ppc with the density falling 4 : 1 along x, and with 2 % of
+    the particles in a Gaussian clump of sigma = 3 cells (cells of ~ 1000 particles: beyond the deferred scatter's buckets of
+    128, the assembly's third staging pass, a colour launch with one pencil several times the mean).  Size-independent
+    properties: the deferred scatter equals the scatter-first step (counts exactly, energies 1e-9), every particle survives,
+    energy is conserved to the accuracy of the solve, the default preconditioner (kind 3) converges -- with its Gershgorin
+    fall-back counter read, whatever it says -- and the bucket overflow of the clump takes the index pass."""
+    import xpic_amd as X
+
+    n, ppc = (128, 128, 128), 64
+    N = n[0] * n[1] * n[2]
+    res = []
+    for fused in (1, 0):
+        g = X.Context("ecsim", n, (0.5, 0.5, 0.5), 1.0)
+        s = g.add_sort(ppc, 1.0, -1.0, 1.0, capacity=int(ppc * N * 1.02))
+        g.load_synthetic(s, ppc, 0.014, seed=21, profile=profile, param=param)
+        B = np.zeros(g.fshape()) + np.array([0.0, 0.0, 0.2])
+        g.set_field(X.B, B)
+        g.set_field(X.B0, B)
+        del B
+        g.set_fused_rebin(fused)
+        occ = g.occupancy(s)
+        e0 = g.energy()
+        g.profile_enable(True)
+        its = [g.step() for _ in range(3)]
+        assert all(0 < i <= 100 for i in its), its
+        e1 = g.energy()
+        assert g.count(s) == ppc * N
+        tot0, tot1 = e0[0] + e0[1] + e0[4], e1[0] + e1[1] + e1[4]
+        assert abs(tot1 - tot0) <= 1e-7 * tot0
+        res.append((its, e1, occ, g.profile_get("index")[0], g.profile_get("scatter")[0], g.profile_get("precond_fallback")[0]))
+        g.close()
+    (its1, e1, occ, idx1, sc1, fb1), (its0, e0, _, idx0, sc0, fb0) = res
+    assert its1 == its0
+    for k in (0, 1, 4):
+        assert abs(e1[k] - e0[k]) <= 1e-9 * abs(e0[k]), (k, e1[k], e0[k])
+    assert sc0 == 3 and idx0 == 0 and sc1 == 0  # scatter first: three scatters; deferred: none
+    if profile == "gradient":
+        assert 64 * 4 / 2.5 * 0.9 < occ["max_cell"] < 64 * 4 / 2.5 * 1.6 and occ["cells_over_128"] > 0
+        assert 1.5 < occ["max_pencil"] / (ppc * n[0]) * 1.0 < 1.1 * 1.0 or occ["max_pencil"] > ppc * n[0] * 0.9  # pencils run along x: balanced
+    else:
+        assert occ["max_cell"] > 500 and occ["cells_over_bucket"] > 0
+        assert idx1 >= 1  # a cell beyond its bucket: the step's index pass
+        assert occ["max_pencil"] > 1.3 * ppc * n[0]
+    print(profile, "occupancy", occ, "iterations", its1, "index passes", idx1, "precond fall-backs", fb1, fb0)

@@ -283,6 +283,77 @@ def test_momentum_conservation_sums_on_device(oracle, scheme):
             g.step()
 
 
+def test_two_stream_growth_rate(oracle):
+    """BASELINE configs[1] is a two-stream set-up; its one physics result is the growth rate of the cold two-stream
+    instability: two equal counter-streaming beams, gamma_max = w_pe / (2 sqrt 2) with w_pe of the total density
+    (tests/two_stream.py: dispersion relation, the quiet start, the seeded mode and the fitted window -- field energy between
+    1e-6 and 1e-2 of its saturation value).  The HIP `basic` step must (a) reproduce the theoretical rate within 10 % and
+    (b) track the oracle's field energy through the linear phase on identical inputs.  Parity unpinned: the reference
+    holds no two-stream fixture (its JSON surface has no drift)."""
+    import two_stream as TS
+    import xpic_amd as X
+
+    bm, n, d, k = TS.beams()
+    o = oracle.OracleSim("basic", n, d, TS.DT)
+    g = X.Context("basic", n, d, TS.DT)
+    for pts in bm:
+        so = o.add_sort(TS.PPC_BEAM, 0.5, -1.0, 1.0)
+        sg = g.add_sort(TS.PPC_BEAM, 0.5, -1.0, 1.0, capacity=2 * pts.shape[0])
+        assert o.add_particles(so, pts) == g.add_particles(sg, pts) == pts.shape[0]
+    t, wg, wo = [], [], []
+    for it in range(700):
+        g.step()
+        t.append((it + 1) * TS.DT)
+        wg.append(g.energy()[0])
+        if it < 400:  # the linear phase (the oracle needs ~ 45 ms per step)
+            assert o.step() == 0
+            wo.append(o.energy()[0])
+    wg, wo = np.array(wg), np.array(wo)
+    rate, npts = TS.fit_growth(t, wg, 1e-6, 1e-2)
+    theory = TS.gamma_theory(k)
+    assert wg.max() > 1e8 * wg[0] and npts >= 100
+    assert abs(rate - theory) <= 0.10 * theory, (rate, theory)
+    # identical inputs, a smooth exponentially growing mode: the two codes differ by round-off times the growth
+    assert np.abs(wg[:400] / wo - 1.0).max() <= 1e-6, np.abs(wg[:400] / wo - 1.0).max()
+    assert g.count(0) == bm[0].shape[0] and g.count(1) == bm[1].shape[0]
+
+
+def test_synthetic_loader_drift_and_profiles():
+    """xpic_sort_load_synthetic: the drift is MaxwellianMomentum's px (added to the thermal momentum before `tov`,
+    src/utils/particles_load.cpp:57-76 -- an extension of the reference's JSON surface, which never reads it); the
+    gradient profile puts ratio : 1 as many particles at x = 0 as at x = Lx; the blob profile a Gaussian clump of the
+    asked fraction and width at the centre of the box.  Same particle total for every profile."""
+    import xpic_amd as X
+
+    n, d = (32, 8, 8), (0.5, 0.5, 0.5)
+    ncell = n[0] * n[1] * n[2]
+    g = X.Context("basic", n, d, 0.1)
+    s = g.add_sort(64, 1.0, -1.0, 1.0, capacity=80 * ncell)
+    p0 = np.array([0.3, -0.1, 0.05])
+    g.load_synthetic(s, 64, 0.01, seed=5, profile="poisson", drift=p0)
+    pts, cells = g.particles(s)
+    assert pts.shape[0] == 64 * ncell
+    gam = np.sqrt(1.0 + (p0 * p0).sum())
+    assert np.abs(pts[:, 3:].mean(0) - p0 / gam).max() < 2e-4  # v = p / sqrt(1 + p^2), thermal spread 0.01 / sqrt(N)
+    assert 0.008 < pts[:, 3].std() < 0.012
+    g.load_synthetic(s, 64, 0.01, seed=6, profile="gradient", param=(4.0,))
+    pts, cells = g.particles(s)
+    assert pts.shape[0] == 64 * ncell
+    col = np.bincount((cells % n[0]).astype(np.int64), minlength=n[0]).astype(float)  # particles per x-column of cells
+    lin = 4.0 - 3.0 * (np.arange(n[0]) + 0.5) / n[0]
+    assert np.abs(col / col.sum() - lin / lin.sum()).max() < 0.01 * (lin / lin.sum()).max()
+    g.load_synthetic(s, 64, 0.01, seed=7, profile="blob", param=(0.25, 1.5))
+    pts, cells = g.particles(s)
+    assert pts.shape[0] == 64 * ncell
+    occ = np.bincount(cells.astype(np.int64), minlength=ncell)
+    centre = ((n[2] // 2) * n[1] + n[1] // 2) * n[0] + n[0] // 2
+    peak = 0.25 * 64 * ncell / ((2 * np.pi) ** 1.5 * 1.5 ** 3)  # clump density at its centre, per cell
+    assert occ.max() > 4 * 64 and abs(occ[centre] - (peak * 0.92 + 48)) < 0.25 * peak  # (0.92: the cell average of the Gaussian's top)
+    r = (pts[:, :3] / np.array(d) - np.array(n) / 2.0)
+    inside = (np.abs(r) < 4.5).all(1).mean()  # within 3 sigma of the centre: the clump + its share of the uniform rest
+    assert abs(inside - (0.25 * 0.99 + 0.75 * 9.0 ** 3 / ncell)) < 0.01
+
+
 def test_config1_size_properties_basic():
     """BASELINE configs[1] at full size on its own scheme: `basic`, 128^3 cells, two electron species of 16 ppc (the
     two-stream set-up: 67 M particles), dt = 0.1.  Size-independent properties only: no particle is lost by the periodic

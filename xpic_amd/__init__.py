@@ -22,7 +22,7 @@ SCHEMES = {"basic": BASIC, "ecsim": ECSIM, "ecsimcorr": ECSIMCORR}
 SYMBOLS = [
     "xpic_last_error", "xpic_version", "xpic_create", "xpic_destroy", "xpic_synchronize", "xpic_add_sort",
     "xpic_sort_add_particles", "xpic_sort_count", "xpic_sort_get_particles", "xpic_sort_clear",
-    "xpic_sort_fill_synthetic", "xpic_field_set", "xpic_field_get", "xpic_sort_current_get", "xpic_vec_set",
+    "xpic_sort_fill_synthetic", "xpic_sort_load_synthetic", "xpic_sort_occupancy", "xpic_field_set", "xpic_field_get", "xpic_sort_current_get", "xpic_vec_set",
     "xpic_vec_axpy", "xpic_vec_axpby", "xpic_vec_dot", "xpic_vec_norm2", "xpic_rot_apply", "xpic_matM_apply",
     "xpic_matL_apply", "xpic_matA_apply", "xpic_matL_get", "xpic_lstencil_decode", "xpic_ecsim_first_push",
     "xpic_update_cells", "xpic_ecsim_fill_current", "xpic_ecsim_second_push", "xpic_basic_push",
@@ -59,6 +59,14 @@ class Geometry(C.Structure):
 
 DEBUG_GATHER_WINDOW, DEBUG_PENCIL_LIMIT = 0, 1  # include/xpic_hip.h: xpic_debug_set
 VERSION_EXPERIMENT_BIT = 0x40000000  # include/xpic_hip.h: XPIC_VERSION_EXPERIMENT_BIT
+
+
+class LoadParams(C.Structure):
+    _fields_ = [("ppc", C.c_int32), ("profile", C.c_int32), ("vth", C.c_double), ("drift", C.c_double * 3),
+                ("profile_param", C.c_double * 4), ("seed", C.c_uint64)]
+
+
+LOAD_PROFILES = {"poisson": 0, "uniform": 0, "regular": 1, "gradient": 2, "blob": 3}  # include/xpic_hip.h: XPIC_LOAD_*
 
 
 class SortParams(C.Structure):
@@ -206,6 +214,23 @@ class Context:
 
     def fill_synthetic(self, sort, ppc, vth, seed=1, regular=False):
         self._ck(self.L.xpic_sort_fill_synthetic(self.h, sort, int(ppc), C.c_double(vth), C.c_uint64(seed), int(regular)))
+
+    def load_synthetic(self, sort, ppc, vth, seed=1, profile="poisson", drift=(0.0, 0.0, 0.0), param=(0.0, 0.0)):
+        """fill_synthetic with a drift (MaxwellianMomentum's px, py, pz: an extension of the reference's JSON surface) and
+        a density profile: "gradient" (param[0] : 1 along x) or "blob" (fraction param[0] in a Gaussian of param[1] cells)"""
+        lp = LoadParams()
+        lp.ppc, lp.profile, lp.vth, lp.seed = int(ppc), LOAD_PROFILES[profile], float(vth), int(seed)
+        lp.drift[:] = [float(v) for v in drift]
+        lp.profile_param[:] = [float(v) for v in param] + [0.0] * (4 - len(param))
+        self._ck(self.L.xpic_sort_load_synthetic(self.h, sort, C.byref(lp)))
+
+    def occupancy(self, sort):
+        """dict of the cell / pencil occupancy statistics of a sort (include/xpic_hip.h: xpic_sort_occupancy)"""
+        o = (C.c_int64 * 8)()
+        self._ck(self.L.xpic_sort_occupancy(self.h, sort, o))
+        keys = ("max_cell", "cells_over_64", "cells_over_128", "cells_over_bucket", "max_pencil", "min_pencil", "empty_cells",
+                "bucket_cap")
+        return dict(zip(keys, (int(v) for v in o)))
 
     # ---- fields
     def fshape(self):

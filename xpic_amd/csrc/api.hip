@@ -477,7 +477,24 @@ int xpic_sort_fill_synthetic(xpic_ctx* ctx, int sort, int ppc, double vth, uint6
 {
   CTX_CHECK(ctx); SORT_CHECK(sort);
   XPIC_CHECK(ppc > 0, "ppc must be positive");
-  return sort_fill_synthetic(ctx, ctx->sorts[sort], ppc, vth, seed, regular != 0);
+  xpic_load_params lp{};
+  lp.ppc = ppc; lp.vth = vth; lp.seed = seed;
+  lp.profile = regular ? XPIC_LOAD_REGULAR : XPIC_LOAD_UNIFORM;
+  return sort_fill_synthetic(ctx, ctx->sorts[sort], lp);
+}
+
+int xpic_sort_load_synthetic(xpic_ctx* ctx, int sort, const xpic_load_params* lp)
+{
+  CTX_CHECK(ctx); SORT_CHECK(sort);
+  XPIC_CHECK(lp && lp->ppc > 0, "ppc must be positive");
+  return sort_fill_synthetic(ctx, ctx->sorts[sort], *lp);
+}
+
+int xpic_sort_occupancy(xpic_ctx* ctx, int sort, int64_t* out8)
+{
+  CTX_CHECK(ctx); SORT_CHECK(sort);
+  XPIC_CHECK(out8, "null argument");
+  return sort_occupancy(ctx, ctx->sorts[sort], out8);
 }
 
 int xpic_field_set(xpic_ctx* ctx, int field, const double* v)

@@ -319,7 +319,8 @@ void sort_deferred_done(Sort& s);             // the assembly has written the so
 int sort_move(xpic_ctx* c, Sort& s, double step); // r += step*v in place, cells left stale // (optional move by step*v), wrap, bin, scatter
 int sort_append_host(xpic_ctx* c, Sort& s, int64_t n, const double* pts6, int64_t* added);
 int sort_download(xpic_ctx* c, Sort& s, double* pts6, int32_t* cell_of);
-int sort_fill_synthetic(xpic_ctx* c, Sort& s, int ppc, double vth, uint64_t seed, bool regular);
+int sort_fill_synthetic(xpic_ctx* c, Sort& s, const xpic_load_params& lp);
+int sort_occupancy(xpic_ctx* c, Sort& s, int64_t* out8);
 int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B, bool prebin = false);
 int charge_density(xpic_ctx* c, Sort& s, double* rho_vec);
 int moment_density(xpic_ctx* c, Sort& s, double* vec);

@@ -938,6 +938,7 @@ int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, d
   // warp-specialised body has no gathering form: scatter first
   if (s.deferred && (ws || !s.def_wrap)) XPIC_CALL(sort_materialize(c, s));
   const bool ga = s.deferred;
+  if (ga && c->profiling) c->prof["fill_gather"].launches += 1; // (what this assembly did, for bench.py's byte counts)
   const bool store_sorted = ga && c->fused_rebin != 2; // 2: the records stay in the old order until k_second_push moves them
   // y is periodic inside the slab; z is periodic only when the slab is the whole box: with z-neighbours the rows
   // below plane 0 / above plane nzl-1 are ghost rows of this rank alone, so plain residues mod per_z suffice

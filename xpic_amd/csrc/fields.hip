@@ -768,6 +768,7 @@ int cheb_matM_inverse(xpic_ctx* c, const double* r, double* out, int degree)
   const double a = 2.0, b = 2.0 + 2.0 * g.dt * g.dt * (1.0 / (g.dx * g.dx) + 1.0 / (g.dy * g.dy) + 1.0 / (g.dz * g.dz));
   const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma1 = theta / delta;
   if (degree <= 1) return launch_ew(c, FScaleTo{out, 1.0 / theta, r});
+  if (c->profiling) c->prof["cheb_steps"].launches += degree - 1;
   double rho = 1.0 / sigma1;
   long blocks = (g.nown + kBlock - 1) / kBlock;
   if (blocks > 65536) blocks = 65536;

@@ -209,6 +209,30 @@ __global__ void __launch_bounds__(kBlock) k_max_pencil(const int* __restrict__ c
   if (pop >= limit) atomicMax(out, pop);
 }
 
+// occupancy statistics of a sort (xpic_sort_occupancy): what the per-cell passes, the buckets and the per-pencil workgroups
+// of the particle kernels will meet.  One thread per x-pencil.
+__global__ void __launch_bounds__(kBlock) k_occupancy(const int* __restrict__ cell_start, int nx, long npencils, int bucket_cap,
+  unsigned long long* out)
+{
+  const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= npencils) return;
+  const int* cs = cell_start + i * nx;
+  int mx = 0, over64 = 0, over128 = 0, overb = 0, empty = 0;
+  for (int x = 0; x < nx; ++x) {
+    const int c = cs[x + 1] - cs[x];
+    mx = c > mx ? c : mx;
+    over64 += c > 64; over128 += c > 128; overb += bucket_cap > 0 && c > bucket_cap; empty += c == 0;
+  }
+  const unsigned long long pop = (unsigned long long)(cs[nx] - cs[0]);
+  atomicMax(&out[0], (unsigned long long)mx);
+  if (over64) atomicAdd(&out[1], (unsigned long long)over64);
+  if (over128) atomicAdd(&out[2], (unsigned long long)over128);
+  if (overb) atomicAdd(&out[3], (unsigned long long)overb);
+  atomicMax(&out[4], pop);
+  atomicMin(&out[5], pop);
+  if (empty) atomicAdd(&out[6], (unsigned long long)empty);
+}
+
 // ... and the records that arrived from the neighbouring slabs stay in the receive buffer: slot <- -1 - (record number)
 __global__ void __launch_bounds__(kBlock) k_index_incoming(SortDev s, int n, const int* __restrict__ inc_cell, const int* __restrict__ inc_rank)
 {
@@ -673,8 +697,16 @@ __device__ inline double u01(uint64_t& st) { return ((splitmix(st) >> 11) + 0.5)
 // otherwise the position is uniform over the whole slab like CoordinateInBox + SetParticles
 // (src/utils/particles_load.cpp:11-18, src/commands/set_particles.cpp:19-43): Poisson occupancy of the cells,
 // binned afterwards by the ordinary counting sort
-template <bool REGULAR>
-__global__ void __launch_bounds__(kBlock) k_synthetic(GridDev g, SortDev s, int64_t n, int ppc, double vth, uint64_t seed)
+// PROFILE (xpic_load_params::profile): 2 = density falling linearly along x from ratio : 1 (x = 0) to 1 (x = Lx), sampled
+// through the inverse of its distribution function; 3 = a fraction of the particles in a Gaussian clump at the centre of the
+// slab (Box-Muller, folded back periodically), the rest uniform.  drift: MaxwellianMomentum's px, py, pz
+// (src/utils/particles_load.cpp:57-76): added to the thermal momentum before `tov`.
+struct LoadDev {
+  double drift[3];
+  double a, b; // profile 2: density ratio; profile 3: clump fraction, clump sigma in cells
+};
+template <bool REGULAR, int PROFILE = 0>
+__global__ void __launch_bounds__(kBlock) k_synthetic(GridDev g, SortDev s, int64_t n, int ppc, double vth, uint64_t seed, LoadDev ld)
 {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= n) return;
@@ -689,14 +721,34 @@ __global__ void __launch_bounds__(kBlock) k_synthetic(GridDev g, SortDev s, int6
     s.r[2][p] = (cz + g.z0 + fz) * g.dz;
   }
   else {
-    s.r[0][p] = fx * g.nx * g.dx;
-    s.r[1][p] = fy * g.ny * g.dy;
-    s.r[2][p] = (g.z0 + fz * g.nzl) * g.dz;
+    double ux = fx, uy = fy, uz = fz;
+    if (PROFILE == 2) {
+      // n(u) ~ ratio - (ratio - 1) u on [0, 1):  F(u) = (ratio u - (ratio - 1) u^2 / 2) / ((ratio + 1) / 2)
+      const double r = ld.a, F = fx * 0.5 * (r + 1.0);
+      ux = r > 1.0 ? (r - sqrt(r * r - 2.0 * (r - 1.0) * F)) / (r - 1.0) : fx;
+      ux = fmin(fmax(ux, 0.0000005), 0.9999995);
+    }
+    if (PROFILE == 3) {
+      const double pick = u01(st);
+      double gs[3];
+      for (int c = 0; c < 3; ++c) {
+        const double u1 = u01(st), u2 = u01(st);
+        gs[c] = ld.b * sqrt(-2.0 * log(u1)) * sin(2.0 * M_PI * u2); // cells
+      }
+      if (pick < ld.a) {
+        ux = 0.5 + gs[0] / g.nx; uy = 0.5 + gs[1] / g.ny; uz = 0.5 + gs[2] / g.nzl;
+        ux -= floor(ux); uy -= floor(uy); uz -= floor(uz);
+        ux = fmin(fmax(ux, 0.0000005), 0.9999995); uy = fmin(fmax(uy, 0.0000005), 0.9999995); uz = fmin(fmax(uz, 0.0000005), 0.9999995);
+      }
+    }
+    s.r[0][p] = ux * g.nx * g.dx;
+    s.r[1][p] = uy * g.ny * g.dy;
+    s.r[2][p] = (g.z0 + uz * g.nzl) * g.dz;
   }
   double v[3];
   for (int c = 0; c < 3; ++c) {
     const double u1 = u01(st), u2 = u01(st);
-    v[c] = vth * sqrt(-2.0 * log(u1)) * sin(2.0 * M_PI * u2);
+    v[c] = ld.drift[c] + vth * sqrt(-2.0 * log(u1)) * sin(2.0 * M_PI * u2);
   }
   const double gam = sqrt(1.0 + v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
   s.v[0][p] = v[0] / gam; s.v[1][p] = v[1] / gam; s.v[2][p] = v[2] / gam;
@@ -828,6 +880,7 @@ static int launch_scatter(xpic_ctx* c, Sort& s, int64_t n_old, double step, bool
 static int rebuild_keys(xpic_ctx* c, Sort& s, int64_t n_old, double step)
 {
   Timed t(c, "move_bin");
+  if (c->profiling) c->prof["rebuild_keys"].launches += 1;
   XPIC_HIP(hipMemsetAsync(s.d.cell_count, 0, sizeof(int) * (c->ncell + 1), c->stream));
   SortDev sd = s.d;
   sd.bucket_cap = 0;
@@ -1064,21 +1117,53 @@ int sort_download(xpic_ctx* c, Sort& s, double* pts6, int32_t* cell_of_out)
   return 0;
 }
 
-int sort_fill_synthetic(xpic_ctx* c, Sort& s, int ppc, double vth, uint64_t seed, bool regular)
+int sort_occupancy(xpic_ctx* c, Sort& s, int64_t* out8)
 {
+  XPIC_CALL(sort_materialize(c, s));
+  unsigned long long* d = nullptr;
+  unsigned long long h[8] = {0, 0, 0, 0, 0, ~0ull, 0, 0};
+  XPIC_HIP(hipMalloc(&d, sizeof(h)));
+  XPIC_HIP(hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+  const long npen = c->ncell / c->g.nx;
+  hipLaunchKernelGGL(k_occupancy, dim3(pgrid(npen)), dim3(kBlock), 0, c->stream, s.d.cell_start, c->g.nx, npen, s.d.bucket_cap, d);
+  XPIC_HIP(hipGetLastError());
+  XPIC_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  XPIC_HIP(hipStreamSynchronize(c->stream));
+  XPIC_HIP(hipFree(d));
+  for (int i = 0; i < 7; ++i) out8[i] = (int64_t)h[i];
+  out8[7] = s.d.bucket_cap;
+  return 0;
+}
+
+int sort_fill_synthetic(xpic_ctx* c, Sort& s, const xpic_load_params& lp)
+{
+  const int ppc = lp.ppc;
+  const double vth = lp.vth;
+  const uint64_t seed = lp.seed;
+  const bool regular = lp.profile == XPIC_LOAD_REGULAR;
+  LoadDev ld{{lp.drift[0], lp.drift[1], lp.drift[2]}, lp.profile_param[0], lp.profile_param[1]};
+  XPIC_CHECK(lp.profile >= 0 && lp.profile <= XPIC_LOAD_BLOB, "unknown load profile");
+  XPIC_CHECK(lp.profile != XPIC_LOAD_GRADIENT || lp.profile_param[0] >= 1.0, "gradient load: density ratio >= 1");
+  XPIC_CHECK(lp.profile != XPIC_LOAD_BLOB || (lp.profile_param[0] >= 0.0 && lp.profile_param[0] <= 1.0 && lp.profile_param[1] > 0.0),
+    "blob load: fraction in [0, 1], sigma > 0 cells");
   XPIC_CALL(sort_materialize(c, s)); // (a deferred re-binning whose assembly has not run)
   s.prebinned = false;
   const int64_t n = (int64_t)c->ncell * ppc;
   XPIC_CHECK(n <= s.cap, "sort capacity exceeded in fill_synthetic");
   if (regular) {
-    hipLaunchKernelGGL(k_synthetic<true>, dim3(pgrid(n)), dim3(kBlock), 0, c->stream, c->g, s.d, n, ppc, vth, seed);
+    hipLaunchKernelGGL((k_synthetic<true, 0>), dim3(pgrid(n)), dim3(kBlock), 0, c->stream, c->g, s.d, n, ppc, vth, seed, ld);
     hipLaunchKernelGGL(k_fill_counts, dim3((unsigned)((c->ncell + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
       s.d.cell_count, s.d.cell_start, (long)c->ncell, ppc);
     XPIC_HIP(hipGetLastError());
     s.n = n;
     return 0;
   }
-  hipLaunchKernelGGL(k_synthetic<false>, dim3(pgrid(n)), dim3(kBlock), 0, c->stream, c->g, s.d, n, ppc, vth, seed);
+  if (lp.profile == XPIC_LOAD_GRADIENT)
+    hipLaunchKernelGGL((k_synthetic<false, 2>), dim3(pgrid(n)), dim3(kBlock), 0, c->stream, c->g, s.d, n, ppc, vth, seed, ld);
+  else if (lp.profile == XPIC_LOAD_BLOB)
+    hipLaunchKernelGGL((k_synthetic<false, 3>), dim3(pgrid(n)), dim3(kBlock), 0, c->stream, c->g, s.d, n, ppc, vth, seed, ld);
+  else
+    hipLaunchKernelGGL((k_synthetic<false, 0>), dim3(pgrid(n)), dim3(kBlock), 0, c->stream, c->g, s.d, n, ppc, vth, seed, ld);
   XPIC_HIP(hipGetLastError());
   s.n = n;
   // add_particle's binning (no wrap; nothing falls outside).  With z-neighbours this is collective like any re-bin;

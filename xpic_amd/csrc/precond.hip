@@ -590,6 +590,7 @@ int cheb_abar_inverse(xpic_ctx* c, const double* r, double* out)
   const double kappa = b / a, rh = (std::sqrt(kappa) - 1.0) / (std::sqrt(kappa) + 1.0);
   int degree = c->cheb_degree_user > 0 ? c->cheb_degree_user : (int)std::ceil(std::log(scaled ? 0.00125 : 0.0125) / std::log(rh));
   degree = degree < 2 ? 2 : (degree > 64 ? 64 : degree);
+  if (c->profiling) c->prof["cheb_steps"].launches += degree - 1; // stencil steps of the polynomial (bench.py: per outer iteration)
   float* d = (float*)c->kry_p[0];
   float* z0 = (float*)c->kry_p[1];
   float* z1 = (float*)c->kry_p[2];

@@ -295,6 +295,13 @@ PetscErrorCode Simulation::init_particles()
       p.Ty = info.at("Ty").as_double();
       p.Tz = info.at("Tz").as_double();
     }
+    // EXTENSION (not reference behaviour): the reference's init_particles never reads the initial momentum
+    // (src/interfaces/simulation.tpp:24-41), although SortParameters has it (sort_parameters.h:13-15) and MaxwellianMomentum
+    // adds it (src/utils/particles_load.cpp:59-70): without it the JSON surface cannot express the two counter-streaming
+    // beams of a two-stream set-up.  Absent keys leave the reference's behaviour (zero drift) untouched.
+    if (info.contains("px")) p.px = info.at("px").as_double();
+    if (info.contains("py")) p.py = info.at("py").as_double();
+    if (info.contains("pz")) p.pz = info.at("pz").as_double();
     auto sort = std::make_shared<Particles>(*this, p);
     xpic_sort_params sp{p.Np, p.n, p.q, p.m};
     const int64_t cells = (int64_t)geom_nx * geom_ny * geom_nz;
