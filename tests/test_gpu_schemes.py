@@ -341,7 +341,7 @@ def test_synthetic_loader_drift_and_profiles():
     assert pts.shape[0] == 64 * ncell
     col = np.bincount((cells % n[0]).astype(np.int64), minlength=n[0]).astype(float)  # particles per x-column of cells
     lin = 4.0 - 3.0 * (np.arange(n[0]) + 0.5) / n[0]
-    assert np.abs(col / col.sum() - lin / lin.sum()).max() < 0.01 * (lin / lin.sum()).max()
+    assert np.abs(col / col.sum() - lin / lin.sum()).max() < 0.06 * (lin / lin.sum()).max()  # (~ 6600 +- 80 particles in the first column)
     g.load_synthetic(s, 64, 0.01, seed=7, profile="blob", param=(0.25, 1.5))
     pts, cells = g.particles(s)
     assert pts.shape[0] == 64 * ncell
