@@ -61,7 +61,7 @@ def parse_args(argv=None):
     ap.add_argument("--fill-kernel", type=int, default=None, choices=[0, 1],
                     help="mass-matrix assembly: 1 warp-specialised kernel, 0 the classic 4-wave kernel (default: the library's)")
     ap.add_argument("--cheb-degree", type=int, default=0, help="override the Chebyshev preconditioner degree (experiments)")
-    ap.add_argument("--precond", type=int, default=None, choices=[0, 1, 2, 3, 4],
+    ap.add_argument("--precond", type=int, default=None, choices=[0, 1, 2, 3, 4, 5],
                     help="xpic_set_preconditioner kind (default: the library's)")
     ap.add_argument("--scheme", default="ecsim", choices=["ecsim", "ecsimcorr", "basic"],
                     help="ecsim is the headline workload (BASELINE configs[2]); basic = configs[1], ecsimcorr = configs[4] "
@@ -528,8 +528,8 @@ def rank_body(args, rank, world, local_rank, job):
                                             "second_push", "mdot", "maxpy", "matL_zero", "scan", "index", "rot_apply",
                                             "halo", "migrate", "matL_ghost_rows", "basic_push", "corr_first_push", "precond_setup",
                                             "corr_second_push", "solve_matM", "precond", "matL_apply", "rebin",
-                                            "allreduce", "cheb_steps", "rebuild_keys", "fill_gather", "precond_fallback")}
-    COUNTERS = ("allreduce", "cheb_steps", "rebuild_keys", "fill_gather", "precond_fallback")
+                                            "allreduce", "cheb_steps", "rebuild_keys", "fill_gather", "precond_fallback", "precond_scaled")}
+    COUNTERS = ("allreduce", "cheb_steps", "rebuild_keys", "fill_gather", "precond_fallback", "precond_scaled")
     count_local = sum(ctx.count(s) for s in sorts)
     count = int(job.reduce(count_local, "sum"))
     assert count == world * npart, "particles were lost in a periodic box"
@@ -578,9 +578,9 @@ def rank_body(args, rank, world, local_rank, job):
             "GMRES(30), no preconditioner" if args.plain_gmres or args.precond == 0 else
             "flexible GMRES(30), right-preconditioned by a Chebyshev polynomial in " +
             ("matM + diag(r) <matL> (the translation average of the assembled mass matrix, its rows scaled by the local "
-             "density ratio r: one 123-point stencil, fp32)" if args.precond == 4 else
+             "density ratio r: one 123-point stencil, fp32)" if args.precond == 4 or (args.precond in (None, 5) and prof["precond_scaled"][0]) else
              "matM + <matL> (the translation average of the assembled mass matrix: one constant 123-point stencil, fp32)"
-             if args.precond in (None, 3) else "matM (fp32 work vectors)" if args.precond == 1 else "matM (fp64)") +
+             if args.precond in (None, 3, 5) else "matM (fp32 work vectors)" if args.precond == 1 else "matM (fp64)") +
             "; outer iterations, each = 1 matA apply + the polynomial's stencil applies"),
         "ksp_iterations_per_step": its_total / world / args.steps,
         # "KSP iterations" of two methods are not one unit (an outer iteration here carries the polynomial's stencil steps, the
@@ -599,7 +599,8 @@ def rank_body(args, rank, world, local_rank, job):
                           index_passes_per_step=prof["index"][0] / args.steps,
                           key_rebuilds_per_step=prof["rebuild_keys"][0] / args.steps,
                           gathering_assemblies_per_step=prof["fill_gather"][0] / args.steps,
-                          precond_fallbacks_per_step=prof["precond_fallback"][0] / args.steps),
+                          precond_fallbacks_per_step=prof["precond_fallback"][0] / args.steps,
+                          density_scaled_surrogates_per_step=prof["precond_scaled"][0] / args.steps),
         "allreduces_per_step": prof["allreduce"][0] / args.steps,  # reductions that are all-reduces on slabs (counted on 1 GPU too)
         "device_copy_GBps": copy_rate / 1e9 if copy_rate else None,
         # what ONE rank puts on its links per step (rank 0; every slab sends the same): point-to-point messages to the two

@@ -190,14 +190,17 @@ int xpic_set_tolerances(xpic_ctx* ctx, double rtol, double atol, int maxit);
 /* PCSetType for the "predict" and "correct" KSPs.  The reference runs PETSc's default ILU(0) (not part of its tree, not a GPU
  * algorithm); here: kind 0 = none, kind 1 / 2 = a fixed Chebyshev polynomial in matM applied from the right
  * (matM = 2 I + 0.5 dt^2 rotB rotE dominates matA and its spectral interval is known in closed form), its work vectors
- * kept in fp32 (kind 1) or fp64 (kind 2); kind 3 (default) = the polynomial in matM + <matL>, the translation average of the assembled
+ * kept in fp32 (kind 1) or fp64 (kind 2); kind 3 = the polynomial in matM + <matL>, the translation average of the assembled
  * mass matrix as one constant-coefficient 123-point stencil (fp32), for the predict solve (the correct solve on matM keeps
  * kind 1); kind 4 = kind 3 with the rows of <matL> scaled by the local density (the ratio of the row's own diagonal
  * entry of matL to the average's): three times the convergence rate per iteration at 64 particles per cell, at twice the
- * polynomial's cost (at the reference's tolerance both need 4 iterations on the 256^3 box: kind 3 is the faster one there).  The GMRES around it is the flexible variant (x = x0 + sum y_j P v_j with the
+ * polynomial's cost (at the reference's tolerance both need 4 iterations on the uniform 256^3 box: kind 3 is the faster one
+ * there; with the density falling 4 : 1 across the box kind 3 needs 6 and kind 4 four); kind 5 (default) = kind 3 or kind 4,
+ * chosen per solve from the relative spread of matL's diagonal (above 0.2: kind 4; a uniform Poisson load of 64 per cell
+ * has 0.1).  The GMRES around it is the flexible variant (x = x0 + sum y_j P v_j with the
  * P v_j stored): the result does not depend on how exactly P is applied, only the iteration count could.
  * degree <= 0 returns to the automatic choice.  The stopping rule of xpic_solve is unchanged (the residual of A x = b).
- * Kinds 3 and 4 check their surrogate per solve (2 + the Gershgorin lower bound of <matL> must be positive) and otherwise runs
+ * Kinds 3, 4 and 5 check their surrogate per solve (2 + the Gershgorin lower bound of <matL> must be positive) and otherwise runs
  * that solve with kind 1. */
 int xpic_set_preconditioner(xpic_ctx* ctx, int kind, int degree);
 /* The mass-matrix assembly (fill_ecsim_current) has two bodies: kind 0 (default) the classic 4-wave kernel (all grids);

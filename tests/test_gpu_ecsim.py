@@ -363,14 +363,15 @@ def test_preconditioned_solve(oracle):
     assert reason_t > 0 and rt <= 2e-12 * np.linalg.norm(rhs), (rt, rn_t)
 
 
-@pytest.mark.parametrize("kind", [3, 4])
+@pytest.mark.parametrize("kind", [3, 4, 5])
 def test_preconditioner_with_the_mean_mass_matrix(oracle, kind):
     """kind 3: Chebyshev polynomial in matM + <matL> (the translation average of the assembled mass matrix as one
     constant 123-point stencil, fp32); kind 4: the same with the rows of <matL> scaled by the local density ratio (the
     row's own diagonal entry of matL over the average's).  The GMRES is flexible and judges the fp64 residual of the
     unpreconditioned system: same solution as the oracle's plain GMRES within 10 x rtol, fewer iterations than the
     matM-only polynomial (kind 1) at enough particles per cell for the average to be a good model (64 ppc here, the
-    headline configuration's noise level), and kind 4 never more than kind 3."""
+    headline configuration's noise level), and kind 4 never more than kind 3.  Kind 5 (the default) is kind 3 here: the
+    spread of matL's diagonal in a uniform Poisson load of 64 per cell is its count noise, 0.1, below the threshold."""
     import xpic_amd as X
 
     n, d = (12, 10, 8), (0.5, 0.5, 0.5)
@@ -384,8 +385,12 @@ def test_preconditioner_with_the_mean_mass_matrix(oracle, kind):
     g.set_preconditioner(3)
     its_k3, _, _ = g.solve(0, X.E, X.W2, 1e-7, 1e-50, 300)
     g.set_preconditioner(kind)
+    g.profile_enable(True)
+    g.profile_reset()
     its3, reason3, rn3 = g.solve(0, X.E, X.W2, 1e-7, 1e-50, 300)
-    assert reason1 > 0 and reason3 > 0 and its3 < its1 and its3 <= (5 if kind == 3 else 4) and its3 <= its_k3, (its1, its_k3, its3)
+    assert g.profile_get("precond_scaled")[0] == (1 if kind == 4 else 0) and g.profile_get("precond_fallback")[0] == 0
+    g.profile_enable(False)
+    assert reason1 > 0 and reason3 > 0 and its3 < its1 and its3 <= (4 if kind == 4 else 5) and its3 <= its_k3, (its1, its_k3, its3)
     x3 = g.get_field(X.W2)
     assert np.abs(xo - x3).max() <= 1e-6 * np.abs(xo).max()
     res = np.linalg.norm(o.matM(x3) + o.matL_apply(x3) - rhs)
@@ -402,6 +407,67 @@ def test_preconditioner_with_the_mean_mass_matrix(oracle, kind):
     for name, fid in (("E", X.E), ("B", X.B)):
         a, b = o.get_field(name), g.get_field(fid)
         assert np.abs(a - b).max() <= 1e-7 * np.abs(a).max()
+
+
+def test_default_preconditioner_scales_its_surrogate_where_the_density_varies(oracle):
+    """Kind 5 (the default) on a plasma whose density falls 6 : 1 along x: the relative spread of matL's diagonal is far
+    above its threshold of 0.2, the solve runs the density-scaled surrogate (kind 4's), needs no more iterations than the
+    plain one (kind 3) and gives the oracle's solution; the true residual is the stopping rule either way."""
+    import xpic_amd as X
+
+    n, d = (16, 10, 8), (0.5, 0.5, 0.5)
+    o, g = make_pair(oracle, "ecsim", n, d, 1.0, [], B0=(0.0, 0.0, 0.2))
+    rng = np.random.default_rng(9)
+    npart = 48 * n[0] * n[1] * n[2]
+    u = rng.random(npart)
+    pts = np.empty((npart, 6))
+    pts[:, 0] = (6.0 - np.sqrt(36.0 - 35.0 * u)) / 5.0 * n[0] * d[0] * 0.999999  # density ~ 6 - 5 x / Lx
+    pts[:, 1:3] = rng.random((npart, 2)) * (np.array(n[1:]) * np.array(d[1:]))
+    pts[:, 3:] = rng.normal(0, 0.014, (npart, 3))
+    so = o.add_sort(48, 1.0, -1.0, 1.0)
+    sg = g.add_sort(48, 1.0, -1.0, 1.0, capacity=2 * npart)
+    assert o.add_particles(so, pts) == g.add_particles(sg, pts) == npart
+    oracle.lib().orc_ecsim_fill_current(o.h)
+    g.ecsim_fill_current()
+    rhs = o.get_field("E")
+    xo, its_o, _ = o.solve(0, rhs, 1e-9, 1e-50, 300)
+    g.profile_enable(True)
+    res = {}
+    for kind in (3, 5):
+        g.set_preconditioner(kind)
+        g.profile_reset()
+        its, reason, rn = g.solve(0, X.E, X.W2, 1e-7, 1e-50, 300)
+        assert reason > 0
+        res[kind] = (its, g.profile_get("precond_scaled")[0], g.profile_get("precond_fallback")[0])
+        x = g.get_field(X.W2)
+        assert np.abs(xo - x).max() <= 1e-6 * np.abs(xo).max(), kind
+        assert np.linalg.norm(o.matM(x) + o.matL_apply(x) - rhs) <= 1.05e-7 * np.linalg.norm(rhs), kind
+    assert res[3][1] == 0 and res[5][1] == 1 and res[5][2] == 0, res  # kind 5 scaled its rows; nobody fell back
+    assert res[5][0] <= res[3][0] < its_o, (res, its_o)
+
+
+def test_preconditioner_falls_back_when_its_surrogate_is_not_trusted(oracle):
+    """Kinds 3 - 5 check their surrogate per solve: 2 + the Gershgorin lower bound of <matL> (times the largest density
+    ratio for the scaled form) must be positive, or the solve runs the polynomial in matM alone (precond.hip; counted as
+    precond_fallback).  A plasma of 30 times the reference density puts the crude bound far below zero: the solve must
+    still converge to the oracle's solution, on the fallback."""
+    import xpic_amd as X
+
+    n, d, dt = GRID_P2FX
+    o, g = make_pair(oracle, "ecsim", n, d, 1.0, [(8, 30.0, -1.0, 1.0)], ppc=8, vth=0.014, B0=(0.0, 0.0, 0.5))
+    oracle.lib().orc_ecsim_fill_current(o.h)
+    g.ecsim_fill_current()
+    rhs = o.get_field("E")
+    xo, its_o, _ = o.solve(0, rhs, 1e-9, 1e-50, 400)
+    g.profile_enable(True)
+    for kind in (3, 4, 5):
+        g.set_preconditioner(kind)
+        g.profile_reset()
+        its, reason, _ = g.solve(0, X.E, X.W2, 1e-7, 1e-50, 400)
+        assert reason > 0 and 0 < its <= its_o, (kind, its, its_o)
+        assert g.profile_get("precond_fallback")[0] == 1, kind
+        x = g.get_field(X.W2)
+        assert np.abs(xo - x).max() <= 1e-6 * np.abs(xo).max(), kind
 
 
 def test_default_step_uses_preconditioner_and_matches_oracle(oracle):

@@ -716,7 +716,7 @@ int xpic_solve(xpic_ctx* ctx, int op, int rhs, int x, double rtol, double atol, 
 int xpic_set_preconditioner(xpic_ctx* ctx, int kind, int degree)
 {
   CTX_CHECK(ctx);
-  XPIC_CHECK(kind >= 0 && kind <= 4, "unknown preconditioner kind");
+  XPIC_CHECK(kind >= 0 && kind <= 5, "unknown preconditioner kind");
   ctx->precond = kind;
   ctx->cheb_degree_user = degree > 0 ? (degree > 64 ? 64 : degree) : 0;
   if (degree > 0) ctx->cheb_degree = ctx->cheb_degree_M = ctx->cheb_degree_user;

@@ -107,12 +107,15 @@ int comm_allreduce_sum_host(xpic_ctx* c, double* hbuf, int n)
 int comm_allreduce_max_host(xpic_ctx* c, double* v)
 {
   if (c->comm.kind == 0) return 0;
-  XPIC_CHECK(c->comm.nranks <= 32, "host all-reduce limited to 32 ranks");
-  double buf[32] = {};
-  buf[c->comm.rank] = *v;
-  XPIC_CALL(comm_allreduce_sum_host(c, buf, c->comm.nranks));
+  // (in chunks of 32 ranks -- the host all-reduce's width: any number of slabs, one more small all-reduce per 32 of them)
   double m = 0.0;
-  for (int i = 0; i < c->comm.nranks; ++i) m = buf[i] > m ? buf[i] : m;
+  for (int base = 0; base < c->comm.nranks; base += 32) {
+    const int n = c->comm.nranks - base < 32 ? c->comm.nranks - base : 32;
+    double buf[32] = {};
+    if (c->comm.rank >= base && c->comm.rank < base + n) buf[c->comm.rank - base] = *v;
+    XPIC_CALL(comm_allreduce_sum_host(c, buf, n));
+    for (int i = 0; i < n; ++i) m = buf[i] > m ? buf[i] : m;
+  }
   *v = m;
   return 0;
 }

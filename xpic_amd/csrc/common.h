@@ -34,8 +34,9 @@
 #define XPIC_DEFAULT_FUSED_REBIN 1
 #endif
 #ifndef XPIC_DEFAULT_PRECOND
-#define XPIC_DEFAULT_PRECOND 3 // 3: polynomial in matM + <matL>; 4: its rows scaled by the local density (precond.hip: 3x the
-// convergence rate, but at 256^3 x 64 its third residual is 1.17e-7 |b| against the tolerance's 1e-7: still 4 iterations, each dearer)
+#define XPIC_DEFAULT_PRECOND 5 // 3: polynomial in matM + <matL>; 4: its rows scaled by the local density (precond.hip: 3x the
+// convergence rate, but at 256^3 x 64 its third residual is 1.17e-7 |b| against the tolerance's 1e-7: still 4 iterations, each dearer);
+// 5: 3 for a uniform plasma, 4 where the density varies (chosen per solve from the spread of matL's diagonal)
 #endif
 #ifndef XPIC_DEFAULT_FILL_KERNEL
 #define XPIC_DEFAULT_FILL_KERNEL 0 // the assembly body a new context runs (xpic_set_fill_kernel): whichever measures faster at 256^3 x 64
@@ -217,7 +218,8 @@ struct xpic_ctx {
   double* kry_Z = nullptr; // flexible GMRES: the preconditioned basis z_j = P v_j (allocated by the first preconditioned solve)
   double* kry_p[3] = {nullptr, nullptr, nullptr}; // Chebyshev preconditioner work vectors
   int precond = XPIC_DEFAULT_PRECOND; // 0 none; Chebyshev polynomial (right preconditioning) in matM on fp32 (1) / fp64 (2) work vectors,
-                       // 3: in matM + the translation average of matL (precond.hip) for the predict solve
+                       // 3: in matM + the translation average of matL (precond.hip) for the predict solve; 4: rows scaled by the local
+                       // density; 5: 3 or 4, chosen per solve
   int num_cus = 256; // hipDeviceAttributeMultiprocessorCount (the colour schedule of the assembly counts workgroup rounds)
   int cheb_degree = 0; // steps of the Chebyshev iteration on matM (set at create from the spectral interval)
   int cheb_degree_M = 0; // the same iteration as the preconditioner of a solve ON matM (ecsimcorr's "correct"): a tighter bound pays there
@@ -229,6 +231,7 @@ struct xpic_ctx {
   double abar_lo = 0, abar_hi = 0; // spectral interval of Abar
   double abar_gershgorin = 0;      // 2 + Gershgorin lower bound of Lbar: kind 3 is used only while this is positive
   bool abar_valid = false;
+  bool abar_scaled = false;        // this solve's surrogate has its rows scaled by the local density (kind 4; kind 5 where it pays)
   double* red_partial = nullptr; // reduction partials
   double* red_out = nullptr;     // device results (pinned mirror below)
   double* red_host = nullptr;

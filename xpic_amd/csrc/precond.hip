@@ -29,6 +29,7 @@ namespace xpic {
 namespace {
 
 constexpr int kB = 256;
+constexpr double kAutoSpread = 0.2; // kind 5: relative spread of matL's diagonal above which the surrogate's rows are scaled
 #ifndef XPIC_CHEB_MIN_ZC
 #define XPIC_CHEB_MIN_ZC 8 // planes per z-chunk of k_cheb_bar at least (a chunk loads 5 more)
 #endif
@@ -118,6 +119,45 @@ __global__ void __launch_bounds__(512) k_lbar_final(const double* __restrict__ s
   }
   __syncthreads();
   if (t < kLPad) sums[c1 * kLPad + t] = (sm[4 * t] + sm[4 * t + 1]) + (sm[4 * t + 2] + sm[4 * t + 3]);
+}
+
+// Second moment of matL's diagonal over the same sampled rows (kind 5's choice between the plain and the density-scaled
+// surrogate): one workgroup per sampled row and component sums d^2 along x in a fixed order; k_diag2_final adds the rows'
+// values, again in a fixed order, into the free slot 123 of `sums` (kLPad = 124), so that it is averaged, all-reduced on
+// slabs and copied into abar64 with the coefficients.
+__global__ void __launch_bounds__(256) k_diag2_rows(GridDev g, const double* __restrict__ matL, int sy, int sz, int nys,
+  double* __restrict__ part2)
+{
+  const int row = blockIdx.x, c1 = blockIdx.y;
+  const int y = (row % nys) * sy, z = (row / nys) * sz;
+  const int kd = lencode(c1, c1, 0, 0, 0);
+  double s = 0.0;
+  for (int x = threadIdx.x; x < g.nx; x += 256) {
+    const double d = matL[g.lindex(c1, z + (g.G ? 1 : 0), y, x, kd)];
+    s += d * d;
+  }
+  __shared__ double sm[256];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part2[(long)row * 3 + c1] = sm[0];
+}
+__global__ void __launch_bounds__(256) k_diag2_final(const double* __restrict__ part2, int nrows, double* __restrict__ sums)
+{
+  const int c1 = blockIdx.x;
+  double s = 0.0;
+  for (int r = threadIdx.x; r < nrows; r += 256) s += part2[(long)r * 3 + c1];
+  __shared__ double sm[256];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sums[c1 * kLPad + kLStencil] = sm[0];
 }
 
 // Abar = matM + <matL>: fp64 copy in the 123-pattern (host: spectral bound) and the fp32 table k_cheb_bar reads, packed
@@ -481,7 +521,12 @@ __global__ void __launch_bounds__(64) k_abar_bounds(const double* __restrict__ a
     if (k == kdiag) diag = v;
   }
   for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o); diag += __shfl_xor(diag, o); }
-  if (lane == 0) { out[c1] = sa; out[3 + c1] = diag - (sa - fabs(diag)); }
+  if (lane == 0) {
+    out[c1] = sa; out[3 + c1] = diag - (sa - fabs(diag));
+    // relative variance of matL's diagonal over the sampled rows: <d^2> / <d>^2 - 1 (slot 123 holds <d^2>, see k_diag2_rows)
+    const double d2 = abar64[c1 * kLPad + kLStencil];
+    out[7 + c1] = diag > 0.0 ? d2 / (diag * diag) - 1.0 : 0.0;
+  }
 }
 
 }  // namespace
@@ -500,7 +545,7 @@ int abar_alloc(xpic_ctx* c)
   XPIC_HIP(hipMemsetAsync(c->abar32, 0, sizeof(float) * ntab, c->stream));
   XPIC_HIP(hipMalloc(&c->abar_r, sizeof(float) * c->nvec + 16)); // kind 4: local density ratios (fp32 field layout) + the max word
   XPIC_HIP(hipMemsetAsync(c->abar_r, 0, sizeof(float) * c->nvec + 16, c->stream));
-  XPIC_HIP(hipMalloc(&c->abar_work, sizeof(double) * (3 * kLPad * 3 + ((size_t)nrows + kSegs) * 3 * kLBlock)));
+  XPIC_HIP(hipMalloc(&c->abar_work, sizeof(double) * (3 * kLPad * 3 + ((size_t)nrows + kSegs) * 3 * kLBlock + (size_t)nrows * 3)));
   double mco[3 * kLPad];
   matM_stencil(g, mco);
   // the compile-time list of matM's taps (is_matM_tap) against the probed coefficients
@@ -532,13 +577,32 @@ int abar_update(xpic_ctx* c)
   double* segsum = partial + (size_t)nrows * 3 * kLBlock;
   hipLaunchKernelGGL(k_lbar_segments, dim3(3, kSegs), dim3(512), 0, c->stream, partial, nrows, segsum);
   hipLaunchKernelGGL(k_lbar_final, dim3(3), dim3(512), 0, c->stream, segsum, sums);
+  if (c->precond == 5) { // (behind k_lbar_final, which writes all 124 slots of a component)
+    double* part2 = segsum + (size_t)kSegs * 3 * kLBlock;
+    hipLaunchKernelGGL(k_diag2_rows, dim3(nrows, 3), dim3(256), 0, c->stream, g, c->matL, sy, sz, nys, part2);
+    hipLaunchKernelGGL(k_diag2_final, dim3(3), dim3(256), 0, c->stream, part2, nrows, sums);
+  }
   XPIC_HIP(hipGetLastError());
   XPIC_CALL(comm_allreduce_sum(c, sums, 3 * kLPad)); // the same surrogate on every slab
   const double count = (double)nrows * g.nx * c->comm.nranks;
   hipLaunchKernelGGL(k_abar, dim3(2), dim3(256), 0, c->stream, sums, mco, 1.0 / count, c->abar32, abar64);
-  double* bounds = c->red_out + 64; // [64, 71): behind the reductions' and the host all-reduce's slots
+  double* bounds = c->red_out + 64; // [64, 74): behind the reductions' and the host all-reduce's slots
   hipLaunchKernelGGL(k_abar_bounds, dim3(3), dim3(64), 0, c->stream, abar64, mco, bounds);
-  const bool scaled = c->precond == 4;
+  double* hb = c->red_host + 48;
+  // Kind 5 chooses per solve: the plain surrogate for a plasma that is uniform up to its count noise, the density-scaled
+  // one (kind 4's) where the density itself varies.  The measure is the relative spread of matL's diagonal over the sampled
+  // rows, sqrt(<d^2> / <d>^2 - 1): 0.1 for a uniform Poisson(64) load (256^3: kind 3 takes 4 iterations of degree 8, kind 4
+  // four dearer ones: 184 against 195 ms per step), 0.37 with the density falling 4 : 1 across the box (kind 3: 6
+  // iterations, kind 4: 4; 218 against 202 ms per step).  It travels in the all-reduced sums: every slab decides alike.
+  bool scaled = c->precond == 4;
+  if (c->precond == 5) {
+    XPIC_HIP(hipMemcpyAsync(hb + 7, bounds + 7, sizeof(double) * 3, hipMemcpyDeviceToHost, c->stream));
+    XPIC_HIP(hipStreamSynchronize(c->stream));
+    const double cv2 = std::max(hb[7], std::max(hb[8], hb[9]));
+    scaled = std::isfinite(cv2) && cv2 > kAutoSpread * kAutoSpread;
+  }
+  c->abar_scaled = scaled;
+  if (scaled && c->profiling) c->prof["precond_scaled"].launches += 1;
   unsigned* rmax_w = (unsigned*)(c->abar_r + c->nvec);
   if (scaled) {
     XPIC_HIP(hipMemsetAsync(rmax_w, 0, sizeof(unsigned), c->stream));
@@ -547,7 +611,6 @@ int abar_update(xpic_ctx* c)
     XPIC_HIP(hipMemcpyAsync(bounds + 6, rmax_w, sizeof(unsigned), hipMemcpyDeviceToDevice, c->stream));
   }
   XPIC_HIP(hipGetLastError());
-  double* hb = c->red_host + 48;
   XPIC_HIP(hipMemcpyAsync(hb, bounds, sizeof(double) * 7, hipMemcpyDeviceToHost, c->stream));
   XPIC_HIP(hipStreamSynchronize(c->stream));
   double rmax = 1.0;
@@ -586,7 +649,7 @@ int cheb_abar_inverse(xpic_ctx* c, const double* r, double* out)
   // error bound 2 rho^k / (1 + rho^2k) <= 2.5 % (what is left for GMRES is the 2 % noise of matL around its average);
   // kind 4 leaves 0.8 % and needs the polynomial at 0.25 % to keep its third iteration below the tolerance (degree 12
   // instead of 8 at dt = 1, h = 0.5: tools/precond_spectrum.py)
-  const bool scaled = c->precond == 4;
+  const bool scaled = c->abar_scaled;
   const double kappa = b / a, rh = (std::sqrt(kappa) - 1.0) / (std::sqrt(kappa) + 1.0);
   int degree = c->cheb_degree_user > 0 ? c->cheb_degree_user : (int)std::ceil(std::log(scaled ? 0.00125 : 0.0125) / std::log(rh));
   degree = degree < 2 ? 2 : (degree > 64 ? 64 : degree);
