@@ -237,7 +237,8 @@ int xpic_debug_set(xpic_ctx* ctx, int what, int64_t value);
  * interior colour launches (off by default: measured slower).
  * Default: 0 -- on the one-GPU self-ring (the only hardware these paths have run on) both overlaps cost more than the
  * exchanges they hide, and over RCCL with more than one rank the second-stream path has not yet run
- * on two distinct GPUs.  XPIC_RCCL_OVERLAP=1 turns bit 0 on at xpic_comm_init_rccl. */
+ * on two distinct GPUs.  XPIC_RCCL_OVERLAP=1 turns bit 0 on at xpic_comm_init_rccl.
+ * bit 2: the matL ghost rows by copy engine (see xpic_comm_peer_import below). */
 int xpic_set_overlap(xpic_ctx* ctx, int on);
 
 /* timestep_implementation of the context's scheme (basic/simulation.cpp:30-43, ecsim/simulation.cpp:145-155,
@@ -299,6 +300,17 @@ typedef struct xpic_comm_callbacks {
 int xpic_comm_init_callbacks(xpic_ctx* ctx, const xpic_comm_callbacks* cb);
 /* number of ranks of the attached communicator: ncclCommCount for RCCL, the z-slab count for callbacks, 1 without one
  * (MPI_Comm_size on PETSC_COMM_WORLD, src/utils/world.cpp:40-42) */
+/* Copy-engine path for the one large message of a step, the matL ghost rows (C11, MatSetValuesCOO's off-process entries,
+ * src/impls/ecsim/simulation.cpp:366): every rank publishes a blob describing the buffers its z-neighbours write into
+ * (xpic_comm_peer_export: IPC handles, hipIpcGetMemHandle), the caller carries the blobs to the neighbours over its bootstrap
+ * channel (as it carries the ncclUniqueId), and each rank maps its lower and its upper neighbour's buffer
+ * (xpic_comm_peer_import: hipIpcOpenMemHandle; ranks that are threads of one process, and a self-ring, use the addresses).
+ * With bit 2 of xpic_set_overlap the ghost rows then travel as hipMemcpyAsync on a copy stream -- between two GPUs an SDMA
+ * engine: no workgroup slot is taken from the assembly's colour launches they run beside -- and the rank's next ring
+ * exchange, issued behind the copies, is the neighbour's arrival signal.  RCCL (or the callbacks) keep every other message. */
+#define XPIC_PEER_BLOB_BYTES 256
+int xpic_comm_peer_export(xpic_ctx* ctx, void* blob /* XPIC_PEER_BLOB_BYTES */);
+int xpic_comm_peer_import(xpic_ctx* ctx, const void* lower_blob, const void* upper_blob);
 int xpic_comm_size(xpic_ctx* ctx, int* nranks);
 /* traffic of this rank since the last reset: out4 = {point-to-point messages sent, bytes sent, all-reduces, their payload
  * bytes} -- what a step puts on the links (the reference's MPI / PetscSF traffic) */

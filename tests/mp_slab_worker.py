@@ -3,7 +3,8 @@ through gloo (xpic_comm_init_callbacks).  Every rank runs the same seeded proble
 single-slab context AND on the CPU oracle (whole box) and checks that the decomposed run reproduces both: fields,
 particle totals and the per-cell occupancy of the whole box (update_cells_mpi, src/interfaces/particles.cpp:118-248).
 usage: mp_slab_worker.py <scheme> [planes per slab]
-environment: XPIC_SLAB_GATHER_WINDOW=<slots> -- the gathering assembly reaches only that far by 32-bit offsets (the far
+environment: XPIC_SLAB_PEER=1 -- the matL ghost rows travel by hipMemcpyAsync into the neighbours' IPC-mapped buffers;
+XPIC_SLAB_GATHER_WINDOW=<slots> -- the gathering assembly reaches only that far by 32-bit offsets (the far
 arm and the receive-buffer arm of its gather then meet the oracle); XPIC_SLAB_CONFINE=1 -- the LAST species lives in the
 middle of slab 0 only and is cold, so the other slabs hold no particle of it (the matL ghost-row exchange must still be
 posted at the same place of every rank's message sequence)"""
@@ -107,11 +108,21 @@ def main():
         ctx.set_overlap(int(os.environ.get("XPIC_SLAB_OVERLAP", "0")))  # 0 blocking, 1 operator halos, 3 + matL ghost rows
     else:
         GlooRing().attach(ctx)
+    if os.environ.get("XPIC_SLAB_PEER") == "1" and scheme != "basic":
+        # the matL ghost rows by hipMemcpyAsync into the neighbours' IPC-mapped receive buffers (the copy-engine path)
+        from xpic_amd.parallel import map_peers
+
+        map_peers(ctx)
+        ctx.set_overlap(4 | int(os.environ.get("XPIC_SLAB_OVERLAP", "0")))
+        ctx.profile_enable(True)
     counts0 = [ctx.count(s) for s in range(2)]
     if CONFINE:
         assert (counts0[1] > 0) == (rank == 0), counts0  # the last species lives on slab 0 alone
     nsteps = 3
     its = [ctx.step() for _ in range(nsteps)]
+    if os.environ.get("XPIC_SLAB_PEER") == "1" and scheme != "basic":
+        assert ctx.profile_get("peer_copies")[0] == 4 * nsteps, ctx.profile_get("peer_copies")  # 3 planes up + 1 down per step
+        ctx.profile_enable(False)
     en = ctx.energy()
     fields = {name: gather_field(ctx, fid, nranks) for name, fid in (("E", X.E), ("B", X.B))}
     counts = [ctx.count(s) for s in range(2)]

@@ -44,6 +44,16 @@ def test_slabs_with_a_short_gather_window():
 
 
 @pytest.mark.parametrize("scheme,world", [("ecsim", 2), ("ecsimcorr", 3)])
+def test_slabs_with_ghost_rows_by_peer_copy(scheme, world):
+    """The copy-engine path of the one large message of a step (xpic_comm_peer_export / _import, xpic_set_overlap bit 2):
+    the ranks -- separate processes sharing the box's one GPU -- map each other's receive buffers through IPC handles and
+    write their matL ghost rows there with hipMemcpyAsync on a copy stream, the next ring exchange being the arrival
+    signal.  Same fields, totals and per-cell occupancy as the single slab and the oracle; four copies per step counted.
+    (Two ranks: both neighbours are one process, two different buffers of it; three ranks: two different processes.)"""
+    run_slabs(scheme, world, 12, XPIC_SLAB_PEER="1")
+
+
+@pytest.mark.parametrize("scheme,world", [("ecsim", 2), ("ecsimcorr", 3)])
 def test_slabs_with_a_species_on_one_slab_only(scheme, world):
     """Point-to-point messages are matched per peer in issue order, so every rank must post the matL ghost-row exchange
     at the same place of its message sequence: behind the boundary colours of the LAST species of the list, whether or
@@ -101,15 +111,21 @@ def build(force):
     ctx.set_tolerances(1e-12, 1e-50, 400)
     return ctx
 
-a, b, c = build(True), build(False), build(True)
+a, b, c, d = build(True), build(False), build(True), build(True)
 a.set_overlap(3)      # operator halos posted beside the interior rows AND the matL ghost rows beside the interior colours
 c.set_overlap(0)      # every exchange first, then one launch over all planes
+blob = d.comm_peer_export()
+d.comm_peer_import(blob, blob)  # its own neighbour on both sides: the buffers' addresses as they are
+d.set_overlap(4)      # the matL ghost rows by hipMemcpyAsync on the copy stream, the next exchange as the arrival signal
+d.profile_enable(True)
 c.set_fused_rebin(0)  # ... and the first re-binning's scatter as a pass of its own (a and b leave it to the assembly)
 a.profile_enable(True); c.profile_enable(True)
 for t in range(3):
-    ia, ib, ic = a.step(), b.step(), c.step()
+    ia, ib, ic, id_ = a.step(), b.step(), c.step(), d.step()
     assert abs(ia - ib) <= 2, (ia, ib)
     assert abs(ia - ic) <= 1, (ia, ic)
+    assert abs(ia - id_) <= 1, (ia, id_)
+assert d.profile_get("peer_copies")[0] == 12
 # per step: the slab that defers runs the index pass (what the neighbours sent stays in the receive buffer and is gathered
 # from there) and ONE scatter (the second re-binning), the other one two scatters
 assert a.profile_get("index")[0] == 3 and a.profile_get("scatter")[0] == 3, (a.profile_get("index"), a.profile_get("scatter"))
@@ -121,7 +137,8 @@ for f in (X.E, X.B):
     # interior rows beside the posted exchange + boundary rows behind it == all rows behind the exchange (the same
     # arithmetic per row; what differs between two runs is the order of the Esirkepov deposit's fp64 atomics)
     assert np.abs(fa - fc).max() <= 1e-11 * np.abs(fc).max()
-assert a.count(0) == b.count(0)
+    assert np.abs(d.get_field(f) - fc).max() <= 1e-11 * np.abs(fc).max()
+assert a.count(0) == b.count(0) == d.count(0)
 assert np.allclose(a.energy(), b.energy(), rtol=1e-9)
 print("self-ring ok")
 ''' % ROOT
@@ -230,6 +247,9 @@ def test_eight_slabs_in_one_process(scheme, oracle):
         try:
             ctx = W.build(scheme, n, d, dt, r, nr, seed=42)
             ring.attach(ctx, r)
+            if scheme == "ecsimcorr":  # one of the two runs takes the copy-engine path for its matL ghost rows
+                ring.map_peers(ctx, r)
+                ctx.set_overlap(4)
             c0 = [ctx.count(s) for s in range(2)]
             its = [ctx.step() for _ in range(3)]
             occ = [np.bincount(ctx.particles(s)[1].astype(np.int64) + ctx.z0 * n[0] * n[1], minlength=n[0] * n[1] * n[2])

@@ -7,7 +7,7 @@ import sys
 L = open(sys.argv[1]).read().split("\n")
 frag = sys.argv[2]
 start = next(i for i, l in enumerate(L) if l.startswith("_Z") and frag in l and ":" in l.split(";")[0])
-end = next(i for i in range(start, len(L)) if "s_endpgm" in L[i])
+end = next(i for i in range(start, len(L)) if L[i].startswith(".Lfunc_end"))  # (not the first s_endpgm: early exits)
 cur, stats = 0, {}
 for l in L[start:end]:
     m = re.search(r"Loop Header: Depth=(\d+)", l) or re.search(r"in Loop: Header=\S+ Depth=(\d+)", l)

@@ -29,7 +29,7 @@ SYMBOLS = [
     "xpic_ecsimcorr_first_push", "xpic_ecsimcorr_second_push", "xpic_ecsimcorr_final_update",
     "xpic_calculate_energy", "xpic_ecsimcorr_scalars", "xpic_solve", "xpic_set_tolerances", "xpic_set_preconditioner", "xpic_set_overlap", "xpic_comm_stats", "xpic_set_fill_kernel", "xpic_set_fused_rebin", "xpic_get_fill_variant", "xpic_debug_set", "xpic_step",
     "xpic_energy", "xpic_momentum", "xpic_charge_density", "xpic_moment_density", "xpic_cell_traversal", "xpic_implicit_esirkepov_interpolate",
-    "xpic_implicit_esirkepov_decompose", "xpic_charge_collect", "xpic_charge_columns", "xpic_comm_rccl_unique_id", "xpic_comm_init_rccl", "xpic_comm_init_callbacks", "xpic_comm_size",
+    "xpic_implicit_esirkepov_decompose", "xpic_charge_collect", "xpic_charge_columns", "xpic_comm_rccl_unique_id", "xpic_comm_init_rccl", "xpic_comm_init_callbacks", "xpic_comm_size", "xpic_comm_peer_export", "xpic_comm_peer_import",
     "xpic_profile_enable", "xpic_profile_reset", "xpic_profile_get", "xpic_probe_copy_bandwidth",
 ]
 
@@ -58,6 +58,7 @@ class Geometry(C.Structure):
 
 
 DEBUG_GATHER_WINDOW, DEBUG_PENCIL_LIMIT = 0, 1  # include/xpic_hip.h: xpic_debug_set
+PEER_BLOB_BYTES = 256  # include/xpic_hip.h: XPIC_PEER_BLOB_BYTES
 VERSION_EXPERIMENT_BIT = 0x40000000  # include/xpic_hip.h: XPIC_VERSION_EXPERIMENT_BIT
 
 
@@ -162,6 +163,17 @@ class Context:
 
         self._cb = CB(None, SR(_sr), AR(_ar))
         self._ck(self.L.xpic_comm_init_callbacks(self.h, C.byref(self._cb)))
+
+    def comm_peer_export(self):
+        """the blob (bytes) that tells a z-neighbour where this rank receives its matL ghost rows (copy-engine path)"""
+        buf = (C.c_char * PEER_BLOB_BYTES)()
+        self._ck(self.L.xpic_comm_peer_export(self.h, buf))
+        return bytes(buf)
+
+    def comm_peer_import(self, lower_blob, upper_blob):
+        lo = (C.c_char * PEER_BLOB_BYTES).from_buffer_copy(bytes(lower_blob))
+        up = (C.c_char * PEER_BLOB_BYTES).from_buffer_copy(bytes(upper_blob))
+        self._ck(self.L.xpic_comm_peer_import(self.h, lo, up))
 
     def comm_size(self):
         n = C.c_int()

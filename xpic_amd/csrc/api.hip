@@ -771,6 +771,7 @@ int xpic_set_overlap(xpic_ctx* ctx, int on)
   CTX_CHECK(ctx);
   ctx->overlap = (on & 1) != 0;
   ctx->overlap_lrows = (on & 2) != 0;
+  ctx->peer_copy = (on & 4) != 0; // takes effect once xpic_comm_peer_import has mapped the neighbours' buffers
   ctx->overlap_explicit = true;
   return 0;
 }

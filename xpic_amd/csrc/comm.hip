@@ -10,6 +10,8 @@
 
 #include <cstdlib>
 
+#include <unistd.h>
+
 #include "common.h"
 
 namespace xpic {
@@ -41,6 +43,8 @@ int comm_ring(xpic_ctx* c, const void* down, size_t ndown, const void* up, size_
 {
   Comm& m = c->comm;
   XPIC_CHECK(m.kind != 0, "comm_ring called on a single-rank context");
+  XPIC_CALL(peer_order(c));
+  c->peer_exchanges += 1;
   m.sent_msgs += (ndown ? 1 : 0) + (nup ? 1 : 0);
   m.sent_bytes += (int64_t)(ndown + nup);
   const int lo = (m.rank - 1 + m.nranks) % m.nranks, hi = (m.rank + 1) % m.nranks;
@@ -76,6 +80,7 @@ int comm_allreduce_sum(xpic_ctx* c, double* dbuf, int n)
   // every reduction that is an MPI_Allreduce on slabs is counted (on a single slab too): xpic_profile_get("allreduce")
   if (c->profiling) c->prof["allreduce"].launches += 1;
   if (m.kind == 0 || n == 0) return 0;
+  XPIC_CALL(peer_order(c));
   m.allreduces += 1;
   m.allreduce_bytes += (int64_t)sizeof(double) * n;
   if (m.kind == 1) {
@@ -120,8 +125,28 @@ int comm_allreduce_max_host(xpic_ctx* c, double* v)
   return 0;
 }
 
+// Peer copies run on copy_stream; whatever this rank sends next -- the message that tells a neighbour its ghost rows have
+// landed -- is issued on the compute (or communication) stream: make that stream wait for the copies first.
+int peer_order(xpic_ctx* c)
+{
+  if (!c->peer_pending) return 0;
+  c->peer_pending = false;
+  XPIC_HIP(hipStreamWaitEvent(c->stream, c->copy_ev[1], 0));
+  return 0;
+}
+
 void comm_free(xpic_ctx* c)
 {
+  if (c->copy_stream) {
+    (void)hipStreamSynchronize(c->copy_stream);
+    for (int i = 0; i < 2; ++i) (void)hipEventDestroy(c->copy_ev[i]);
+    (void)hipStreamDestroy(c->copy_stream);
+    c->copy_stream = nullptr;
+  }
+  for (int i = 0; i < 2; ++i) {
+    if (c->peer_mapped[i]) (void)hipIpcCloseMemHandle(c->peer_mapped[i]);
+    c->peer_mapped[i] = nullptr; c->peer_lrow[i] = nullptr;
+  }
   if (c->comm_stream) {
     (void)hipStreamSynchronize(c->comm_stream);
     for (int i = 0; i < 2; ++i) (void)hipEventDestroy(c->comm_ev[i]);
@@ -179,6 +204,69 @@ int xpic_comm_init_rccl(xpic_ctx* ctx, const void* id128)
   if (ctx->geom.nranks > 1 && !ctx->overlap_explicit) {
     const char* e = getenv("XPIC_RCCL_OVERLAP");
     ctx->overlap = e && e[0] == '1';
+  }
+  return 0;
+}
+
+// ---- copy-engine path: the neighbours' receive buffers, mapped ------------------------------------------------------
+namespace {
+struct PeerBlob { // what a rank publishes (fits XPIC_PEER_BLOB_BYTES)
+  uint64_t magic;
+  int64_t pid;
+  int32_t device, valid;
+  uint64_t raw[2];   // the buffers' addresses in the exporting process (peers inside that process use them as they are)
+  uint64_t bytes;
+  hipIpcMemHandle_t h[2];
+};
+static_assert(sizeof(PeerBlob) <= XPIC_PEER_BLOB_BYTES, "peer blob");
+constexpr uint64_t kPeerMagic = 0x7870696370656572ull; // "xpicpeer"
+}  // namespace
+
+int xpic_comm_peer_export(xpic_ctx* ctx, void* blob)
+{
+  XPIC_CHECK(ctx && blob, "null argument");
+  XPIC_CHECK(ctx->g.G > 0 && ctx->lrow_buf[0] && ctx->lrow_buf[1], "no ghost-row buffers: a single slab, or a scheme without matL");
+  PeerBlob b{};
+  b.magic = kPeerMagic;
+  b.pid = (int64_t)getpid();
+  b.device = ctx->geom.device;
+  b.bytes = sizeof(double) * 3 * (uint64_t)ctx->g.lplane();
+  b.valid = 1;
+  for (int i = 0; i < 2; ++i) {
+    b.raw[i] = (uint64_t)(uintptr_t)ctx->lrow_buf[i];
+    if (hipIpcGetMemHandle(&b.h[i], ctx->lrow_buf[i]) != hipSuccess) { (void)hipGetLastError(); b.valid = 2; } // same-process peers only
+  }
+  memcpy(blob, &b, sizeof(b));
+  return 0;
+}
+
+int xpic_comm_peer_import(xpic_ctx* ctx, const void* lower_blob, const void* upper_blob)
+{
+  XPIC_CHECK(ctx && lower_blob && upper_blob, "null argument");
+  XPIC_CHECK(ctx->g.G > 0 && ctx->lrow_buf[0], "no ghost-row buffers: a single slab, or a scheme without matL");
+  XPIC_CHECK(!ctx->peer_lrow[0] && !ctx->peer_lrow[1], "peer buffers imported twice");
+  XPIC_HIP(hipSetDevice(ctx->geom.device));
+  const void* blobs[2] = {lower_blob, upper_blob};
+  for (int side = 0; side < 2; ++side) {
+    PeerBlob b;
+    memcpy(&b, blobs[side], sizeof(b));
+    XPIC_CHECK(b.magic == kPeerMagic && b.valid != 0, "not a peer blob of xpic_comm_peer_export");
+    XPIC_CHECK(b.bytes == sizeof(double) * 3 * (uint64_t)ctx->g.lplane(), "the neighbour's ghost-row buffer has another size (another grid?)");
+    // my "down" message lands in the lower neighbour's from-above buffer (its lrow_buf[0]), my "up" message in the upper
+    // neighbour's from-below buffer (its lrow_buf[1]): two different allocations even when both neighbours are one process
+    const int which = side;
+    if (b.pid == (int64_t)getpid()) ctx->peer_lrow[side] = (double*)(uintptr_t)b.raw[which]; // threads of one process, a self-ring
+    else {
+      XPIC_CHECK(b.valid == 1, "the neighbour could not export an IPC handle of its ghost-row buffer");
+      void* p = nullptr;
+      XPIC_HIP(hipIpcOpenMemHandle(&p, b.h[which], hipIpcMemLazyEnablePeerAccess));
+      ctx->peer_mapped[side] = p;
+      ctx->peer_lrow[side] = (double*)p;
+    }
+  }
+  if (!ctx->copy_stream) {
+    XPIC_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) XPIC_HIP(hipEventCreateWithFlags(&ctx->copy_ev[i], hipEventDisableTiming));
   }
   return 0;
 }

@@ -19,7 +19,7 @@
 #if !defined(XPIC_EXPERIMENT) && (defined(FILL_EXP) || defined(FILL_STAMPS) || defined(FILL_GA_EXP) || defined(FILL_GA_NOCHAIN) || \
   defined(FILL_KCP) || defined(FILL_OCC) || defined(FILL_PITCH) || defined(FILL_WPITCH) || defined(FILL_WS_KCP) || \
   defined(FILL_WS_PRIO_C) || defined(FILL_WS_PRIO_P) || defined(FILL_WS_PRIO_F) || defined(ESK_EXP) || defined(ESK_STAMPS) || \
-  defined(ESK_BOX_GENERIC) || defined(ESK_PIPE) || defined(ESK_LANES) || defined(ESK_COLS1) || defined(ESK_SEG0) || defined(ESK_OCC1) || \
+  defined(ESK_FLUSH) || defined(ESK_BOX_GENERIC) || defined(ESK_PIPE) || defined(ESK_LANES) || defined(ESK_COLS1) || defined(ESK_SEG0) || defined(ESK_OCC1) || \
   defined(ESK_DRAIN0) || defined(ESK_TILE_LATE) || defined(XPIC_CHEB_MIN_ZC) || defined(BAR_SCHED_SCALED) || defined(BAR_SCHED_GROUP) || \
   defined(XPIC_MAX_PER_Z) || defined(XPIC_SLAB_FIRST_TOUCH) || defined(XPIC_CHEB_M_BOUND) || defined(XPIC_BUCKET_CAP) || \
   defined(XPIC_DEFAULT_FUSED_REBIN) || defined(XPIC_DEFAULT_PRECOND) || defined(XPIC_DEFAULT_FILL_KERNEL))
@@ -243,6 +243,18 @@ struct xpic_ctx {
   double* halo_buf[4] = {}; // send down, send up, recv from up, recv from down
   double* lrow_buf[2] = {nullptr, nullptr}; // matL ghost rows received from the upper / lower neighbour (3 row planes each; slabs)
   bool lrow_posted = false, lrow_on_comm_stream = false;
+  // Copy-engine path of the large messages (comm.hip: xpic_comm_peer_import): the neighbours' receive buffers mapped into this
+  // process (peer_lrow[0]: the lower neighbour's "from above" buffer, [1]: the upper neighbour's "from below" buffer); the
+  // ghost rows then travel as hipMemcpyAsync on copy_stream -- SDMA engines between two GPUs, no workgroup slot taken from
+  // the assembly -- and the NEXT ring exchange with the neighbour is what tells it that they have arrived.
+  double* peer_lrow[2] = {nullptr, nullptr};
+  void* peer_mapped[2] = {nullptr, nullptr}; // what hipIpcOpenMemHandle returned (closed with the context); null for same-process peers
+  bool peer_copy = false;          // xpic_set_overlap bit 2
+  bool lrow_by_copy = false;       // this step's ghost rows went by copy
+  bool peer_pending = false;       // copies issued on copy_stream that no exchange has been ordered behind yet
+  int peer_exchanges = 0;          // ring exchanges since the post (the arrival signal)
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t copy_ev[2] = {nullptr, nullptr};
   size_t halo_bytes = 0;
   // overlapped operator applies (fields.hip: op_apply_overlapped): RCCL traffic of a posted halo runs on its own stream
   hipStream_t comm_stream = nullptr;
@@ -350,6 +362,7 @@ int comm_allreduce_sum_host(xpic_ctx* c, double* hbuf, int n);
 int comm_allreduce_max_host(xpic_ctx* c, double* v); // one non-negative value
 void comm_free(xpic_ctx* c);
 int ensure_halo_buf(xpic_ctx* c, size_t bytes);
+int peer_order(xpic_ctx* c); // an exchange is about to be issued: order it behind the peer copies still in flight
 
 // krylov.hip
 int solve(xpic_ctx* c, int op, const double* rhs, double* x, double rtol, double atol, int maxit, int* its,

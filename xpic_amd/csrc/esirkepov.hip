@@ -84,12 +84,16 @@ constexpr int kSeg = 8;               // cells (segments) per round
 #ifndef ESK_PIPE
 #define ESK_PIPE 6 // bit MODE: phase 2 requests the operands of the next K step before this step's products (MODE 1, 2: -2 %; MODE 0 spills with it)
 #endif
+#ifndef ESK_FLUSH
+#define ESK_FLUSH 1 // the J window's finished nodes leave 1: in aligned groups of 8 (one 64-byte atomic request per row), 0: as each round completes them
+#endif
 #ifndef ESK_BOX_GENERIC
 #define ESK_BOX_GENERIC 0 // 1: the staged box values by four calls of the generic spline per axis and position (round 2)
 #endif
 template <int MODE> struct StageDim {
   static constexpr int kSegM = MODE == 0 ? ESK_SEG0 : 8; // cells (segments) per round
-  static constexpr int kCols = MODE == 1 ? ESK_COLS1 : 240;
+  // (MODE 2: 232, not 240: the 2.3 KB pay for the J window's pending columns -- its LDS is full, see kJX)
+  static constexpr int kCols = MODE == 1 ? ESK_COLS1 : (MODE == 2 && ESK_FLUSH ? 232 : 240);
   static constexpr int kPitch = kCols + 4; // row pitch: 4 rows x 4 columns of a phase-2 read fall in 16 distinct bank pairs (pitch = 4 mod 8)
   static_assert(kCols % 4 == 0 && kCols <= kThreadsB && kPitch % 8 == 4, "stage geometry");
 };
@@ -259,7 +263,10 @@ __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkep
   // fills half of the 256 lanes (the instruction stream of a round costs the same); the names below shadow the
   // namespace-scope values that MODE 1 and 2 keep.
   constexpr int kSeg = StageDim<MODE>::kSegM;
-  constexpr int kJX = kSeg + kD - 1, kJN = kJX * kD * kD, kJPer = (3 * kJN + kThreadsB - 1) / kThreadsB;
+  // J window: the kSeg + kD - 1 nodes a round's boxes reach + up to kJG - 1 finished nodes that wait for their aligned group
+  // of kJG to be complete (the flush at the end of a round)
+  // (MODE 1 runs three workgroups per CU and has 832 bytes of LDS to spare for it: groups of 4 there -- half a request)
+  constexpr int kJGs = ESK_FLUSH ? (MODE == 1 ? 2 : 3) : 0, kJG = 1 << kJGs, kJX = kSeg + kD - 1 + kJG - 1, kJN = kJX * kD * kD;
   constexpr int kTX = kSeg + kT - 1, kTileN = kTX * kT * kT, kFtPer = (6 * kTileN + kThreadsB - 1) / kThreadsB;
   static_assert(kSeg <= kCellStartPad && kSeg <= kSegMax, "compose reads kSeg entries ahead");
   static_assert(MODE != 0 || 6 * kTileN <= kSRows * kPitch, "the gather tile shares the stage's LDS");
@@ -467,6 +474,7 @@ __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkep
 
   double pw = 0.0;
   int bad = 0;
+  int jflushed = -kJG; // J window: nodes below this one have left (a multiple of kJG; the window starts at node -1)
   const double dt = g.dt;
 
   // the line of this lane: component c along its own axis; transverse axes (A, B) with the reference's roles
@@ -930,12 +938,22 @@ __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkep
 #endif
     // (every wave is past its last read of this round's table: the barrier above)
     if constexpr (PRE) tab_put(tab[rd & 1], tw);
-    // ---- the next round starts at cell base + adv: the window's nodes base - 1 .. base + adv - 2 are final and leave
-    // with one fp64 atomic per node (other pencils add to the same nodes); their columns, zeroed, become the nodes
-    // kJX further on (the window is circular, nothing moves).  The last round flushes everything (its tail wraps
-    // periodically onto nodes 0, 1, ...).  The next merges are two barriers away.
+    // ---- the next round starts at cell base + adv: the window's nodes below base + adv - 1 are final.  They leave in
+    // ALIGNED GROUPS of kJG = 8 nodes (4 in MODE 1), one fp64 atomic per node (other pencils add to the same nodes): float atomics execute
+    // at the memory side as 64-byte requests (MI355X_MICROARCH.md, "Global float atomics"), so a row's 8 aligned nodes are
+    // ONE request where the `adv` (about 7) nodes a round completes, flushed as they came, straddled two 64-byte segments most of
+    // the time -- the J atomics wrote 65 times the field per launch (profiles/r04_pmc_traffic_ecsimcorr_128.txt).  A
+    // group's entry is (row = e >> 3, node = e & 7): shifts, where the walk over the whole window (every round, flushed or
+    // not) cost three integer divisions per entry and three iterations per thread.  Finished nodes wait in the window for
+    // their group (kJX has the room); the flushed columns, zeroed, become the nodes kJX further on (the window is circular,
+    // nothing moves).  The last round flushes everything (its tail wraps periodically onto nodes 0, 1).  The next merges
+    // are two barriers away.
     {
       const bool last = base + adv >= g.nx;
+      const int fin = last ? g.nx + kD - 2 : base + adv - 1; // nodes below `fin` are final (the last round: all of them)
+#if !ESK_FLUSH
+      (void)fin;
+      constexpr int kJPer = (3 * kJN + kThreadsB - 1) / kThreadsB;
       const int b11 = base % kJX;
 #pragma unroll
       for (int k = 0; k < kJPer; ++k) {
@@ -948,14 +966,34 @@ __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkep
           if (j < adv || last) {
             const double val = jtile[t];
             if (val != 0.0) {
-#if ESK_EXP != 1 // (experiment builds: 1 drops the J atomics, 2 the particle stores -- what each costs, results garbage)
               unsafeAtomicAdd(&J[c * g.cstride + g.nodew(base - 1 + j, cy - 1 + ty, cz - 1 + tz)], val);
-#endif
               jtile[t] = 0.0;
             }
           }
         }
       }
+#else
+      while (jflushed + (last ? 1 : kJG) <= fin) {
+#pragma unroll
+        for (int k = 0; k < (kLinesB * kJG + kThreadsB - 1) / kThreadsB; ++k) {
+          const int e = threadIdx.x + k * kThreadsB;
+          const int row = e >> kJGs, x = jflushed + (e & (kJG - 1)); // row = (c, tz, ty): the window's own row order
+          if (row < kLinesB && x >= -1 && x < fin) {
+            const int c = row >> 4, tz = (row >> 2) & 3, ty = row & 3;
+            int wc = (x + 1) % kJX; // (x + 1 >= 0)
+            double* const w = &jtile[c * kJN + (tz * kD + ty) * kJX + wc];
+            const double val = *w;
+            if (val != 0.0) {
+#if ESK_EXP != 1 // (experiment builds: 1 drops the J atomics, 2 the particle stores -- what each costs, results garbage)
+              unsafeAtomicAdd(&J[c * g.cstride + g.nodew(x, cy - 1 + ty, cz - 1 + tz)], val);
+#endif
+              *w = 0.0;
+            }
+          }
+        }
+        jflushed += kJG;
+      }
+#endif
     }
   }
 

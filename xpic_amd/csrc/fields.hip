@@ -1029,6 +1029,30 @@ int matL_ghost_rows_post(xpic_ctx* c)
   // a colour launch is sized to fill every workgroup slot of the chip exactly once, so each slot an RCCL workgroup holds
   // sends one assembly workgroup into a second round, which doubles the launch.  The blocking exchange costs its own
   // duration and nothing else.
+  // Copy-engine form (xpic_set_overlap bit 2, after xpic_comm_peer_import): the rows are written straight into the
+  // neighbours' receive buffers by hipMemcpyAsync on the copy stream -- between two GPUs that is an SDMA engine, which
+  // takes no workgroup slot from the colour launches still to come (the reason the RCCL form beside the assembly lost).
+  // No message of its own tells the neighbour that the rows are there: this rank's NEXT ring exchange is issued behind the
+  // copies (comm.hip: peer_order), the neighbour's matching receive completes after it, and matL_ghost_rows_finish makes
+  // sure one such exchange lies between post and finish.  The receiver's buffer is free again by then: its finish of the
+  // step before was enqueued ahead of every message it has sent since.
+  if (c->peer_copy && c->peer_lrow[0] && c->peer_lrow[1] && c->copy_stream) {
+    XPIC_HIP(hipEventRecord(c->copy_ev[0], c->stream));
+    XPIC_HIP(hipStreamWaitEvent(c->copy_stream, c->copy_ev[0], 0));
+    for (int c1 = 0; c1 < 3; ++c1) {
+      double* base = c->matL + (long)c1 * nzp * per;
+      if (c1 == 2) XPIC_HIP(hipMemcpyAsync(c->peer_lrow[0] + (long)c1 * per, base, bytes, hipMemcpyDefault, c->copy_stream));
+      XPIC_HIP(hipMemcpyAsync(c->peer_lrow[1] + (long)c1 * per, base + (long)(nzp - 1) * per, bytes, hipMemcpyDefault, c->copy_stream));
+    }
+    XPIC_HIP(hipEventRecord(c->copy_ev[1], c->copy_stream));
+    c->comm.sent_msgs += 4; c->comm.sent_bytes += (int64_t)(4 * bytes);
+    if (c->profiling) c->prof["peer_copies"].launches += 4;
+    c->peer_pending = true;
+    c->peer_exchanges = 0;
+    c->lrow_posted = true; c->lrow_by_copy = true; c->lrow_on_comm_stream = false;
+    return 0;
+  }
+  c->lrow_by_copy = false;
   const bool side = c->overlap_lrows && c->comm.kind == 1 && c->comm_stream;
   hipStream_t compute = c->stream;
   if (side) {
@@ -1060,6 +1084,13 @@ int matL_ghost_rows_finish(xpic_ctx* c)
   if (!c->lrow_posted) XPIC_CALL(matL_ghost_rows_post(c));
   Timed t(c, "matL_ghost_rows");
   if (c->lrow_on_comm_stream) XPIC_HIP(hipStreamWaitEvent(c->stream, c->comm_ev[1], 0));
+  if (c->lrow_by_copy && c->peer_exchanges == 0) {
+    // the neighbours' rows came by copy and nothing has been exchanged since they were posted (no current to add back):
+    // a one-word exchange is the arrival signal
+    double* w = c->red_out + 124;
+    XPIC_CALL(comm_ring(c, w, sizeof(double), w + 1, sizeof(double), w + 2, sizeof(double), w + 3, sizeof(double)));
+  }
+  c->lrow_by_copy = false;
   c->lrow_posted = false;
   const long per = g.lplane();
   const int nzp = g.nzl + 2;

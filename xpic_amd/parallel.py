@@ -42,6 +42,18 @@ def init_rccl(ctx, device=None):
     ctx.comm_init_rccl(bytes(t.cpu().numpy().tobytes()))
 
 
+def map_peers(ctx):
+    """Copy-engine path of the large messages (xpic_comm_peer_export / _import): every rank publishes the blob of its
+    receive buffers over torch.distributed -- the bootstrap channel, like the ncclUniqueId -- and maps its two z-neighbours'."""
+    import torch.distributed as dist
+
+    n, rank = dist.get_world_size(), dist.get_rank()
+    blobs = [None] * n
+    dist.all_gather_object(blobs, ctx.comm_peer_export())
+    lo, hi = neighbours(rank, n)
+    ctx.comm_peer_import(blobs[lo], blobs[hi])
+
+
 class GlooRing:
     """Ring exchange with the semantics xpic_comm_callbacks asks for, over torch.distributed point-to-point ops.
     Messages to the same peer (2 ranks: both neighbours are one process) are told apart by tag: 0 = sent downwards,
@@ -102,6 +114,14 @@ class ThreadRing:
         self.down = [b""] * n
         self.up = [b""] * n
         self.red = [None] * n
+        self.blobs = [None] * n
+
+    def map_peers(self, ctx, rank):
+        """xpic_comm_peer_export / _import between the threads of this process (the buffers' own addresses are used)"""
+        self.blobs[rank] = ctx.comm_peer_export()
+        self.bar.wait()
+        ctx.comm_peer_import(self.blobs[(rank - 1 + self.n) % self.n], self.blobs[(rank + 1) % self.n])
+        self.bar.wait()
 
     def attach(self, ctx, rank):
         n = self.n
