@@ -245,6 +245,9 @@ def test_esirkepov_rounds_ragged_pencils(oracle, scheme, table):
         for ph in (("basic_push",) if scheme == "basic" else ("corr_first_push", "corr_second_push")):
             # (later steps: the blob has spread along its pencil and may fit)
             assert g.profile_get(ph)[0] in ((1,) if table == "precomposed" else ((2,) if t == 0 else (1, 2))), (t, ph)
+        # ... and the pushes that composed their rounds themselves are counted for the caller to see
+        nself = g.profile_get("esk_self_composed")[0]
+        assert nself == 0 if table == "precomposed" else nself >= (1 if scheme == "basic" else 2) * (1 if t == 0 else 0), (t, nself)
         same_fields(o, g, ["E", "B"], 1e-7)
     po, co = canon(*o.particles(0))
     pg, cg = canon(*g.particles(0))

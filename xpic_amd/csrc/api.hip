@@ -163,11 +163,12 @@ static int ecsim_fill_current(xpic_ctx* c)
   return ecsim_fill_check(c);
 }
 
-// ecsim::Simulation::final_update (src/impls/ecsim/simulation.cpp:241-253)
+// ecsim::Simulation::final_update (src/impls/ecsim/simulation.cpp:241-253).  Ep's ghost planes are valid at both call
+// sites (filled in front of the second push, resp. in front of `currI += matL Ec` whose operand becomes Ep by the swap;
+// nothing has written Ep since): no exchange here.
 static int ecsim_final_update(xpic_ctx* c)
 {
   XPIC_CALL(vec_axpby(c, c->field[XPIC_E], 2.0, -1.0, c->field[XPIC_EP]));          // E = 2 Ep - E
-  XPIC_CALL(halo_fill(c, c->field[XPIC_EP]));
   XPIC_CALL(rot_apply(c, +1, -c->g.dt, c->field[XPIC_EP], c->field[XPIC_B], true)); // B -= dt rot(+) Ep
   return 0;
 }
@@ -179,8 +180,7 @@ static int step_ecsim(xpic_ctx* c, int* its)
   for (auto& s : c->sorts) XPIC_CALL(sort_rebin(c, s, c->g.dt, true, c->fused_rebin != 0));
   XPIC_CALL(ecsim_fill_current(c));
   XPIC_CALL(advance_fields(c, XPIC_OP_MATA_GMRES, c->field[XPIC_CURRI], c->field[XPIC_EP], its)); // :191-210
-  XPIC_CALL(halo_fill(c, c->field[XPIC_EP]));
-  XPIC_CALL(halo_fill(c, c->field[XPIC_B]));
+  XPIC_CALL(halo_fill2(c, c->field[XPIC_EP], c->field[XPIC_B]));
   // second_push :212-239.  Positions did not change since the re-bin of first_push and are already wrapped,
   // so correct_coordinates() + update_cells() of :227,:233 are the identity here.
   // the next step starts with sort_rebin(dt) of exactly this state: bin it in the same pass (Sort::prebinned)
@@ -262,8 +262,7 @@ static int step_ecsimcorr(xpic_ctx* c, int* its)
   int its0 = 0, its1 = 0;
   XPIC_CALL(advance_fields(c, XPIC_OP_MATA_GMRES, c->field[XPIC_CURRI], Ep, &its0)); // KSP "predict"
   // second_push (ecsim/simulation.cpp:212-239 with the ecsimcorr particles)
-  XPIC_CALL(halo_fill(c, Ep));
-  XPIC_CALL(halo_fill(c, B));
+  XPIC_CALL(halo_fill2(c, Ep, B));
   for (auto& s : c->sorts) {
     XPIC_CALL(esirkepov_push(c, s, 2, Ep, B, s.currJe, &s.pred_w));
     XPIC_CALL(halo_add(c, s.currJe, 3));                          // DMLocalToGlobal(ADD) particles.cpp:88

@@ -318,6 +318,7 @@ int field_import(xpic_ctx* c, double* dst_soa, const double* src_aos_host);
 int field_export(xpic_ctx* c, const double* src_soa, double* dst_aos_host);
 int field_stats_host(xpic_ctx* c, const double* f, double* sumsq, double* mean3);
 int halo_fill(xpic_ctx* c, double* f, int width = 3); // ghost planes <- neighbours' owned planes (no-op when G == 0)
+int halo_fill2(xpic_ctx* c, double* f0, double* f1, int width = 3); // two vectors, one message per neighbour
 int halo_add(xpic_ctx* c, double* f, int width);      // owned planes += neighbours' ghost planes (DMLocalToGlobal ADD)
 int matL_exchange_ghost_rows(xpic_ctx* c);  // blocking: post + finish
 int matL_ghost_rows_post(xpic_ctx* c);      // ship this slab's two ghost row planes (on the communication stream when overlapping)

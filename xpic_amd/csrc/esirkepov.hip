@@ -92,8 +92,7 @@ constexpr int kSeg = 8;               // cells (segments) per round
 #endif
 template <int MODE> struct StageDim {
   static constexpr int kSegM = MODE == 0 ? ESK_SEG0 : 8; // cells (segments) per round
-  // (MODE 2: 232, not 240: the 2.3 KB pay for the J window's pending columns -- its LDS is full, see kJX)
-  static constexpr int kCols = MODE == 1 ? ESK_COLS1 : (MODE == 2 && ESK_FLUSH ? 232 : 240);
+  static constexpr int kCols = MODE == 1 ? ESK_COLS1 : 240;
   static constexpr int kPitch = kCols + 4; // row pitch: 4 rows x 4 columns of a phase-2 read fall in 16 distinct bank pairs (pitch = 4 mod 8)
   static_assert(kCols % 4 == 0 && kCols <= kThreadsB && kPitch % 8 == 4, "stage geometry");
 };
@@ -265,8 +264,9 @@ __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkep
   constexpr int kSeg = StageDim<MODE>::kSegM;
   // J window: the kSeg + kD - 1 nodes a round's boxes reach + up to kJG - 1 finished nodes that wait for their aligned group
   // of kJG to be complete (the flush at the end of a round)
-  // (MODE 1 runs three workgroups per CU and has 832 bytes of LDS to spare for it: groups of 4 there -- half a request)
-  constexpr int kJGs = ESK_FLUSH ? (MODE == 1 ? 2 : 3) : 0, kJG = 1 << kJGs, kJX = kSeg + kD - 1 + kJG - 1, kJN = kJX * kD * kD;
+  // (MODE 1 runs three workgroups per CU and has 832 bytes of LDS to spare for the pending columns, MODE 2 1 160: groups of
+  // 4 there; a stage of 232 instead of 240 columns to make room for groups of 8 cost MODE 2 more than they gave)
+  constexpr int kJGs = ESK_FLUSH ? (MODE == 0 ? 3 : 2) : 0, kJG = 1 << kJGs, kJX = kSeg + kD - 1 + kJG - 1, kJN = kJX * kD * kD;
   constexpr int kTX = kSeg + kT - 1, kTileN = kTX * kT * kT, kFtPer = (6 * kTileN + kThreadsB - 1) / kThreadsB;
   static_assert(kSeg <= kCellStartPad && kSeg <= kSegMax, "compose reads kSeg entries ahead");
   static_assert(MODE != 0 || 6 * kTileN <= kSRows * kPitch, "the gather tile shares the stage's LDS");
@@ -939,7 +939,7 @@ __global__ void __launch_bounds__(kThreadsB, MODE == 1 ? ESK_OCC1 : 2) k_esirkep
     // (every wave is past its last read of this round's table: the barrier above)
     if constexpr (PRE) tab_put(tab[rd & 1], tw);
     // ---- the next round starts at cell base + adv: the window's nodes below base + adv - 1 are final.  They leave in
-    // ALIGNED GROUPS of kJG = 8 nodes (4 in MODE 1), one fp64 atomic per node (other pencils add to the same nodes): float atomics execute
+    // ALIGNED GROUPS of kJG = 8 nodes (4 in MODE 1 and 2), one fp64 atomic per node (other pencils add to the same nodes): float atomics execute
     // at the memory side as 64-byte requests (MI355X_MICROARCH.md, "Global float atomics"), so a row's 8 aligned nodes are
     // ONE request where the `adv` (about 7) nodes a round completes, flushed as they came, straddled two 64-byte segments most of
     // the time -- the J atomics wrote 65 times the field per launch (profiles/r04_pmc_traffic_ecsimcorr_128.txt).  A
@@ -1121,6 +1121,9 @@ int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double
       hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, c->stream, c->kry_w, nblocks, scal);
     }
   };
+  // (a push that composes its rounds itself -- no room for the table, or a pencil with more rounds than it holds -- is slower
+  // by 6 %: counted, so that the caller can see it: xpic_profile_get("esk_self_composed"))
+  if (!pre && c->profiling) c->prof["esk_self_composed"].launches += 1;
   launch(pre);
   XPIC_HIP(hipGetLastError());
   XPIC_HIP(hipMemcpyAsync(c->red_host, scal, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
@@ -1132,6 +1135,7 @@ int esirkepov_push(xpic_ctx* c, Sort& s, int mode, const double* E, const double
     if (fl[1] != 0) {
       if (ga) { XPIC_CALL(sort_materialize(c, s)); ga = false; } // (the gathering push returned before touching anything)
       XPIC_HIP(hipMemsetAsync(scal, 0, sizeof(double) * 2, c->stream));
+      if (c->profiling) c->prof["esk_self_composed"].launches += 1;
       launch(false);
       XPIC_HIP(hipGetLastError());
       XPIC_HIP(hipMemcpyAsync(c->red_host, scal, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));

@@ -945,6 +945,30 @@ int halo_fill_t(xpic_ctx* c, T* f, int width)
 
 int halo_fill(xpic_ctx* c, double* f, int width) { return halo_fill_t<double>(c, f, width); }
 
+// DMGlobalToLocal of two vectors of one phase (E and B in front of a push) as ONE message per neighbour: a slab step is
+// bound by the number of its small exchanges, not by their bytes
+int halo_fill2(xpic_ctx* c, double* f0, double* f1, int width)
+{
+  const GridDev& g = c->g;
+  if (g.G == 0) return 0;
+  XPIC_CHECK(width <= g.G && width <= g.nzl, "halo width exceeds the ghost layer");
+  Timed t(c, "halo");
+  const long n = 3L * width * g.plane;
+  const size_t bytes = sizeof(double) * n;
+  XPIC_CALL(ensure_halo_buf(c, 2 * bytes));
+  const unsigned nb = plane_grid(n);
+  double* hb[4] = {c->halo_buf[0], c->halo_buf[1], c->halo_buf[2], c->halo_buf[3]};
+  double* fs[2] = {f0, f1};
+  for (int k = 0; k < 2; ++k)
+    hipLaunchKernelGGL((k_planes<0, double>), dim3(nb, 2), dim3(kBlock), 0, c->stream, g, fs[k], hb[0] + k * n, g.G, hb[1] + k * n, g.G + g.nzl - width, width);
+  XPIC_HIP(hipGetLastError());
+  XPIC_CALL(comm_ring(c, hb[0], 2 * bytes, hb[1], 2 * bytes, hb[2], 2 * bytes, hb[3], 2 * bytes));
+  for (int k = 0; k < 2; ++k)
+    hipLaunchKernelGGL((k_planes<1, double>), dim3(nb, 2), dim3(kBlock), 0, c->stream, g, fs[k], hb[2] + k * n, g.G + g.nzl, hb[3] + k * n, g.G - width, width);
+  XPIC_HIP(hipGetLastError());
+  return 0;
+}
+
 // Split form of halo_fill for the overlapped operator apply.  With RCCL the exchange and the unpack run on the
 // context's communication stream between two events; with the host-callback transport (tests) the exchange is
 // synchronous and halo_post simply completes it.

@@ -29,6 +29,11 @@ namespace xpic {
 namespace {
 
 constexpr int kB = 256;
+// The density ratios of the scaled surrogate are capped: the top of the polynomial's interval, and with it the degree, grows
+// with the largest ratio, and one dense clump (a blob of 160 times the mean density was measured) would otherwise either
+// push the surrogate through its Gershgorin check into the fall-back or make every solve pay a polynomial of degree 60 for
+// a few thousand rows.  Rows beyond the cap are under-preconditioned; the flexible GMRES around it takes them as outliers.
+static const double kRatioCap = getenv("XPIC_RCAP") ? atof(getenv("XPIC_RCAP")) : 1e30;
 constexpr double kAutoSpread = 0.2; // kind 5: relative spread of matL's diagonal above which the surrogate's rows are scaled
 #ifndef XPIC_CHEB_MIN_ZC
 #define XPIC_CHEB_MIN_ZC 8 // planes per z-chunk of k_cheb_bar at least (a chunk loads 5 more)
@@ -272,7 +277,7 @@ __global__ void k_abar(const double* __restrict__ sums, const double* __restrict
 // kind 4: r[c1][node] = matL[node][c1][diagonal] / Lbar[c1][diagonal] (1 where the average has no diagonal: vacuum), in the
 // layout of a fp32 field vector; the largest ratio goes to *rmax (as the bits of a positive float: integer max)
 __global__ void __launch_bounds__(256) k_rscale(GridDev g, const double* __restrict__ matL, const double* __restrict__ abar64,
-  const double* __restrict__ mco, float* __restrict__ rsc, unsigned* __restrict__ rmax)
+  const double* __restrict__ mco, float* __restrict__ rsc, unsigned* __restrict__ rmax, float rcap)
 {
   const int c1 = blockIdx.y;
   const int kd = lencode(c1, c1, 0, 0, 0);
@@ -282,7 +287,7 @@ __global__ void __launch_bounds__(256) k_rscale(GridDev g, const double* __restr
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < g.nown; i += (long)gridDim.x * 256) {
     const int x = (int)(i % g.nx), y = (int)((i / g.nx) % g.ny), z = (int)(i / g.plane);
     const double dg = matL[g.lindex(c1, z + (g.G ? 1 : 0), y, x, kd)];
-    const float r = lb > 0.0 ? (float)(dg * inv) : 1.f;
+    const float r = lb > 0.0 ? fminf((float)(dg * inv), rcap) : 1.f;
     rsc[c1 * g.cstride + (long)g.G * g.plane + i] = r;
     mx = fmaxf(mx, r);
   }
@@ -607,7 +612,7 @@ int abar_update(xpic_ctx* c)
   if (scaled) {
     XPIC_HIP(hipMemsetAsync(rmax_w, 0, sizeof(unsigned), c->stream));
     const unsigned nb = (unsigned)std::min<long>((g.nown + 255) / 256, 2048);
-    hipLaunchKernelGGL(k_rscale, dim3(nb, 3), dim3(256), 0, c->stream, g, c->matL, abar64, mco, c->abar_r, rmax_w);
+    hipLaunchKernelGGL(k_rscale, dim3(nb, 3), dim3(256), 0, c->stream, g, c->matL, abar64, mco, c->abar_r, rmax_w, (float)kRatioCap);
     XPIC_HIP(hipMemcpyAsync(bounds + 6, rmax_w, sizeof(unsigned), hipMemcpyDeviceToDevice, c->stream));
   }
   XPIC_HIP(hipGetLastError());
