@@ -528,8 +528,8 @@ def rank_body(args, rank, world, local_rank, job):
                                             "second_push", "mdot", "maxpy", "matL_zero", "scan", "index", "rot_apply",
                                             "halo", "migrate", "matL_ghost_rows", "basic_push", "corr_first_push", "precond_setup",
                                             "corr_second_push", "solve_matM", "precond", "matL_apply", "rebin",
-                                            "allreduce", "cheb_steps", "rebuild_keys", "fill_gather", "precond_fallback", "precond_scaled")}
-    COUNTERS = ("allreduce", "cheb_steps", "rebuild_keys", "fill_gather", "precond_fallback", "precond_scaled")
+                                            "allreduce", "cheb_steps", "rebuild_keys", "fill_gather", "precond_fallback", "precond_scaled", "precond_probation")}
+    COUNTERS = ("allreduce", "cheb_steps", "rebuild_keys", "fill_gather", "precond_fallback", "precond_scaled", "precond_probation")
     count_local = sum(ctx.count(s) for s in sorts)
     count = int(job.reduce(count_local, "sum"))
     assert count == world * npart, "particles were lost in a periodic box"
@@ -600,7 +600,8 @@ def rank_body(args, rank, world, local_rank, job):
                           key_rebuilds_per_step=prof["rebuild_keys"][0] / args.steps,
                           gathering_assemblies_per_step=prof["fill_gather"][0] / args.steps,
                           precond_fallbacks_per_step=prof["precond_fallback"][0] / args.steps,
-                          density_scaled_surrogates_per_step=prof["precond_scaled"][0] / args.steps),
+                          density_scaled_surrogates_per_step=prof["precond_scaled"][0] / args.steps,
+                          surrogates_on_probation_per_step=prof["precond_probation"][0] / args.steps),
         "allreduces_per_step": prof["allreduce"][0] / args.steps,  # reductions that are all-reduces on slabs (counted on 1 GPU too)
         "device_copy_GBps": copy_rate / 1e9 if copy_rate else None,
         # what ONE rank puts on its links per step (rank 0; every slab sends the same): point-to-point messages to the two

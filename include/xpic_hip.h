@@ -200,8 +200,9 @@ int xpic_set_tolerances(xpic_ctx* ctx, double rtol, double atol, int maxit);
  * has 0.1).  The GMRES around it is the flexible variant (x = x0 + sum y_j P v_j with the
  * P v_j stored): the result does not depend on how exactly P is applied, only the iteration count could.
  * degree <= 0 returns to the automatic choice.  The stopping rule of xpic_solve is unchanged (the residual of A x = b).
- * Kinds 3, 4 and 5 check their surrogate per solve (2 + the Gershgorin lower bound of <matL> must be positive) and otherwise runs
- * that solve with kind 1. */
+ * Kinds 3, 4 and 5 check their surrogate per solve: where 2 + the Gershgorin lower bound of <matL> (times the largest density
+ * ratio) is positive the polynomial's interval is proven; otherwise the surrogate runs on probation -- an iteration that does
+ * not halve the residual, or is not finite, ends it and the solve goes on with kind 1. */
 int xpic_set_preconditioner(xpic_ctx* ctx, int kind, int degree);
 /* The mass-matrix assembly (fill_ecsim_current) has two bodies: kind 0 (default) the classic 4-wave kernel (all grids);
  * kind 1 the warp-specialised kernel (one 16-wave workgroup per CU: a producer wave per SIMD runs the per-particle algebra,
@@ -229,6 +230,10 @@ int xpic_get_fill_variant(xpic_ctx* ctx, int* out3);
  * more scatters first instead of deferring (default and maximum 2^29, the reach of the sorted copy's 32-bit offsets). */
 #define XPIC_DEBUG_GATHER_WINDOW 0
 #define XPIC_DEBUG_PENCIL_LIMIT 1
+/* XPIC_DEBUG_SURROGATE_SCALE: the preconditioner's surrogate is built from `value` / 1000 times <matL> (1000 = as it is): a
+ * deliberately wrong surrogate, to see the probation of an unproven one end in the fall-back (results are unchanged: the
+ * stopping rule is the true residual). */
+#define XPIC_DEBUG_SURROGATE_SCALE 2
 int xpic_debug_set(xpic_ctx* ctx, int what, int64_t value);
 /* MatMult on a z-slab with neighbours: on = 1 posts the ghost exchange of the operand (VecScatterBegin), applies
  * the rows of the interior planes meanwhile and the rows of the boundary planes after it (VecScatterEnd), as PETSc's

@@ -57,7 +57,7 @@ class Geometry(C.Structure):
                 ("rank", C.c_int32), ("nranks", C.c_int32), ("device", C.c_int32), ("self_ring", C.c_int32)]
 
 
-DEBUG_GATHER_WINDOW, DEBUG_PENCIL_LIMIT = 0, 1  # include/xpic_hip.h: xpic_debug_set
+DEBUG_GATHER_WINDOW, DEBUG_PENCIL_LIMIT, DEBUG_SURROGATE_SCALE = 0, 1, 2  # include/xpic_hip.h: xpic_debug_set
 PEER_BLOB_BYTES = 256  # include/xpic_hip.h: XPIC_PEER_BLOB_BYTES
 VERSION_EXPERIMENT_BIT = 0x40000000  # include/xpic_hip.h: XPIC_VERSION_EXPERIMENT_BIT
 

@@ -751,6 +751,9 @@ int xpic_debug_set(xpic_ctx* ctx, int what, int64_t value)
       XPIC_CHECK(value >= 1 && value <= (1 << 29), "pencil limit: 1 .. 2^29 particles");
       ctx->pencil_limit = (int)value;
       return 0;
+    case XPIC_DEBUG_SURROGATE_SCALE:
+      ctx->debug_surrogate_scale = (double)value / 1000.0;
+      return 0;
     default:
       XPIC_CHECK(false, "xpic_debug_set: unknown knob");
   }

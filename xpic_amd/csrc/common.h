@@ -231,6 +231,8 @@ struct xpic_ctx {
   double abar_lo = 0, abar_hi = 0; // spectral interval of Abar
   double abar_gershgorin = 0;      // 2 + Gershgorin lower bound of Lbar: kind 3 is used only while this is positive
   bool abar_valid = false;
+  bool abar_proven = false;        // its Gershgorin bound proves the polynomial's interval; otherwise the surrogate runs on probation
+  double debug_surrogate_scale = 1.0; // xpic_debug_set(XPIC_DEBUG_SURROGATE_SCALE): <matL> times this in the surrogate (tests)
   bool abar_scaled = false;        // this solve's surrogate has its rows scaled by the local density (kind 4; kind 5 where it pays)
   double* red_partial = nullptr; // reduction partials
   double* red_out = nullptr;     // device results (pinned mirror below)

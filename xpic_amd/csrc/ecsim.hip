@@ -54,8 +54,13 @@ extern "C" int xpic_debug_fill_stamps(double* out, int reset)
   }
   return 0;
 }
+// sub-section timers inside a section (they do not move the section chain's clock)
+#define SUB_BEGIN() const unsigned long long sub_t_ = __builtin_readcyclecounter()
+#define SUB_END(k) stamp_acc_[k] += __builtin_readcyclecounter() - sub_t_
 #else
 #define STAMP(k)
+#define SUB_BEGIN()
+#define SUB_END(k)
 #endif
 
 namespace xpic {
@@ -89,6 +94,10 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
 {
   const int cy = cy0 + (int)(blockIdx.x % ncy) * cystep;
   const int cz = cz0 + (int)(blockIdx.x / ncy) * czstep;
+#ifdef FILL_STAMPS
+  unsigned long long stamp_t_ = 0;
+  unsigned long long stamp_acc_[13] = {};
+#endif
 
   __shared__ __attribute__((aligned(16))) double sh[kW * kStage];
   __shared__ __attribute__((aligned(16))) double zslot[kPitch]; // the particle of weight zero that fills up a K = 4 step
@@ -208,6 +217,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
   // z-slabs: a negative source index -1 - i is record i of what the neighbours sent (SortDev::inc, {r, v} per record, moved
   // and wrapped by its sender); the returned mask names those lanes: settle() must not move them again.
   auto gather = [&](int srcidx, bool on, double (&rec)[6]) -> unsigned long long {
+    SUB_BEGIN();
     // 32-bit arithmetic modulo 2^32: gb and every source index lie in [0, 2^31), so an index below gb, and the negative
     // index of a received record, wrap to 2^31 or more -- not near.  The offset is made opaque: knowing its range the
     // compiler widened it and added it to each of the six bases with 64-bit vector arithmetic (7 instructions per gather)
@@ -238,6 +248,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
 #pragma unroll
       for (int a = 0; a < 6; ++a) rec[a] = (on && !near) ? far[a] : rec[a];
     }
+    SUB_END(11); // the gather's issue (addresses, six loads, the far branch)
     return incm;
   };
   // where slot i of cell cx finds its source index: the binning's bucket of the cell, or the index k_index built
@@ -270,6 +281,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
   // the whole thing the compiler merged the two versions of the record with 22 register moves per pass, and the `||` of the
   // six range tests became five nested branches.
   auto settle = [&](double (&cur)[6], int drel, bool fresh, unsigned long long incm) {
+    SUB_BEGIN();
     bool mv = fresh;
     if (__builtin_expect(incm != 0ull, 0)) mv = fresh & !((incm >> lane) & 1ull); // (the sender moved it)
     const double st = mv ? step : 0.0;
@@ -285,6 +297,10 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
       cur[2] = bound_periodic_sel(cur[2], g.Lz);
     }
     if (!ga_store) return; // (xpic_set_fused_rebin 2: k_second_push writes the sorted copy)
+    SUB_END(9); // move + wrap
+#ifdef FILL_STAMPS
+    const unsigned long long sub2_t_ = __builtin_readcyclecounter();
+#endif
     if (fresh) {
       const unsigned off8 = (unsigned)drel << 3;
 #if FILL_GA_EXP != 1
@@ -294,6 +310,9 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
       }
 #endif
     }
+#ifdef FILL_STAMPS
+    stamp_acc_[10] += __builtin_readcyclecounter() - sub2_t_; // the six stores of the sorted copy
+#endif
   };
 
   Prefetch pf;
@@ -310,8 +329,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
   for (int mm = 0; mm < kOwn; ++mm) carry[mm][0] = carry[mm][1] = 0.0;
 
 #ifdef FILL_STAMPS
-  unsigned long long stamp_t_ = __builtin_readcyclecounter();
-  unsigned long long stamp_acc_[9] = {};
+  stamp_t_ = __builtin_readcyclecounter();
 #endif
   // the cell block of this wave: zeroed here and again right behind the merge that consumes it (zeroing at the top of
   // the chunk made the compiler clear all 36 twice: once for the path around the pass loop and once in front of it)
@@ -724,7 +742,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
   }
 #ifdef FILL_STAMPS
   if (threadIdx.x == 0)
-    for (int k = 0; k < 9; ++k) atomicAdd(&g_fill_stamps[k], stamp_acc_[k]);
+    for (int k = 0; k < 13; ++k) atomicAdd(&g_fill_stamps[k], stamp_acc_[k]);
 #endif
 
   // ---- the two columns still carried are x = nx, nx+1 = 0, 1 (periodic): columns this workgroup has

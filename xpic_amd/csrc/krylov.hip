@@ -42,9 +42,15 @@ int gmres(xpic_ctx* c, int op, const double* b, double* x, double rtol, double a
   bool pc_abar = pc && c->precond >= 3 && op == XPIC_OP_MATA_GMRES;
   if (pc_abar) {
     XPIC_CALL(abar_update(c));
-    // the surrogate's Gershgorin check failed (precond.hip): this solve falls back to the matM polynomial, on every slab
+    // (sums that are not finite: nothing to build a surrogate from)
     if (!c->abar_valid) { pc_abar = false; if (c->profiling) c->prof["precond_fallback"].launches += 1; }
   }
+  // A surrogate whose spectral interval is not proven (precond.hip: abar_proven) runs on PROBATION: every iteration must at
+  // least halve the residual (a sound one divides it by 70 - 200; the matM polynomial it would fall back to by 1.5) and
+  // return finite numbers, or the solve continues with the matM polynomial -- the GMRES is flexible, its preconditioner may
+  // change between two iterations.  The decision rests on all-reduced numbers: every slab takes it alike.
+  bool probation = pc_abar && !c->abar_proven;
+  if (probation && c->profiling) c->prof["precond_probation"].launches += 1;
   double* Z = c->kry_Z;
   double* V = c->kry_V;
   double* w = c->kry_w;
@@ -97,6 +103,13 @@ int gmres(xpic_ctx* c, int op, const double* b, double* x, double rtol, double a
       XPIC_CALL(vec_mdot_ww_host(c, w, V, j + 1, h.data(), pythagoras ? &ww : nullptr)); // VecMDot (+ the norm's w . w)
       double hh = 0.0;
       for (int i = 0; i <= j; ++i) hh += h[i] * h[i];
+      if (probation && !(std::isfinite(hh) && std::isfinite(ww))) {
+        // the surrogate's polynomial blew up: this column is discarded and the iteration taken again with the matM polynomial
+        probation = false; pc_abar = false;
+        if (c->profiling) c->prof["precond_fallback"].launches += 1;
+        --j;
+        continue;
+      }
       double nrm2 = pythagoras ? ww - hh : 0.0;
       double* Vn = V + (long)(j + 1) * c->nvec;
       if (!pythagoras || !(nrm2 > 1e-4 * ww)) {
@@ -121,7 +134,13 @@ int gmres(xpic_ctx* c, int op, const double* b, double* x, double rtol, double a
       gg[j] = cs[j] * gg[j];
       for (int i = 0; i <= j; ++i) H[i * m + j] = h[i];
       ++its;
+      const double rprev = rnorm;
       rnorm = std::abs(gg[j + 1]);
+      if (probation && !(rnorm <= 0.5 * rprev)) {
+        // (the column itself is sound Arnoldi data and stays; the next ones are built with the matM polynomial)
+        probation = false; pc_abar = false;
+        if (c->profiling) c->prof["precond_fallback"].launches += 1;
+      }
       if (rnorm <= tol) { ++j; break; }
     }
     for (int i = j - 1; i >= 0; --i) {
