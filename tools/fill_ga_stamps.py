@@ -38,6 +38,8 @@ tot = st[:9].sum()
 print("assembly %.2f ms (%d launches of %.3f ms); section shares of wave 0, absolute = share x assembly time:" % (ms / steps, nl // steps, ms / nl))
 for k, nm in enumerate(names):
     print("  %-22s %6.2f %%   %6.2f ms" % (nm, 100 * st[k] / tot, st[k] / tot * ms / steps))
-for k, nm in ((9, "  of it: move + wrap (settle)"), (10, "  of it: the six sorted-copy stores"), (11, "  of it: gather issue (phase 1 + prefetch)")):
+for k, nm in ((9, "  of it: move + wrap (settle)"), (10, "  of it: the six sorted-copy stores"), (11, "  of it: gather issue (phase 1 + prefetch)"),
+              (13, "  of it: the wait at the end of a pass"), (12, "  of it: the wait in front of the prefetch"),
+              (14, "  of it: index prefetch (two cells ahead)"), (15, "  of it: RMW requests + offset table loads")):
     if st[k]:
         print("  %-42s %6.2f %%   %6.2f ms" % (nm, 100 * st[k] / tot, st[k] / tot * ms / steps))

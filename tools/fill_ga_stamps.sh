@@ -7,7 +7,10 @@ for f in "$@"; do
   rm -f xpic_amd/csrc/ecsim.o xpic_amd/csrc/api.o
   make -s -j8 xpic_amd/libxpic_hip.so EXTRA="-DXPIC_EXPERIMENT -DFILL_STAMPS $f" > gpurun_out/fill_stamps_build.log 2>&1 || { tail gpurun_out/fill_stamps_build.log; exit 1; }
   echo "[$f]"
-  timeout -k 10 400 python tools/fill_ga_stamps.py 256 64 3 2> gpurun_out/fill_stamps.err || { tail -3 gpurun_out/fill_stamps.err; exit 1; }
+  for mode in ${FILL_MODES:-1 0}; do
+    echo "fused_rebin $mode:"
+    timeout -k 10 400 python tools/fill_ga_stamps.py 256 64 3 $mode 2> gpurun_out/fill_stamps.err || { tail -3 gpurun_out/fill_stamps.err; exit 1; }
+  done
 done
 rm -f xpic_amd/csrc/ecsim.o xpic_amd/csrc/api.o
 make -s -j8 xpic_amd/libxpic_hip.so > gpurun_out/fill_stamps_build.log 2>&1

@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
   const int cz = cz0 + (int)(blockIdx.x / ncy) * czstep;
 #ifdef FILL_STAMPS
   unsigned long long stamp_t_ = 0;
-  unsigned long long stamp_acc_[13] = {};
+  unsigned long long stamp_acc_[16] = {};
 #endif
 
   __shared__ __attribute__((aligned(16))) double sh[kW * kStage];
@@ -563,7 +563,11 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
         // pass body, or the compiler keeps its own): left to the compiler the wait sits at the head of EVERY pass, the
         // first one of a chunk included, where -- the memory counter being in order -- it is a wait for the previous
         // chunk's flush stores
-        __builtin_amdgcn_s_waitcnt(0x0F70);
+        {
+          SUB_BEGIN();
+          __builtin_amdgcn_s_waitcnt(0x0F70);
+          SUB_END(13);
+        }
         if (lastpass) break;
         real = real_next;
       }
@@ -573,12 +577,21 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     // next chunk's cell: particle data and B neighbourhood travel while this chunk is merged and flushed
     // (nothing is outstanding here but the previous chunk's stores: said explicitly, so that the compiler does not guard its
     // re-use of the pass loop's load registers with waits BEHIND the requests below)
-    __builtin_amdgcn_s_waitcnt(0x0F70);
+    {
+      SUB_BEGIN();
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      SUB_END(12);
+    }
     if (GA) {
       prefetch_rec(i + kW, pi, pf);   // its indices were requested a chunk ago
+      SUB_BEGIN();
       prefetch_idx(i + 2 * kW, pi);
+      SUB_END(14);
     }
     else prefetch_cell(i + kW, pf);
+#ifdef FILL_STAMPS
+    const unsigned long long sub3_t_ = __builtin_readcyclecounter();
+#endif
 
     // ---- the finished columns of this chunk leave by read-modify-write: request their current values NOW, so
     // that the HBM latency runs under the merge below (addresses depend only on the chunk, not on the data)
@@ -637,6 +650,9 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
           if (k * 8 + h < kAcc) wdst[k * 8 + h] = (w[h >> 1] >> (16 * (h & 1))) & 0xffffu; // byte offset
       }
     }
+#ifdef FILL_STAMPS
+    stamp_acc_[15] += __builtin_readcyclecounter() - sub3_t_; // RMW requests + the merge's offset table loads
+#endif
     STAMP(3);
     lds_barrier();
     STAMP(4);
@@ -742,7 +758,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
   }
 #ifdef FILL_STAMPS
   if (threadIdx.x == 0)
-    for (int k = 0; k < 13; ++k) atomicAdd(&g_fill_stamps[k], stamp_acc_[k]);
+    for (int k = 0; k < 16; ++k) atomicAdd(&g_fill_stamps[k], stamp_acc_[k]);
 #endif
 
   // ---- the two columns still carried are x = nx, nx+1 = 0, 1 (periodic): columns this workgroup has
