@@ -261,6 +261,21 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     pi.start = 0; pi.cnt = 0; pi.src = 0; pi.srcx = 0;
     if (i >= g.nx) return;
     const int cxu = __builtin_amdgcn_readfirstlane(cell_x(i));
+    if (bucket_cap > 0) {
+      // Buckets: where a slot finds its index does not depend on cell_start, and a slot beyond the cell's count is a stale
+      // index nobody uses -- so the indices are requested at once, and the cell's range (needed a chunk from now, by
+      // prefetch_rec) comes by a VECTOR load of one address for all lanes, waited for with the memory counter a chunk
+      // later.  As a scalar load consumed here it was a full miss latency per chunk, exposed: the row of cell_start is
+      // touched for the first time by this workgroup, every fourth chunk goes to HBM, and the in-kernel timers put 10 ms
+      // of the assembly on this one s_waitcnt (profiles/r05_fill_ga_stamps.txt).
+      const int* csv = s.cell_start + pencil0 + cxu;
+      pi.start = csv[0];
+      pi.cnt = csv[1]; // (the next cell's start: prefetch_rec takes the difference)
+      const int* bk = s.bucket + (pencil0 + cxu) * bucket_cap;
+      pi.src = bk[lane];
+      if (kCP + lane < bucket_cap) pi.srcx = bk[kCP + lane];
+      return;
+    }
     UniformIntsG cs = (UniformIntsG)(s.cell_start + pencil0);
     pi.start = cs[cxu];
     pi.cnt = cs[cxu + 1] - pi.start;
@@ -268,8 +283,13 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     if (lane < min(kCP, pi.cnt - kCP)) pi.srcx = idx_of(cxu, pi.start, kCP + lane);
   };
   auto prefetch_rec = [&](int i, const PrefetchIdx& pi, Prefetch& pf) {
-    pf.start = pi.start; pf.cnt = pi.cnt; pf.b = 0.0; pf.srcx = pi.srcx; pf.incm = 0ull;
-    if (i >= g.nx) return;
+    if (bucket_cap > 0) { // (the range arrived as two lane values: see prefetch_idx)
+      pf.start = __builtin_amdgcn_readfirstlane(pi.start);
+      pf.cnt = __builtin_amdgcn_readfirstlane(pi.cnt) - pf.start;
+    }
+    else { pf.start = pi.start; pf.cnt = pi.cnt; }
+    pf.b = 0.0; pf.srcx = pi.srcx; pf.incm = 0ull;
+    if (i >= g.nx) { pf.start = 0; pf.cnt = 0; return; }
     pf.b = brow ? brow[g.wx(cell_x(i) + box)] : 0.0;
     pf.incm = gather(FILL_GA_NOCHAIN ? pf.start + lane : pi.src, lane < min(kCP, pf.cnt), pf.p);
   };
