@@ -86,12 +86,16 @@ struct PrefetchIdx {
 // the index src[d] of its record in the OLD order; the record is moved by `step`, wrapped (the same arithmetic as k_scatter)
 // and written to r2 / v2 [d] on its way into phase 1 -- the scatter pass of the re-binning (56 B read + 48 B written per
 // particle, 27 ms of the 256^3 x 64 step) shrinks to the index pass and these stores.
-template <bool P2, bool FX, bool GA>
+// GAK: 0 the records lie sorted; 1 gathered through the index k_index built (s.src: z-slabs, a cell beyond its bucket);
+// 2 through the binning's buckets.  Compile-time: at 256 registers per lane the two gathering forms in one body were 18
+// registers in scratch.
+template <bool P2, bool FX, int GAK>
 __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, SortDev s, const double* __restrict__ B,
   double* currI, double* matL, const unsigned short* __restrict__ dtab, const int* __restrict__ linetab, const int* __restrict__ cowr, double q, double m,
   double mpw, int cy0, int cystep, int ncy, int cz0, int czstep, int my_order, int ncol_y, int per_y, int per_z, int first_sort,
   int alias_rows, unsigned long long zord, double step, int* __restrict__ gerr, int ga_store, int bucket_cap, int gwin)
 {
+  constexpr bool GA = GAK != 0;
   const int cy = cy0 + (int)(blockIdx.x % ncy) * cystep;
   const int cz = cz0 + (int)(blockIdx.x / ncy) * czstep;
 #ifdef FILL_STAMPS
@@ -253,7 +257,7 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
   };
   // where slot i of cell cx finds its source index: the binning's bucket of the cell, or the index k_index built
   auto idx_of = [&](int cx, int start, int i) {
-    return bucket_cap > 0 ? s.bucket[(pencil0 + cx) * bucket_cap + i] : s.src[(long)start + i];
+    return GAK == 2 ? s.bucket[(pencil0 + cx) * bucket_cap + i] : s.src[(long)start + i];
   };
   // two cells ahead: the cell's range and the source indices of its first 2 kCP slots (the index -> record chain of one
   // cell ahead was 2.6 ms of the assembly)
@@ -261,21 +265,6 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     pi.start = 0; pi.cnt = 0; pi.src = 0; pi.srcx = 0;
     if (i >= g.nx) return;
     const int cxu = __builtin_amdgcn_readfirstlane(cell_x(i));
-    if (bucket_cap > 0) {
-      // Buckets: where a slot finds its index does not depend on cell_start, and a slot beyond the cell's count is a stale
-      // index nobody uses -- so the indices are requested at once, and the cell's range (needed a chunk from now, by
-      // prefetch_rec) comes by a VECTOR load of one address for all lanes, waited for with the memory counter a chunk
-      // later.  As a scalar load consumed here it was a full miss latency per chunk, exposed: the row of cell_start is
-      // touched for the first time by this workgroup, every fourth chunk goes to HBM, and the in-kernel timers put 10 ms
-      // of the assembly on this one s_waitcnt (profiles/r05_fill_ga_stamps.txt).
-      const int* csv = s.cell_start + pencil0 + cxu;
-      pi.start = csv[0];
-      pi.cnt = csv[1]; // (the next cell's start: prefetch_rec takes the difference)
-      const int* bk = s.bucket + (pencil0 + cxu) * bucket_cap;
-      pi.src = bk[lane];
-      if (kCP + lane < bucket_cap) pi.srcx = bk[kCP + lane];
-      return;
-    }
     UniformIntsG cs = (UniformIntsG)(s.cell_start + pencil0);
     pi.start = cs[cxu];
     pi.cnt = cs[cxu + 1] - pi.start;
@@ -283,13 +272,8 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     if (lane < min(kCP, pi.cnt - kCP)) pi.srcx = idx_of(cxu, pi.start, kCP + lane);
   };
   auto prefetch_rec = [&](int i, const PrefetchIdx& pi, Prefetch& pf) {
-    if (bucket_cap > 0) { // (the range arrived as two lane values: see prefetch_idx)
-      pf.start = __builtin_amdgcn_readfirstlane(pi.start);
-      pf.cnt = __builtin_amdgcn_readfirstlane(pi.cnt) - pf.start;
-    }
-    else { pf.start = pi.start; pf.cnt = pi.cnt; }
-    pf.b = 0.0; pf.srcx = pi.srcx; pf.incm = 0ull;
-    if (i >= g.nx) { pf.start = 0; pf.cnt = 0; return; }
+    pf.start = pi.start; pf.cnt = pi.cnt; pf.b = 0.0; pf.srcx = pi.srcx; pf.incm = 0ull;
+    if (i >= g.nx) return;
     pf.b = brow ? brow[g.wx(cell_x(i) + box)] : 0.0;
     pf.incm = gather(FILL_GA_NOCHAIN ? pf.start + lane : pi.src, lane < min(kCP, pf.cnt), pf.p);
   };
@@ -604,6 +588,11 @@ __global__ void __launch_bounds__(kThreads, FILL_OCC) k_ecsim_fill(GridDev g, So
     }
     if (GA) {
       prefetch_rec(i + kW, pi, pf);   // its indices were requested a chunk ago
+      // (The cell's range is a scalar load consumed on the spot, and the in-kernel timers put 10 ms of the assembly on its
+      // wait -- every fourth chunk's row of cell_start comes from HBM.  Round 5 took the wait away -- the range riding in
+      // two lanes of the index load, requested behind the flush -- and the assembly took 108.8 - 109.0 ms against 107.0 -
+      // 108.0 on the same box (profiles/r05_fill_idx_ab.txt): the other workgroup's wave on the SIMD issues during the
+      // stall; what the kernel is short of is issue slots, not latency hiding.)
       SUB_BEGIN();
       prefetch_idx(i + 2 * kW, pi);
       SUB_END(14);
@@ -1034,10 +1023,11 @@ int ecsim_fill_sort(xpic_ctx* c, Sort& s, const double* B, double* currI_sort, d
           pos * ncol_y + a, ncol_y, per_y, per_z, first_sort ? 1 : 0, zord);
         continue;
       }
-      auto kern = ga ? (g.pow2 ? (fx ? k_ecsim_fill<true, true, true> : k_ecsim_fill<true, false, true>)
-                               : (fx ? k_ecsim_fill<false, true, true> : k_ecsim_fill<false, false, true>))
-                     : (g.pow2 ? (fx ? k_ecsim_fill<true, true, false> : k_ecsim_fill<true, false, false>)
-                               : (fx ? k_ecsim_fill<false, true, false> : k_ecsim_fill<false, false, false>));
+      const int gak = ga ? (s.def_bucket ? 2 : 1) : 0;
+#define FILLK(G) (g.pow2 ? (fx ? k_ecsim_fill<true, true, G> : k_ecsim_fill<true, false, G>) \
+                         : (fx ? k_ecsim_fill<false, true, G> : k_ecsim_fill<false, false, G>))
+      auto kern = gak == 2 ? FILLK(2) : (gak == 1 ? FILLK(1) : FILLK(0));
+#undef FILLK
       hipLaunchKernelGGL(kern, dim3((unsigned)(ncy * ncz)), dim3(kThreads), 0, c->stream, g, s.d, B,
         currI_sort, matL, dtab, c->ltab, c->ltab + kLines, s.par.q, s.par.m,
         s.par.n / (double)s.par.Np, cy0, cys, ncy, cz0, czs, pos * ncol_y + a, ncol_y, per_y, per_z, first_sort && !alias ? 1 : 0,
