@@ -131,8 +131,15 @@ def test_single_rank_line_has_the_contract_fields():
         assert key in line, key
     assert line["n_gpus"] == 1 and line["dtype"] == "f64" and line["vs_baseline"] is None
     r = line["roofline"]
-    assert r["kernel"].startswith("k_ecsim_fill") and r["bound"] == "mfma" and r["flop_per_particle"] == 1200.0
+    assert r["kernel"].startswith("k_ecsim_fill") and r["flop_per_particle"] == 1200.0
+    # the binding roof by the ridge test: flop per algorithmic byte against 78.6 TFLOP/s / 8 TB/s; both fractions are carried
+    assert r["bound"] == ("hbm" if r["flop_per_byte"] < r["ridge_flop_per_byte"] else "mfma")
+    assert r["unit"] == ("GB/s" if r["bound"] == "hbm" else "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["frac"] - (r["frac_hbm"] if r["bound"] == "hbm" else r["frac_fp64"])) < 1e-12
+    for key in ("solve_ms_per_step", "ms_per_solve", "matA_applies_per_step", "stencil_steps_per_iteration", "occupancy"):
+        assert key in line, key
+    assert line["occupancy"]["gathering_assemblies_per_step"] == 1  # the default step defers its scatter into the assembly
     assert line["roofline_spmv"]["bound"] == "hbm"
     c = line["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["ksp_iters_per_s_at_sample_grid"] > 0
