@@ -1,6 +1,7 @@
 # bench.py under several compile-time configurations in ONE gpurun call, selected phases printed per configuration:
 #   tools/bench_cfg.sh "<bench args>" "<make EXTRA flags 1>" "<flags 2>" ...      (the default build is restored at the end)
 set -o pipefail
+export XPIC_ALLOW_EXPERIMENT=1  # (flag sets that set a kernel switch are experiment builds: -DXPIC_EXPERIMENT in the flags, common.h)
 cd $GRAFT_REPO_ROOT
 ARGS=$1; shift
 for f in "$@"; do

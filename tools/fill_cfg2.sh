@@ -1,6 +1,7 @@
 # several compile-time configurations of ecsim.hip timed with tools/fill_bench.py in ONE gpurun call, then the default
 # build's parity tests:  tools/fill_cfg2.sh "<flags1>" "<flags2>" ...
 set -o pipefail
+export XPIC_ALLOW_EXPERIMENT=1  # (flag sets that set a kernel switch are experiment builds: -DXPIC_EXPERIMENT in the flags, common.h)
 cd $GRAFT_REPO_ROOT
 for f in "$@"; do
   rm -f xpic_amd/csrc/ecsim.o

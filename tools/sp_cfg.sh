@@ -1,5 +1,6 @@
 # times the ecsim step phases with different compile-time flags of particles.hip: tools/sp_cfg.sh "<flags1>" ...
 set -o pipefail
+export XPIC_ALLOW_EXPERIMENT=1  # (flag sets that set a kernel switch are experiment builds: -DXPIC_EXPERIMENT in the flags, common.h)
 R=$GRAFT_REPO_ROOT
 cd $R
 for f in "$@"; do
