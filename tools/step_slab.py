@@ -15,7 +15,10 @@ ppc = int(sys.argv[5]) if len(sys.argv) > 5 else 64
 steps = 5
 ctx = X.Context(scheme, (nx, ny, nz), (0.5,) * 3, 1.0, self_ring=True)
 ctx.comm_init_rccl(X.rccl_unique_id())
-if os.environ.get("XPIC_SLAB_OVERLAP") is not None:  # 0: every exchange blocks the compute stream (A/B against the default)
+if os.environ.get("XPIC_SLAB_PEER") == "1":  # the copy-engine path needs the neighbours' buffers mapped: its own, on a self-ring
+    blob = ctx.comm_peer_export()
+    ctx.comm_peer_import(blob, blob)
+if os.environ.get("XPIC_SLAB_OVERLAP") is not None:  # 0: every exchange blocks the compute stream (A/B against the default); 4: ghost rows by peer copy
     ctx.set_overlap(int(os.environ["XPIC_SLAB_OVERLAP"]))
 s = ctx.add_sort(ppc, 1.0, -1.0, 1.0, capacity=int(ppc * nx * ny * nz * 1.05) + 4096)
 ctx.fill_synthetic(s, ppc, 0.014, seed=1234)
@@ -37,7 +40,7 @@ for _ in range(steps):
 ctx.synchronize()
 ms = (time.perf_counter() - t0) / steps * 1e3
 names = ("fill_current", "solve_matA", "solve_matM", "matA_apply", "precond", "scatter", "second_push", "move_bin", "halo",
-         "migrate", "index", "matL_ghost_rows", "matL_zero", "precond_setup", "rot_apply", "mdot", "maxpy", "corr_first_push", "corr_second_push", "matL_apply", "scan", "allreduce")
+         "migrate", "index", "matL_ghost_rows", "matL_zero", "precond_setup", "rot_apply", "mdot", "maxpy", "corr_first_push", "corr_second_push", "matL_apply", "scan", "allreduce", "peer_copies")
 prof = {k: ctx.profile_get(k) for k in names}
 print("%s slab %d x %d x %d, %d ppc (self-ring): %.2f ms/step, %.1f iterations/step" % (scheme, nx, ny, nz, ppc, ms, its / steps))
 print("  " + ", ".join("%s %.2f" % (k, v[1] / steps) for k, v in prof.items() if v[1] / steps > 0.05),
