@@ -594,25 +594,26 @@ int abar_update(xpic_ctx* c)
   // rows, sqrt(<d^2> / <d>^2 - 1): 0.1 for a uniform Poisson(64) load (256^3: kind 3 takes 4 iterations of degree 8, kind 4
   // four dearer ones: 184 against 195 ms per step), 0.37 with the density falling 4 : 1 across the box (kind 3: 6
   // iterations, kind 4: 4; 218 against 202 ms per step).  It travels in the all-reduced sums: every slab decides alike.
+  // (one synchronisation for the bounds and the spread; a second one only where the rows are scaled, for their largest ratio)
+  XPIC_HIP(hipGetLastError());
+  XPIC_HIP(hipMemcpyAsync(hb, bounds, sizeof(double) * 10, hipMemcpyDeviceToHost, c->stream));
+  XPIC_HIP(hipStreamSynchronize(c->stream));
   bool scaled = c->precond == 4;
   if (c->precond == 5) {
-    XPIC_HIP(hipMemcpyAsync(hb + 7, bounds + 7, sizeof(double) * 3, hipMemcpyDeviceToHost, c->stream));
-    XPIC_HIP(hipStreamSynchronize(c->stream));
     const double cv2 = std::max(hb[7], std::max(hb[8], hb[9]));
     scaled = std::isfinite(cv2) && cv2 > kAutoSpread * kAutoSpread;
   }
   c->abar_scaled = scaled;
   if (scaled && c->profiling) c->prof["precond_scaled"].launches += 1;
-  unsigned* rmax_w = (unsigned*)(c->abar_r + c->nvec);
   if (scaled) {
+    unsigned* rmax_w = (unsigned*)(c->abar_r + c->nvec);
     XPIC_HIP(hipMemsetAsync(rmax_w, 0, sizeof(unsigned), c->stream));
     const unsigned nb = (unsigned)std::min<long>((g.nown + 255) / 256, 2048);
     hipLaunchKernelGGL(k_rscale, dim3(nb, 3), dim3(256), 0, c->stream, g, c->matL, abar64, mco, c->abar_r, rmax_w);
-    XPIC_HIP(hipMemcpyAsync(bounds + 6, rmax_w, sizeof(unsigned), hipMemcpyDeviceToDevice, c->stream));
+    XPIC_HIP(hipGetLastError());
+    XPIC_HIP(hipMemcpyAsync(hb + 6, rmax_w, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    XPIC_HIP(hipStreamSynchronize(c->stream));
   }
-  XPIC_HIP(hipGetLastError());
-  XPIC_HIP(hipMemcpyAsync(hb, bounds, sizeof(double) * 7, hipMemcpyDeviceToHost, c->stream));
-  XPIC_HIP(hipStreamSynchronize(c->stream));
   double rmax = 1.0;
   if (scaled) {
     unsigned bits;
