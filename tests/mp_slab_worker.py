@@ -7,7 +7,11 @@ environment: XPIC_SLAB_PEER=1 -- the matL ghost rows travel by hipMemcpyAsync in
 XPIC_SLAB_GATHER_WINDOW=<slots> -- the gathering assembly reaches only that far by 32-bit offsets (the far
 arm and the receive-buffer arm of its gather then meet the oracle); XPIC_SLAB_CONFINE=1 -- the LAST species lives in the
 middle of slab 0 only and is cold, so the other slabs hold no particle of it (the matL ghost-row exchange must still be
-posted at the same place of every rank's message sequence)"""
+posted at the same place of every rank's message sequence); XPIC_SLAB_CLUMP=1 -- 110 slow particles of the first
+species sit in ONE cell of the first plane of slab 1 and 60 more fly towards it from two planes below (slab 0), one plane per
+step: at the second step they arrive through the migration and the cell holds more than a bucket of the deferred scatter
+(128), so that slab falls back to the index built from the keys -- which the pre-binning second push did not write: they
+are rebuilt -- while the other slabs keep their buckets"""
 import os
 import sys
 
@@ -34,6 +38,12 @@ def problem(scheme, n, d, seed):
         pts = np.empty((8 * N, 6))
         pts[:, :3] = rng.random((8 * N, 3)) * L
         pts[:, 3:] = rng.normal(0, vth, (8 * N, 3))
+        if CLUMP and i == 0:
+            cell = np.array([3, 2, CLUMP]) * np.array(d)  # (x, y, first plane of slab 1)
+            pts[:170, :3] = cell + (0.3 + 0.4 * rng.random((170, 3))) * np.array(d)
+            pts[:170, 3:] *= 0.02  # (slow: they are still there after the steps)
+            pts[110:170, 2] -= 2 * d[2]  # two planes below: slab 0 ...
+            pts[110:170, 5] += d[2] / 0.8  # ... and one plane per step of ecsim's dt = 0.8 upwards
         if CONFINE and i == len(SORTS) - 1:
             pts = pts[: N]
             pts[:, 2] = (0.3 + 0.4 * rng.random(N)) * CONFINE * d[2]  # CONFINE = planes of slab 0
@@ -47,6 +57,7 @@ def problem(scheme, n, d, seed):
 
 
 CONFINE = 0  # planes of slab 0 (set by main() from XPIC_SLAB_CONFINE)
+CLUMP = 0    # planes per slab (set by main() from XPIC_SLAB_CLUMP)
 RCCL = os.environ.get("XPIC_SLAB_TRANSPORT") == "rccl"  # one GPU per rank, RCCL over xGMI (needs >= nranks devices)
 
 
@@ -93,11 +104,13 @@ def gather_field(ctx, fid, nranks):
 def main():
     scheme = sys.argv[1]
     nzl = int(sys.argv[2]) if len(sys.argv) > 2 else 12
-    global CONFINE
+    global CONFINE, CLUMP
     dist.init_process_group("gloo")
     rank, nranks = dist.get_rank(), dist.get_world_size()
     if os.environ.get("XPIC_SLAB_CONFINE") == "1":
         CONFINE = nzl
+    if os.environ.get("XPIC_SLAB_CLUMP") == "1":
+        CLUMP = nzl
     n, d = (12, 10, nzl * nranks), (0.5, 0.4, 0.25)
     dt = 0.2 if scheme != "ecsim" else 0.8
     ctx = build(scheme, n, d, dt, rank, nranks, seed=42)
@@ -119,7 +132,16 @@ def main():
     if CONFINE:
         assert (counts0[1] > 0) == (rank == 0), counts0  # the last species lives on slab 0 alone
     nsteps = 3
+    if CLUMP:
+        ctx.profile_enable(True)
     its = [ctx.step() for _ in range(nsteps)]
+    if CLUMP and scheme == "ecsim":
+        # the clump's slab went through the index from the second step on (its keys rebuilt once, after the key-less
+        # pre-binning that the arrivals overflowed), the others kept their buckets; every slab's assembly gathered
+        idx, rebuilt, gathered = (ctx.profile_get(k)[0] for k in ("index", "rebuild_keys", "fill_gather"))
+        assert gathered == 2 * nsteps, gathered
+        assert (idx, rebuilt) == ((nsteps - 1, 1) if rank == 1 else (0, 0)), (rank, idx, rebuilt)
+        ctx.profile_enable(False)
     if os.environ.get("XPIC_SLAB_PEER") == "1" and scheme != "basic":
         assert ctx.profile_get("peer_copies")[0] == 4 * nsteps, ctx.profile_get("peer_copies")  # 3 planes up + 1 down per step
         ctx.profile_enable(False)

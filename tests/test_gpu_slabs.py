@@ -43,6 +43,15 @@ def test_slabs_with_a_short_gather_window():
     run_slabs("ecsim", 2, 12, XPIC_SLAB_GATHER_WINDOW="150")
 
 
+def test_slabs_with_a_cell_above_the_bucket_capacity():
+    """The deferred scatter's buckets on slabs: the pre-binning second push and the arrivals' binning fill them (what a
+    neighbour sent is the source index -1 - i), no keys are written.  One cell of slab 1 holds 200 particles, more than its
+    bucket (128): that slab alone rebuilds the keys and takes the index form of the gather, the others keep the bucket
+    form (counted in the worker) -- a rank-local decision, no exchange depends on it -- and the run equals the single
+    slab and the oracle as before."""
+    run_slabs("ecsim", 3, 12, XPIC_SLAB_CLUMP="1")
+
+
 @pytest.mark.parametrize("scheme,world", [("ecsim", 2), ("ecsimcorr", 3)])
 def test_slabs_with_ghost_rows_by_peer_copy(scheme, world):
     """The copy-engine path of the one large message of a step (xpic_comm_peer_export / _import, xpic_set_overlap bit 2):
@@ -126,10 +135,11 @@ for t in range(3):
     assert abs(ia - ic) <= 1, (ia, ic)
     assert abs(ia - id_) <= 1, (ia, id_)
 assert d.profile_get("peer_copies")[0] == 12
-# per step: the slab that defers runs the index pass (what the neighbours sent stays in the receive buffer and is gathered
-# from there) and ONE scatter (the second re-binning), the other one two scatters
-assert a.profile_get("index")[0] == 3 and a.profile_get("scatter")[0] == 3, (a.profile_get("index"), a.profile_get("scatter"))
-assert c.profile_get("index")[0] == 0 and c.profile_get("scatter")[0] == 6
+# per step: the slab that defers gathers through the cells' buckets (what the neighbours sent stays in the receive buffer,
+# source indices -1 - i, and is gathered from there; no index pass) and runs ONE scatter (the second re-binning), the other
+# one two scatters
+assert a.profile_get("index")[0] == 0 and a.profile_get("fill_gather")[0] == 3 and a.profile_get("scatter")[0] == 3, (a.profile_get("index"), a.profile_get("scatter"))
+assert c.profile_get("index")[0] == 0 and c.profile_get("fill_gather")[0] == 0 and c.profile_get("scatter")[0] == 6
 assert a.profile_get("migrate")[0] == 6  # particles do cross the slab's (own) boundary in both re-binnings
 for f in (X.E, X.B):
     fa, fb, fc = a.get_field(f), b.get_field(f), c.get_field(f)

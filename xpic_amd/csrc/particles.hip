@@ -137,8 +137,14 @@ __global__ void __launch_bounds__(kBlock) k_bin_incoming(GridDev g, SortDev s, c
   if (i >= n) return;
   const int c = cell_of(g, inc[6L * i], inc[6L * i + 1], inc[6L * i + 2]);
   inc_cell[i] = c;
-  if (c >= 0) inc_rank[i] = atomicAdd(&s.cell_count[c], 1);
-  else atomicOr(err, 4);
+  if (c < 0) { atomicOr(err, 4); return; }
+  const int rank = inc_rank[i] = atomicAdd(&s.cell_count[c], 1);
+  // (a binning that fills the cells' buckets: record i of the receive buffer is the source index -1 - i, as k_index_incoming
+  // writes it into the index)
+  if (s.bucket_cap > 0) {
+    if (rank < s.bucket_cap) s.bucket[(long)c * s.bucket_cap + rank] = -1 - i;
+    else atomicOr(s.bucket + s.ncell * s.bucket_cap, 1);
+  }
 }
 
 __global__ void __launch_bounds__(kBlock) k_scatter_incoming(SortDev s, const double* inc, int n, const int* inc_cell,
@@ -800,11 +806,11 @@ int sort_alloc(xpic_ctx* c, Sort& s, int64_t cap)
   s.d.bucket = nullptr; s.d.bucket_cap = 0; s.d.ncell = c->ncell;
   XPIC_HIP(hipMalloc(&s.d.src, sizeof(int) * (cap + 1))); // deferred scatter (into the assembly, or into the next Esirkepov push)
   if (c->scheme != XPIC_BASIC) {
-    // buckets of XPIC_BUCKET_CAP source indices per cell, on a single slab, where they cost at most as much as the particles' keys
+    // buckets of XPIC_BUCKET_CAP source indices per cell, where they cost at most as much as the particles' keys
     // (twice the mean occupancy the capacity allows, in steps of 32, at most XPIC_BUCKET_CAP: a Poisson cell never gets there)
     long bcap = ((2 * cap / c->ncell + 32 + 31) / 32) * 32;
     if (bcap > XPIC_BUCKET_CAP) bcap = XPIC_BUCKET_CAP;
-    if (c->g.G == 0 && bcap > 0) {
+    if (bcap > 0) {
       XPIC_HIP(hipMalloc(&s.d.bucket, sizeof(int) * (c->ncell * bcap + 1)));
       XPIC_HIP(hipMemsetAsync(s.d.bucket + c->ncell * bcap, 0, sizeof(int), c->stream));
       s.d.bucket_cap = (int)bcap;
@@ -933,13 +939,15 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap, int defer)
     if (s.d.bucket_cap > 0) XPIC_HIP(hipMemsetAsync(s.d.bucket + c->ncell * s.d.bucket_cap, 0, sizeof(int), c->stream));
     if (mig) XPIC_HIP(hipMemsetAsync(s.mig_count, 0, sizeof(int) * 4, c->stream));
   }
-  if (!prebinned) s.keys_valid = true; // (k_move_bin below writes them; an un-consumed key-less pre-binning is forgotten)
+  if (!prebinned) {
+    s.keys_valid = true; // (k_move_bin below writes them; an un-consumed key-less pre-binning is forgotten)
+    // (the buckets are filled only for a binning that a deferred scatter will read -- by the arrivals too, sort or no sort)
+    s.bucket_written = defer == 1 && s.d.bucket_cap > 0 && c->fused_rebin == 1;
+  }
   if (s.n > 0 && !prebinned) {
     Timed t(c, "move_bin");
     const unsigned nb = pgrid(s.n);
-    // (the buckets are filled only for a binning that a deferred scatter will read)
     SortDev sd = s.d;
-    s.bucket_written = defer == 1 && !mig && s.d.bucket_cap > 0 && c->fused_rebin == 1;
     if (!s.bucket_written) sd.bucket_cap = 0;
 #define LAUNCH(M, W, G) hipLaunchKernelGGL((k_move_bin<M, W, G>), dim3(nb), dim3(kBlock), 0, c->stream, c->g, sd, s.n, step, mg)
     if (mig) {
@@ -994,7 +1002,9 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap, int defer)
     XPIC_CALL(comm_ring(c, s.mig_send[0], sizeof(double) * 6 * hc[0], s.mig_send[1], sizeof(double) * 6 * hc[1], s.mig_recv,
       sizeof(double) * 6 * hin[0], s.mig_recv + 6L * hin[0], sizeof(double) * 6 * hin[1]));
     if (n_in > 0) {
-      hipLaunchKernelGGL(k_bin_incoming, dim3(pgrid(n_in)), dim3(kBlock), 0, c->stream, c->g, s.d, s.mig_recv, n_in,
+      SortDev sdi = s.d; // (the arrivals join the buckets of a binning that filled them: this pass's, or the second push's)
+      if (!(s.bucket_written && defer == 1 && c->fused_rebin == 1)) sdi.bucket_cap = 0;
+      hipLaunchKernelGGL(k_bin_incoming, dim3(pgrid(n_in)), dim3(kBlock), 0, c->stream, c->g, sdi, s.mig_recv, n_in,
         s.mig_cell, s.mig_rank, s.mig_count + 2);
       XPIC_HIP(hipGetLastError());
     }
@@ -1018,7 +1028,7 @@ int sort_rebin(xpic_ctx* c, Sort& s, double step, bool wrap, int defer)
   // Deferred (the ecsim step on a single slab): the records stay where they are; slot d of the new order learns its
   // source, and the mass-matrix assembly -- which reads every particle anyway -- moves, wraps and writes it (ecsim.hip).
   // On z-slabs too (the assembly only: defer == 1): what the neighbours sent stays in the receive buffer and gets the source
-  // indices -1 - i; no buckets there.
+  // indices -1 - i, in the buckets (k_bin_incoming) or in the index (k_index_incoming).
   // What the deferral's decisions need from the device, fetched with ONE synchronisation: the bucket-overflow flag of the
   // binning, and -- for sorts of 2^29 particles or more only -- whether an x-pencil holds 2^29 or more: that is beyond the
   // 32-bit offsets of the gathering assembly, and such a sort is scattered here, by this rank alone (nothing collective
@@ -1192,7 +1202,7 @@ int ecsim_second_push(xpic_ctx* c, Sort& s, const double* E, const double* B, bo
   }
   // (the pre-binning fills the buckets when the next step's re-binning will defer its scatter into the assembly)
   SortDev sd = s.d;
-  const bool wbucket = prebin && !mig && s.d.bucket_cap > 0 && c->fused_rebin == 1 && c->scheme == XPIC_ECSIM;
+  const bool wbucket = prebin && s.d.bucket_cap > 0 && c->fused_rebin == 1 && c->scheme == XPIC_ECSIM;
   if (!wbucket) sd.bucket_cap = 0;
   // ... and then the buckets are ALL the next re-binning reads: the keys stay unwritten (8 of the 84 B per particle), unless
   // this sort has overflowed a bucket before or the assembly that follows is not the gathering kind
