@@ -291,7 +291,8 @@ const char* xpic_last_error(void) { return g_error.c_str(); }
 int xpic_version(void)
 {
   // bit 30: some object of this library was built with -DXPIC_EXPERIMENT (ablation switches, in-kernel timers)
-  const bool exp = XPIC_TU_EXPERIMENT || experiment_ecsim() || experiment_ecsim_ws() || experiment_esirkepov();
+  const bool exp = XPIC_TU_EXPERIMENT || experiment_ecsim() || experiment_ecsim_ws() || experiment_esirkepov() || experiment_fields() ||
+    experiment_precond() || experiment_particles();
   return XPIC_VERSION | (exp ? XPIC_VERSION_EXPERIMENT_BIT : 0);
 }
 

@@ -22,7 +22,8 @@
   defined(ESK_FLUSH) || defined(ESK_BOX_GENERIC) || defined(ESK_PIPE) || defined(ESK_LANES) || defined(ESK_COLS1) || defined(ESK_SEG0) || defined(ESK_OCC1) || \
   defined(ESK_DRAIN0) || defined(ESK_TILE_LATE) || defined(XPIC_CHEB_MIN_ZC) || defined(BAR_SCHED_SCALED) || defined(BAR_SCHED_GROUP) || \
   defined(XPIC_MAX_PER_Z) || defined(XPIC_SLAB_FIRST_TOUCH) || defined(XPIC_CHEB_M_BOUND) || defined(XPIC_BUCKET_CAP) || \
-  defined(XPIC_DEFAULT_FUSED_REBIN) || defined(XPIC_DEFAULT_PRECOND) || defined(XPIC_DEFAULT_FILL_KERNEL))
+  defined(XPIC_DEFAULT_FUSED_REBIN) || defined(XPIC_DEFAULT_PRECOND) || defined(XPIC_DEFAULT_FILL_KERNEL) || defined(MATA_GROUP) || \
+  defined(MATA_DEPTH))
 #error "a build switch of the kernels was set on the command line: that is an experiment build, add -DXPIC_EXPERIMENT"
 #endif
 #ifdef XPIC_EXPERIMENT
@@ -49,6 +50,9 @@ void set_error(const std::string& msg);
 int experiment_ecsim();
 int experiment_ecsim_ws();
 int experiment_esirkepov();
+int experiment_fields();
+int experiment_precond();
+int experiment_particles();
 
 #define XPIC_HIP(call)                                                                         \
   do {                                                                                         \

@@ -9,6 +9,8 @@
 
 namespace xpic {
 
+int experiment_fields() { return XPIC_TU_EXPERIMENT; }
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -357,56 +359,113 @@ __global__ void __launch_bounds__(kBlock) k_cheb32(GridDev g, const double* __re
 // an integer_sequence so that all address arithmetic folds into immediates and wave-uniform row bases.
 // (Two neighbouring rows per lane -- 16-byte coefficient loads, the operand taps of a stencil line as three 16-byte loads,
 // 2.2 x fewer vector-memory instructions per row -- was built and measured SLOWER: 11.6 against 10.5 ms per apply.)
-struct RowCtx {
-  const char* Lb;    // wave-uniform: first coefficient of the row block (c1, z, y), x = 0
-  const char* Xb;    // operand vector
-  unsigned xl8;      // lane: byte offset of (x-block, x % 4) inside the row block
-  unsigned xs8[5];   // lane: 8 * wrap(x + d), d = -2..2
-  unsigned crow[3];  // wave-uniform byte offsets: component c2,
-  unsigned yrow[5];  //   row wrap(y + d),
-  unsigned zrow[5];  //   plane wrap(z + d)          (a field vector is < 4 GiB by construction)
+constexpr int kRowX = 64, kRowY = 4;
+constexpr int kBandY = 4; // y-chunks per band: 16 rows
+
+// The operand's neighbourhood of a workgroup's 4 x 64 rows of component C1, staged in LDS: per column component c2 the
+// nodes the rows' stencil reaches (lstencil.h: lrange), (n_z) x (n_y + 3) x (n_x + 63) values.  Before (rounds 2 - 4)
+// every lane fetched its 123 operand values through the vector L1 beside the 123 coefficients it streams: measured on
+// the kernel itself, the operand loads alone cost 2.0 of its 10.1 ms (the coefficient stream needs that L1 -- four
+// consecutive k share a 128-byte line -- and a pure stream of matL in this layout runs at 6.4 TB/s, tools/ubench/matl_layout.hip).
+template <int C1>
+struct XTile {
+  static constexpr int nx(int c2) { return lrange(C1, c2).n[0] + kRowX - 1; }
+  static constexpr int ny(int c2) { return lrange(C1, c2).n[1] + kRowY - 1; }
+  static constexpr int nz(int c2) { return lrange(C1, c2).n[2]; }
+  static constexpr int off(int c2)
+  {
+    int o = 0;
+    for (int c = 0; c < c2; ++c) o += nx(c) * ny(c) * nz(c);
+    return o;
+  }
+  static constexpr int size = off(3);
+  // entry of (component c2, node offset d) for the row of thread (0, 0); thread (tx, ty) adds ty * nx(c2) + tx
+  static constexpr int at(int c2, int dx, int dy, int dz)
+  {
+    const LRange r = lrange(C1, c2);
+    return off(c2) + ((dz - r.lo[2]) * ny(c2) + (dy - r.lo[1])) * nx(c2) + (dx - r.lo[0]);
+  }
+};
+constexpr int kXTileMax = XTile<0>::size > XTile<1>::size ? (XTile<0>::size > XTile<2>::size ? XTile<0>::size : XTile<2>::size)
+                                                          : (XTile<1>::size > XTile<2>::size ? XTile<1>::size : XTile<2>::size);
+static_assert(kXTileMax * 8 <= 40960 - 1280, "four workgroups of k_matA per CU: 160 KB of LDS");
+
+// one periodic fold, as GridDev::wx; what is still outside belongs to lanes / rows beyond the grid's edge (a partial
+// chunk): nobody reads those entries, any valid index will do
+__device__ __forceinline__ int fold_or_zero(int v, int n)
+{
+  v = v < 0 ? v + n : (v >= n ? v - n : v);
+  return v < n ? v : 0;
+}
+
+template <int C1, int C2>
+__device__ __forceinline__ void xtile_fill_c(const GridDev& g, const double* __restrict__ X, double* tile, int x0, int y0, int z, int tx, int w)
+{
+  constexpr LRange r = lrange(C1, C2);
+  constexpr int NX = XTile<C1>::nx(C2), NY = XTile<C1>::ny(C2), NZ = XTile<C1>::nz(C2), OFF = XTile<C1>::off(C2);
+  static_assert(NX > kRowX && NX <= 2 * kRowX, "a tile row is one full and one partial pass of the wave");
+  const int gx0 = fold_or_zero(x0 + r.lo[0] + tx, g.nx), gx1 = fold_or_zero(x0 + r.lo[0] + kRowX + tx, g.nx);
+  for (int row = w; row < NY * NZ; row += kRowY) { // (w is wave-uniform: scalar arithmetic)
+    const int pz = row / NY, py = row - pz * NY;
+    const double* src = X + C2 * g.cstride + (long)g.wz(z + r.lo[2] + pz) * g.plane + (long)fold_or_zero(y0 + r.lo[1] + py, g.ny) * g.nx;
+    tile[OFF + row * NX + tx] = src[gx0];
+    if (tx < NX - kRowX) tile[OFF + row * NX + kRowX + tx] = src[gx1];
+  }
+}
+
+#ifndef MATA_GROUP
+#define MATA_GROUP 12 // (experiment builds: 8 / 12 / 16 / 20 x depth 2: 9.3 / 8.8 / 8.8 / 9.3 ms per apply at 256^3; 8 x 3 and 8 x 4: 9.1; 12 x 3: 8.8; 24 x 1: 9.5)
+#endif
+#ifndef MATA_DEPTH
+#define MATA_DEPTH 2
+#endif
+constexpr int kLGroup = MATA_GROUP, kLDepth = MATA_DEPTH;
+
+// The 123 terms of a row in groups of kLGroup, the coefficients of kLDepth groups in flight: group j takes the lane's offset
+// into the row block from copy j % kLDepth, and that copy passes through an opaque statement together with the sums at
+// the end of its group, so that the requests of group j + kLDepth cannot be issued before the products of group j, while
+// those of the groups between are on their way.  The tile bases pass through every group's statement: a group's operand
+// values are read out of LDS when the group before it is done.  (Left to itself the scheduler requests all 123
+// coefficients and all 123 operand values first and spills a thousand registers; a scheduling barrier does not hold it.)
+struct RowAddr {
+  unsigned xl8[kLDepth]; // byte offset of (x-block, x % 4) inside the row block
+  int lb[3];             // ty * nx(c2) + tx
 };
 
 template <int C1, int K>
-__device__ __forceinline__ void lterm(double (&acc)[2], const RowCtx& r)
+__device__ __forceinline__ void lterm(double (&acc)[2], const char* Lb, RowAddr& a, const double* tile)
 {
   constexpr LEntry e = ldecode(C1, K);
-  const unsigned srow = r.crow[e.c2] + r.zrow[e.d[2] + 2] + r.yrow[e.d[1] + 2]; // scalar
-  const double xv = *reinterpret_cast<const double*>(r.Xb + (size_t)(srow + r.xs8[e.d[0] + 2]));
-  const double lv = *reinterpret_cast<const double*>(r.Lb + (size_t)K * 32 + r.xl8);
+  constexpr int toff = XTile<C1>::at(e.c2, e.d[0], e.d[1], e.d[2]);
+  constexpr int set = (K / kLGroup) % kLDepth;
+  const double xv = tile[a.lb[e.c2] + toff];
+  const double lv = *reinterpret_cast<const double*>(Lb + (size_t)K * 32 + a.xl8[set]);
   acc[K & 1] += lv * xv;
+  if (K % kLGroup == kLGroup - 1)
+    asm volatile("" : "+v"(a.xl8[set]), "+v"(a.lb[0]), "+v"(a.lb[1]), "+v"(a.lb[2]) : "v"(acc[0]), "v"(acc[1]));
 }
 
 template <int C1, int... Ks>
-__device__ __forceinline__ double row_apply(std::integer_sequence<int, Ks...>, const GridDev& g,
-  const double* __restrict__ L, const double* __restrict__ X, int x, int y, int z)
+__device__ __forceinline__ double row_apply(std::integer_sequence<int, Ks...>, const GridDev& g, const double* __restrict__ L,
+  const double* tile, const int (&lb)[3], int x, int y, int z)
 {
-  RowCtx r;
-  r.Lb = reinterpret_cast<const char*>(L + g.lindex(C1, z + (g.G ? 1 : 0), y, 0, 0));
-  r.Xb = reinterpret_cast<const char*>(X);
-  r.xl8 = (unsigned)(x >> 2) * (8u * kLBlock) + 8u * (unsigned)(x & 3);
-#pragma unroll
-  for (int d = -2; d <= 2; ++d) {
-    r.xs8[d + 2] = 8u * (unsigned)g.wx(x + d);
-    // every extent is >= 4 > |d|: one fold is enough
-    r.yrow[d + 2] = 8u * (unsigned)(g.wy(y + d) * g.nx);
-    r.zrow[d + 2] = 8u * (unsigned)((long)g.wz(z + d) * g.plane);
-  }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) r.crow[c] = 8u * (unsigned)(c * g.cstride);
+  const char* Lb = reinterpret_cast<const char*>(L + g.lindex(C1, z + (g.G ? 1 : 0), y, 0, 0)); // wave-uniform: the row block (c1, z, y)
+  RowAddr a;
+  for (int d = 0; d < kLDepth; ++d) a.xl8[d] = (unsigned)(x >> 2) * (8u * kLBlock) + 8u * (unsigned)(x & 3);
+  for (int c = 0; c < 3; ++c) a.lb[c] = lb[c];
   double acc[2] = {0.0, 0.0};
-  (lterm<C1, Ks>(acc, r), ...);
+  (lterm<C1, Ks>(acc, Lb, a, tile), ...);
   return acc[0] + acc[1];
 }
 
 // one component of matM x = 2 x + 0.5 dt^2 rot(-) rot(+) x, written for component C with the cyclic
-// axes A = C+1, B = C+2:  (rot- G)_C = d-_A G_B - d-_B G_A,  G_B = d+_C F_A - d+_A F_C,  G_A = d+_B F_C - d+_C F_B
-template <int C>
-__device__ __forceinline__ double matM_comp(const GridDev& g, const double* __restrict__ F, int x, int y, int z)
+// axes A = C+1, B = C+2:  (rot- G)_C = d-_A G_B - d-_B G_A,  G_B = d+_C F_A - d+_A F_C,  G_A = d+_B F_C - d+_C F_B;
+// at(comp, ox, oy, oz): the operand's component `comp` at the node offset (ox, oy, oz) from the row's node
+template <int C, class At>
+__device__ __forceinline__ double matM_comp(const GridDev& g, At at)
 {
   constexpr int A = (C + 1) % 3, B = (C + 2) % 3;
   const double ih[3] = {g.inv[0], g.inv[1], g.inv[2]}; // 1 / d, formed once on the host (the same quotient)
-  auto at = [&](int comp, int ox, int oy, int oz) { return F[comp * g.cstride + g.nodew(x + ox, y + oy, z + oz)]; };
   auto sh = [&](int axis, int s, int& ox, int& oy, int& oz) { (axis == 0 ? ox : (axis == 1 ? oy : oz)) += s; };
   // G_comp at offset (ox,oy,oz): forward differences
   auto dplus = [&](int comp, int axis, int ox, int oy, int oz) {
@@ -423,10 +482,28 @@ __device__ __forceinline__ double matM_comp(const GridDev& g, const double* __re
   return 2.0 * at(C, 0, 0, 0) + (0.5 * g.dt * g.dt) * r;
 }
 
-constexpr int kRowX = 64, kRowY = 4;
-constexpr int kBandY = 4; // y-chunks per band: 16 rows
+// the rows of component C1 of one workgroup: stage the operand, then every live thread its row
+template <bool WITH_M, int C1>
+__device__ __forceinline__ void rows_of(const GridDev& g, const double* __restrict__ L, const double* __restrict__ X,
+  double* __restrict__ Y, double* tile, int add, int x0, int y0, int z, int tx, int ty)
+{
+  xtile_fill_c<C1, 0>(g, X, tile, x0, y0, z, tx, ty);
+  xtile_fill_c<C1, 1>(g, X, tile, x0, y0, z, tx, ty);
+  xtile_fill_c<C1, 2>(g, X, tile, x0, y0, z, tx, ty);
+  __syncthreads();
+  const int x = x0 + tx, y = y0 + ty;
+  if (x >= g.nx || y >= g.ny) return;
+  const int lb[3] = {ty * XTile<C1>::nx(0) + tx, ty * XTile<C1>::nx(1) + tx, ty * XTile<C1>::nx(2) + tx};
+  double r = 0.0;
+  // (matM's 13 taps lie inside matL's pattern: the same tile serves them)
+  if (WITH_M) r = matM_comp<C1>(g, [&](int comp, int ox, int oy, int oz) { return tile[lb[comp] + XTile<C1>::at(comp, ox, oy, oz)]; });
+  r += row_apply<C1>(std::make_integer_sequence<int, kLStencil>{}, g, L, tile, lb, x, y, z);
+  const long o = C1 * g.cstride + g.node(x, y, g.wz(z));
+  if (add) Y[o] += r;
+  else Y[o] = r;
+}
 
-template <bool WITH_L, bool WITH_M>
+template <bool WITH_M>
 __global__ void __launch_bounds__(kRowX* kRowY, 4) k_matA(GridDev g, const double* __restrict__ L,
   const double* __restrict__ X, double* __restrict__ Y, int add, int z0r, int nzr, int zsplit)
 {
@@ -435,6 +512,7 @@ __global__ void __launch_bounds__(kRowX* kRowY, 4) k_matA(GridDev g, const doubl
   // run of z-planes, and inside the run a band of 16 y-rows at a time along z: the operand footprint of a band
   // (20 rows x 5 planes x 3 components) stays in that XCD's 4 MiB L2 while the coefficient streams pass through.
   // Order inside a band position: component fastest (the three rows of a node share their operand footprint), x, y.
+  __shared__ double tile[kXTileMax];
   const int nxc = (g.nx + kRowX - 1) / kRowX, nyc = (g.ny + kRowY - 1) / kRowY;
   const int nyt = (nyc + kBandY - 1) / kBandY;         // y-bands
   // the 8 XCDs split the planes zsplit ways and the y-bands 8 / zsplit ways (row_split: whatever leaves the least idle;
@@ -452,29 +530,15 @@ __global__ void __launch_bounds__(kRowX* kRowY, 4) k_matA(GridDev g, const doubl
   const int z = z0r + zr;
   const int rem2 = rem % per_z;
   const int c1 = rem2 % 3;
-  const int x = ((rem2 / 3) % nxc) * kRowX + threadIdx.x;
-  // y is the same for the 64 lanes of a wave (blockDim.x == 64): tell the compiler, so that every row base
-  // below is scalar arithmetic
-  const int y = (yt * kBandY + rem2 / (3 * nxc)) * kRowY + __builtin_amdgcn_readfirstlane(threadIdx.y);
-  if (ytl >= Pb || yt >= nyt || zr >= nzr) return;
-  if (x >= g.nx || y >= g.ny) return;
-  using Seq = std::make_integer_sequence<int, kLStencil>;
-  double r = 0.0;
-  if (c1 == 0) {
-    if (WITH_M) r = matM_comp<0>(g, X, x, y, z);
-    if (WITH_L) r += row_apply<0>(Seq{}, g, L, X, x, y, z);
-  }
-  else if (c1 == 1) {
-    if (WITH_M) r = matM_comp<1>(g, X, x, y, z);
-    if (WITH_L) r += row_apply<1>(Seq{}, g, L, X, x, y, z);
-  }
-  else {
-    if (WITH_M) r = matM_comp<2>(g, X, x, y, z);
-    if (WITH_L) r += row_apply<2>(Seq{}, g, L, X, x, y, z);
-  }
-  const long o = c1 * g.cstride + g.node(x, y, g.wz(z));
-  if (add) Y[o] += r;
-  else Y[o] = r;
+  const int x0 = ((rem2 / 3) % nxc) * kRowX;
+  const int y0 = (yt * kBandY + rem2 / (3 * nxc)) * kRowY;
+  if (ytl >= Pb || yt >= nyt || zr >= nzr) return; // (the whole workgroup: nothing here depends on the thread)
+  // the wave index is the same for the 64 lanes of a wave (blockDim.x == 64): tell the compiler, so that every row base is
+  // scalar arithmetic
+  const int tx = threadIdx.x, ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  if (c1 == 0) rows_of<WITH_M, 0>(g, L, X, Y, tile, add, x0, y0, z, tx, ty);
+  else if (c1 == 1) rows_of<WITH_M, 1>(g, L, X, Y, tile, add, x0, y0, z, tx, ty);
+  else rows_of<WITH_M, 2>(g, L, X, Y, tile, add, x0, y0, z, tx, ty);
 }
 
 // Divergence, negative Yee shift (src/utils/operators.cpp:275-333), added into component 0 of `out`;
@@ -708,7 +772,7 @@ int matL_apply(xpic_ctx* c, const double* x, double* y, bool add)
 {
   Timed t(c, "matL_apply");
   const int zs = row_split(c->g, c->g.nzl);
-  hipLaunchKernelGGL((k_matA<true, false>), row_grid(c->g, c->g.nzl, zs), dim3(kRowX, kRowY), 0, c->stream, c->g, c->matL, x, y,
+  hipLaunchKernelGGL((k_matA<false>), row_grid(c->g, c->g.nzl, zs), dim3(kRowX, kRowY), 0, c->stream, c->g, c->matL, x, y,
     add ? 1 : 0, 0, c->g.nzl, zs);
   XPIC_HIP(hipGetLastError());
   return 0;
@@ -718,7 +782,7 @@ static int matA_planes(xpic_ctx* c, const double* x, double* y, int z0r, int nzr
 {
   if (nzr <= 0) return 0;
   const int zs = row_split(c->g, nzr);
-  hipLaunchKernelGGL((k_matA<true, true>), row_grid(c->g, nzr, zs), dim3(kRowX, kRowY), 0, c->stream, c->g, c->matL, x, y, 0, z0r,
+  hipLaunchKernelGGL((k_matA<true>), row_grid(c->g, nzr, zs), dim3(kRowX, kRowY), 0, c->stream, c->g, c->matL, x, y, 0, z0r,
     nzr, zs);
   XPIC_HIP(hipGetLastError());
   return 0;

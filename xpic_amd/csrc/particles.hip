@@ -13,6 +13,8 @@
 
 namespace xpic {
 
+int experiment_particles() { return XPIC_TU_EXPERIMENT; }
+
 namespace {
 
 constexpr int kBlock = 256;

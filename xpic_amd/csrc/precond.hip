@@ -26,6 +26,8 @@
 
 namespace xpic {
 
+int experiment_precond() { return XPIC_TU_EXPERIMENT; }
+
 namespace {
 
 constexpr int kB = 256;
