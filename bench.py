@@ -657,7 +657,7 @@ def rank_body(args, rank, world, local_rank, job):
         spmv = {
             "kernel": "k_matA (matL+matM SpMV)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(args.scheme, n3, "k_matA<true, true>") if world == 1 else None,
+            "traffic": pmc_traffic(args.scheme, n3, "k_matA<true>") if world == 1 else None,
             "bytes_per_launch": bytes_apply, "launches": n_apply, "avg_ms": ms_apply / n_apply,
         }
     esk = {}

@@ -14,7 +14,7 @@ for r in csv.DictReader(open(f)):
     m = re.search(r"(k_[A-Za-z0-9_]+(<[^>]*>)?)", r["Kernel_Name"])
     if m:
         agg[m.group(1)].append(float(r["Counter_Value"]))
-for k in ("k_matA<true, true>", "k_ecsim_fill<true, true>", "k_scatter<true, true>", "k_second_push<true, false, true>", "k_cheb_bar<false, false, true>"):
+for k in ("k_matA<true>", "k_ecsim_fill<true, true>", "k_scatter<true, true>", "k_second_push<true, false, true>", "k_cheb_bar<false, false, true>"):
     if k in agg:
         print("%-28s %-34s %14.4g per launch (%d launches)" % (sys.argv[2], k, sum(agg[k]) / len(agg[k]), len(agg[k])))
 P
