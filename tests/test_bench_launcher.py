@@ -116,8 +116,10 @@ def test_eight_rank_rehearsal_in_one_process():
     assert line["phase_ms_per_step"]["halo"] > 0 and line["phase_ms_per_step"]["migrate"] > 0
     # one per Krylov iteration + the fixed ones of a step (norm of the right-hand side, initial residual, the surrogate's
     # sums, the migration's flags) + the explicit norms of the last iterations (residual below 1e-6 of the right-hand side:
-    # krylov.hip's rule); classical Gram-Schmidt with a separate norm would be 2 per iteration + the fixed ones
-    assert line["allreduces_per_step"] <= its + 6
+    # krylov.hip's rule) + the assembly's error word + -- at 8 particles per cell the spread of matL's diagonal is above the
+    # default preconditioner's threshold -- the largest density ratio of the scaled surrogate; classical Gram-Schmidt with
+    # a separate norm would be 2 per iteration + the fixed ones
+    assert line["allreduces_per_step"] <= its + 8
 
 
 @pytest.mark.gpu
