@@ -165,6 +165,32 @@ def test_fill_current_and_matL(oracle, B0, grid):
     assert np.abs(g.get_field(X.W2) - ref).max() <= 1e-12 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("n", [(70, 6, 5), (132, 5, 7), (64, 9, 4)], ids=["70x6x5", "132x5x7", "64x9x4"])
+def test_row_kernel_on_rows_longer_than_a_wave(oracle, n):
+    """k_matA stages the operand's neighbourhood of a workgroup's 4 x 64 rows in LDS: rows longer than one chunk of 64 (a
+    second, partial chunk whose tile wraps around the periodic x edge; two full chunks and a short third), y extents that
+    are not a multiple of the 4 rows of a workgroup, and the single exact chunk -- matL x and (matL + matM) x against the
+    oracle's products on the assembled matrix, as on the standard grids."""
+    import xpic_amd as X
+
+    d, dt = (0.5, 0.4, 0.25), 0.7
+    o, g = make_pair(oracle, "ecsim", n, d, dt, [(4, 1.0, -1.0, 1.0)], ppc=4, B0=(0.3, -0.2, 0.9))
+    oracle.lib().orc_ecsim_fill_current(o.h)
+    g.ecsim_fill_current()
+    Lo, Lg = o.matL(), g.matL()
+    assert np.abs(Lo).max() > 0 and np.abs(Lo - Lg).max() <= 1e-12 * np.abs(Lo).max()
+    x = o.get_field("E")
+    g.matL_apply(X.E, X.W2)
+    ref = o.matL_apply(x)
+    assert np.abs(g.get_field(X.W2) - ref).max() <= 1e-12 * np.abs(ref).max()
+    g.matA_apply(X.E, X.W2)
+    ref = ref + o.matM(x)
+    assert np.abs(g.get_field(X.W2) - ref).max() <= 1e-12 * np.abs(ref).max()
+    g.matL_apply(X.E, X.W2, add=True)
+    ref = ref + o.matL_apply(x)
+    assert np.abs(g.get_field(X.W2) - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
 @BOTH_GRIDS
 def test_both_assembly_kernels_match_the_oracle(oracle, grid):
     """The warp-specialised assembly (xpic_set_fill_kernel 1, where nx % 4 == 0) and the classic kernel (the default) on
