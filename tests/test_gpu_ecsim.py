@@ -421,7 +421,8 @@ def test_preconditioner_with_the_mean_mass_matrix(oracle, kind):
     x3 = g.get_field(X.W2)
     assert np.abs(xo - x3).max() <= 1e-6 * np.abs(xo).max()
     res = np.linalg.norm(o.matM(x3) + o.matL_apply(x3) - rhs)
-    assert res <= 1.05e-7 * np.linalg.norm(rhs) and abs(res - rn3) <= 0.2 * rn3  # the reported norm is the true residual
+    # the reported norm is the true residual up to the recurrence's own error (one-reduction Gram-Schmidt: 1e-8 |b| at this depth)
+    assert res <= 1.05e-7 * np.linalg.norm(rhs) and abs(res - rn3) <= 1e-8 * np.linalg.norm(rhs)
     # tight tolerance: the fp32 polynomial does not limit the residual that can be reached
     _, reason_t, _ = g.solve(0, X.E, X.W1, 1e-12, 1e-50, 300)
     xt = g.get_field(X.W1)

@@ -23,7 +23,7 @@
   defined(ESK_DRAIN0) || defined(ESK_TILE_LATE) || defined(XPIC_CHEB_MIN_ZC) || defined(BAR_SCHED_SCALED) || defined(BAR_SCHED_GROUP) || \
   defined(XPIC_MAX_PER_Z) || defined(XPIC_SLAB_FIRST_TOUCH) || defined(XPIC_CHEB_M_BOUND) || defined(XPIC_BUCKET_CAP) || \
   defined(XPIC_DEFAULT_FUSED_REBIN) || defined(XPIC_DEFAULT_PRECOND) || defined(XPIC_DEFAULT_FILL_KERNEL) || defined(MATA_GROUP) || \
-  defined(MATA_DEPTH))
+  defined(MATA_DEPTH) || defined(BAR_TRUNCATE))
 #error "a build switch of the kernels was set on the command line: that is an experiment build, add -DXPIC_EXPERIMENT"
 #endif
 #ifdef XPIC_EXPERIMENT

@@ -178,11 +178,41 @@ __global__ void k_abar(const double* __restrict__ sums, const double* __restrict
 constexpr int kTX = 128, kTY = 4, kH = 2, kPX = kTX + 2 * kH, kPY = kTY + 2 * kH, kZW = 6;
 constexpr int kPlaneF = 3 * kPY * kPX; // floats of one window plane
 
+// Which taps of the 123-pattern the polynomial's stencil keeps (round 5).  The translation average of matL is, up to its
+// sampling noise, a(c1, c2) times a PRODUCT of per-axis CIC overlaps (checked against the CPU restatement's matL: 3e-3 of
+// the largest entry on a 10^3 box, the noise of 1 000 rows): between equally staggered components (1/6, 2/3, 1/6), between
+// a component staggered along the axis and one that is not (1/48, 23/48, 23/48, 1/48).  In a block c2 != c1 every tap that
+// carries a 1/48 -- d[c1] outside {0, 1} or d[c2] outside {-1, 0} -- is 2 % of its neighbours; together they hold
+// 1 - (46/48)^2 = 8 % of a block that is itself the rotation part of the particle matrix (a tenth of the diagonal block at
+// the reference's field): 36 of the 48 taps for 0.4 % of the row.  They are dropped and their sum is spread over the 12
+// that stay (k_abar), so the block's sum -- what a smooth field sees -- is kept: 51 taps per row instead of 123 in a
+// kernel that is short of vector issue slots (profiles/r05_pmc_sq_solve.txt).  The diagonal blocks and matM's taps (a
+// subset of the kept pattern) are untouched.
+#ifndef BAR_TRUNCATE
+#define BAR_TRUNCATE 1
+#endif
+// (Measured at 256^3 x 64, the solve's residuals after 1 .. 6 iterations are the same to three digits with and without
+// the dropped taps -- 3.92e-8 against 3.91e-8 |b| at the fourth -- and the polynomial's 28 steps take 7.5 instead of 10.3 ms.
+// Dropping more -- the eight corners of the diagonal blocks, the third axis' outer taps of the others: 27 taps per row --
+// left the fourth residual at 4.04e-8 / 4.24e-8 and the time at 7.5 / 7.1 ms: the kernel is at its vector traffic by
+// then, and those taps are not negligible for a strong field or a dense plasma.  Not taken.)
+__host__ __device__ constexpr bool tap_kept(int c1, int c2, int dx, int dy, int dz)
+{
+  if (!BAR_TRUNCATE || c1 == c2) return true;
+  const int d[3] = {dx, dy, dz};
+  return (d[c1] == 0 || d[c1] == 1) && (d[c2] == 0 || d[c2] == -1);
+}
+// the tap exists in the polynomial's stencil
+__host__ __device__ constexpr bool tap_in(int c1, int c2, int dx, int dy, int dz)
+{
+  return lencode(c1, c2, dx, dy, dz) >= 0 && tap_kept(c1, c2, dx, dy, dz);
+}
+
 __host__ __device__ constexpr bool line_used(int c2, int dy, int dz)
 {
   for (int c1 = 0; c1 < 3; ++c1)
     for (int dx = -2; dx <= 2; ++dx)
-      if (lencode(c1, c2, dx, dy, dz) >= 0) return true;
+      if (tap_in(c1, c2, dx, dy, dz)) return true;
   return false;
 }
 
@@ -205,7 +235,7 @@ constexpr int kLinesUsed = line_slot(75);
 __host__ __device__ constexpr int tap_pos(int c2, int dz, int dy, int I)
 {
   int n = 0;
-  for (int i = 0; i < I; ++i) n += lencode(i % 3, c2, i / 3 - 2, dy, dz) >= 0 ? 1 : 0;
+  for (int i = 0; i < I; ++i) n += tap_in(i % 3, c2, i / 3 - 2, dy, dz) ? 1 : 0;
   return n;
 }
 
@@ -261,11 +291,26 @@ __global__ void k_abar(const double* __restrict__ sums, const double* __restrict
   if (i >= 3 * kLPad) return;
   const int c1 = i / kLPad, k = i % kLPad;
   const double v = mco[i] + sums[i] * inv_count * (k < kLStencil ? lscale : 1.0); // (lscale = 1 but in the probation test)
-  abar64[i] = v;
+  abar64[i] = v; // (the full pattern: the host's spectral bounds are taken on it -- the kept taps' absolute sums are no larger)
   if (k >= kLStencil) return;
   const LEntry e = ldecode(c1, k);
+  if (!tap_kept(c1, e.c2, e.d[0], e.d[1], e.d[2])) return;
+  // the kept taps of a block share the sum of its dropped ones in proportion (tap_kept; matM has no dropped tap)
+  double keep = 1.0;
+  if (BAR_TRUNCATE && e.c2 != c1) {
+    double all = 0.0, kept = 0.0;
+    const int k0 = lblock_offset(c1, e.c2);
+    for (int kk = k0; kk < k0 + 48; ++kk) {
+      const LEntry f = ldecode(c1, kk);
+      all += sums[c1 * kLPad + kk];
+      if (tap_kept(c1, f.c2, f.d[0], f.d[1], f.d[2])) kept += sums[c1 * kLPad + kk];
+    }
+    // (a block without weight, or whose kept taps cancel: leave it as it is)
+    if (kept != 0.0 && fabs(all) <= 4.0 * fabs(kept)) keep = all / kept;
+  }
+  const double vk = mco[i] + keep * sums[i] * inv_count * lscale;
   const int L = (e.c2 * 5 + e.d[2] + 2) * 5 + e.d[1] + 2;
-  packed[line_slot(L) * kCoefPitch + tap_pos(e.c2, e.d[2], e.d[1], (e.d[0] + 2) * 3 + c1)] = (float)v;
+  packed[line_slot(L) * kCoefPitch + tap_pos(e.c2, e.d[2], e.d[1], (e.d[0] + 2) * 3 + c1)] = (float)vk;
   // matM's own coefficients, packed per line behind the full table (kind 4)
   if (is_matM_tap(c1, e.c2, e.d[0], e.d[1], e.d[2]))
     packed[kLinesUsed * kCoefPitch + mline_slot(L) * kMPitch + mtap_pos(e.c2, e.d[2], e.d[1], (e.d[0] + 2) * 3 + c1)] = (float)mco[i];
@@ -297,7 +342,7 @@ __device__ __forceinline__ void bar_tap(float (&acc)[2][3], float (&accM)[2][3],
   const float (&cm)[kMPitch])
 {
   constexpr int dx = I / 3 - 2, c1 = I % 3;
-  if constexpr (lencode(c1, C2, dx, DY, DZ) >= 0) {
+  if constexpr (tap_in(c1, C2, dx, DY, DZ)) {
     constexpr int pos = tap_pos(C2, DZ, DY, I);
     const float a = cf[pos];
     acc[0][c1] += a * v[dx + 2];
