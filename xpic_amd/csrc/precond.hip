@@ -545,11 +545,12 @@ int halo_fill_f32(xpic_ctx* c, float* f, int width);
 
 namespace {
 
-// rows of the translation average: every 4th row in y and z of extents that have 16
+// rows of the translation average: every 4th row in y and z of extents that have 16, every 8th of extents that have 64
+// (256^3: 3 x 262 144 rows x 256 nodes, the average's own noise 1e-4 of an entry; the pass reads 0.8 GB instead of 3.1)
 inline void lbar_rows(const GridDev& g, int* sy, int* sz, int* nys, int* nrows)
 {
-  *sy = g.ny >= 16 ? 4 : 1;
-  *sz = g.nzl >= 16 ? 4 : 1;
+  *sy = g.ny >= 64 ? 8 : (g.ny >= 16 ? 4 : 1);
+  *sz = g.nzl >= 64 ? 8 : (g.nzl >= 16 ? 4 : 1);
   *nys = (g.ny + *sy - 1) / *sy;
   *nrows = *nys * ((g.nzl + *sz - 1) / *sz);
 }
