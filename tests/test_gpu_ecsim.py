@@ -512,6 +512,34 @@ def test_unproven_surrogate_runs_on_probation(oracle):
     g.debug_set(X.DEBUG_SURROGATE_SCALE, 1000)
 
 
+def test_surrogate_in_a_strong_magnetic_field(oracle):
+    """The polynomial's stencil keeps 51 of the 123 taps of <matL>: of the blocks between different components -- the
+    rotation part of the particle matrix -- the 12 taps that do not carry a 1/48 CIC overlap, with the block's sum spread
+    over them (precond.hip: tap_kept).  Those blocks are a tenth of the diagonal ones at the reference's field and as large
+    as them where the gyro-frequency times dt / 2 reaches 1: there (B = (0.5, -1, 2), dt = 1) the default preconditioner
+    must still beat the polynomial in matM alone by a wide margin, run without fall-back, and return the oracle's solution
+    with the true residual inside the tolerance."""
+    import xpic_amd as X
+
+    n, d = (12, 10, 8), (0.5, 0.5, 0.5)
+    o, g = make_pair(oracle, "ecsim", n, d, 1.0, [(64, 1.0, -1.0, 1.0)], ppc=64, vth=0.014, B0=(0.5, -1.0, 2.0))
+    oracle.lib().orc_ecsim_fill_current(o.h)
+    g.ecsim_fill_current()
+    rhs = o.get_field("E")
+    xo, its_o, _ = o.solve(0, rhs, 1e-9, 1e-50, 400)
+    g.profile_enable(True)
+    g.set_preconditioner(1)
+    its1, reason1, _ = g.solve(0, X.E, X.W2, 1e-7, 1e-50, 400)
+    g.set_preconditioner(5)
+    g.profile_reset()
+    its5, reason5, _ = g.solve(0, X.E, X.W2, 1e-7, 1e-50, 400)
+    assert reason1 > 0 and reason5 > 0 and g.profile_get("precond_fallback")[0] == 0
+    assert its5 <= 6 and its5 <= its1 - 2, (its1, its5, its_o)
+    x = g.get_field(X.W2)
+    assert np.abs(xo - x).max() <= 1e-6 * np.abs(xo).max()
+    assert np.linalg.norm(o.matM(x) + o.matL_apply(x) - rhs) <= 1.05e-7 * np.linalg.norm(rhs)
+
+
 def test_default_step_uses_preconditioner_and_matches_oracle(oracle):
     import xpic_amd as X
 
